@@ -1,0 +1,942 @@
+// phd_api.cpp — the C-ABI of include/phdslam.h over the gfx950 kernels.
+//
+// One phd_filter owns every device buffer of one rank's particle shard for the whole run
+// (the reference allocates and frees ~22 buffers per update, src/phdfilter.cu:2966-3102,
+// 3403-3438,3525-3552).  All work is enqueued on one HIP stream; nothing in the per-step
+// path allocates, frees or synchronises.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "phd_device.h"
+#include "phdslam.h"
+
+using namespace phd;
+
+// layout checks against the reference's src/slamtypes.h (offsets measured from the reference header)
+static_assert(sizeof(phd_gaussian2d) == 28, "Gaussian2D layout");
+static_assert(sizeof(phd_pose) == 24, "ConstantVelocityState layout");
+static_assert(sizeof(phd_measurement) == 12, "RangeBearingMeasurement layout");
+static_assert(sizeof(phd_slam_config) == 324, "SlamConfig layout");
+static_assert(offsetof(phd_slam_config, dt) == 80, "SlamConfig.dt");
+static_assert(offsetof(phd_slam_config, minRange) == 84, "SlamConfig.minRange");
+static_assert(offsetof(phd_slam_config, n_particles) == 196, "SlamConfig.n_particles");
+static_assert(offsetof(phd_slam_config, birthWeight) == 212, "SlamConfig.birthWeight");
+static_assert(offsetof(phd_slam_config, minSeparation) == 232, "SlamConfig.minSeparation");
+static_assert(offsetof(phd_slam_config, filterType) == 260, "SlamConfig.filterType");
+static_assert(offsetof(phd_slam_config, labeledMeasurements) == 292, "SlamConfig.labeledMeasurements");
+static_assert(offsetof(phd_slam_config, l) == 296, "SlamConfig.l");
+static_assert(offsetof(phd_slam_config, saveAllMaps) == 320, "SlamConfig.saveAllMaps");
+
+static thread_local std::string g_err;
+
+extern "C" const char* phd_last_error(void) { return g_err.c_str(); }
+extern "C" const char* phd_version(void) { return "cuda-phdslam_amd 0.1 (gfx950)"; }
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+// used by phd_host.cpp (config / loaders / log writer) to report through the same channel
+extern "C" int phd_internal_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(PHD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+struct TimedEvent {
+    hipEvent_t a, b;
+    int kind;
+};
+
+struct phd_filter {
+    phd_slam_config cfg;
+    DevConfig dcfg;
+    int n = 0, cap = 0, MM = 0, S_cap = 0, device = 0;
+    int n_global = 0, global_offset = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    size_t lds_bytes = 0;
+
+    float* maps[2] = {nullptr, nullptr};
+    int* counts[2] = {nullptr, nullptr};
+    int cur = 0;
+    int* parent[3] = {nullptr, nullptr, nullptr}; // [pcur] live, [pcur^1] next, [2] frozen scratch
+    int pcur = 0;
+    bool parent_dirty = false;
+    phd_pose* pose[3] = {nullptr, nullptr, nullptr}; // [pose_cur] live, other: next / scratch
+    int pose_cur = 0;
+    float* logw = nullptr;
+    float* logw_scratch = nullptr;
+    float* logw_raw = nullptr;
+    float* dlogw = nullptr;
+    phd_measurement* d_z = nullptr;
+    phd_ackerman_noise* d_noise = nullptr;
+    double* d_uniforms = nullptr; // n entries
+    double* cdf = nullptr;        // n_global entries
+    int* idx = nullptr;           // n_global entries
+    float* neff = nullptr;
+    int* did = nullptr;
+    float* state_pose = nullptr;
+    int* state_argmax = nullptr;
+    unsigned* status = nullptr;
+    int* max_surv = nullptr;
+    int* max_map = nullptr;
+    int* d_tmp_int = nullptr; // n entries (selection / slot lists)
+    // staging for AoS <-> SoA
+    phd_gaussian2d* d_concat = nullptr;
+    size_t concat_cap = 0;
+    int* d_offsets = nullptr;
+    int* d_sizes = nullptr;
+    // inspection
+    bool debug = false;
+    float* dbg_surv = nullptr;
+    int* dbg_u = nullptr;
+    int* dbg_n = nullptr;
+    int* dbg_nin = nullptr;
+    int last_M = 0;
+
+    bool frozen = false;
+    uint64_t seed = 0x5EED, counter = 0;
+    const phd_pose* pose_for_update = nullptr; // set by a frozen predict
+
+    bool timing = false;
+    std::vector<TimedEvent> events;
+    double t_ms[PHD_K_COUNT] = {0, 0, 0};
+    int64_t t_n[PHD_K_COUNT] = {0, 0, 0};
+};
+
+static void fill_devcfg(const phd_slam_config& c, DevConfig& d)
+{
+    d.dt = c.dt;
+    d.minRange = c.minRange; d.maxRange = c.maxRange; d.maxBearing = c.maxBearing;
+    d.stdRange = c.stdRange; d.stdBearing = c.stdBearing;
+    d.clutterDensity = c.clutterDensity; d.pd = c.pd;
+    d.birthWeight = c.birthWeight; d.birthNoiseFactor = c.birthNoiseFactor;
+    d.minFeatureWeight = c.minFeatureWeight; d.minSeparation = c.minSeparation;
+    d.l = c.l; d.h = c.h; d.a = c.a; d.b = c.b;
+    d.stdAlpha = c.stdAlpha; d.stdEncoder = c.stdEncoder;
+    d.subdividePredict = c.subdividePredict > 0 ? c.subdividePredict : 1;
+    d.distanceMetric = c.distanceMetric;
+    d.labeledMeasurements = c.labeledMeasurements ? 1 : 0;
+}
+
+static int check_supported(const phd_slam_config& c)
+{
+    // branches SURVEY.md §2 marks out of scope fail loudly instead of silently running something else
+    if (c.featureModel != 0) return fail(PHD_ERR_UNSUPPORTED, "feature_model != 0 (dynamic/mixed features) is not supported");
+    if (c.particleWeighting != 0) return fail(PHD_ERR_UNSUPPORTED, "particle_weighting != 0 is not supported");
+    if (c.motionType != 1) return fail(PHD_ERR_UNSUPPORTED, "motion_type != 1 (Ackerman) is not supported");
+    if (c.filterType != 0) return fail(PHD_ERR_UNSUPPORTED, "filter_type != 0 (CPHD) is not supported in this build");
+    if (c.distanceMetric != 0 && c.distanceMetric != 1) return fail(PHD_ERR_INVALID_ARG, "distance_metric must be 0 or 1");
+    if (c.nPredictParticles > 1) return fail(PHD_ERR_UNSUPPORTED, "n_predict_particles > 1 is not supported in this build");
+    return PHD_OK;
+}
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t n)
+{
+    return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+static int next_pow2(int x)
+{
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, phd_filter** out)
+{
+    if (!cfg || !out) return fail(PHD_ERR_INVALID_ARG, "phd_create: null argument");
+    int rc = check_supported(*cfg);
+    if (rc) return rc;
+    phd_options o;
+    memset(&o, 0, sizeof(o));
+    if (opt) o = *opt;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PHD_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+    if (o.device < 0 || o.device >= ndev) return fail(PHD_ERR_INVALID_ARG, "phd_create: bad device ordinal");
+    HIPCHK(hipSetDevice(o.device));
+
+    phd_filter* f = new phd_filter();
+    f->cfg = *cfg;
+    fill_devcfg(*cfg, f->dcfg);
+    f->device = o.device;
+    f->n = o.n_particles > 0 ? o.n_particles : cfg->n_particles;
+    f->cap = o.map_capacity > 0 ? o.map_capacity : 256;
+    f->MM = o.max_measurements > 0 ? std::min(o.max_measurements, PHD_MAX_MEASUREMENTS) : PHD_MAX_MEASUREMENTS;
+    f->n_global = o.global_particles > 0 ? o.global_particles : f->n;
+    f->global_offset = o.global_offset;
+    if (f->n <= 0) { delete f; return fail(PHD_ERR_INVALID_ARG, "phd_create: n_particles <= 0"); }
+    if (f->cap > 65535) { delete f; return fail(PHD_ERR_INVALID_ARG, "phd_create: map_capacity > 65535"); }
+    int S = o.survivor_capacity > 0 ? o.survivor_capacity : (f->cap + 8 * f->MM);
+    S = next_pow2(std::max(S, 64));
+    if (S > 2048) S = 2048; // register-staged permutation in merge_in_lds handles <= 2048
+    f->S_cap = S;
+    f->lds_bytes = update_lds_bytes(f->S_cap, f->cap, f->MM);
+    if (f->lds_bytes > 160 * 1024) {
+        delete f;
+        return fail(PHD_ERR_CAPACITY, "phd_create: map_capacity/survivor_capacity need more than 160 KiB of LDS");
+    }
+    if (o.stream) {
+        f->stream = (hipStream_t)o.stream;
+    } else {
+        if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete f;
+            return fail(PHD_ERR_HIP, "hipStreamCreate failed");
+        }
+        f->own_stream = true;
+    }
+    const size_t slab = (size_t)f->n * 6 * f->cap;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
+    for (int k = 0; k < 2; ++k) { A(dalloc(&f->maps[k], slab)); A(dalloc(&f->counts[k], f->n)); }
+    for (int k = 0; k < 3; ++k) { A(dalloc(&f->parent[k], f->n)); A(dalloc(&f->pose[k], f->n)); }
+    A(dalloc(&f->logw, f->n)); A(dalloc(&f->logw_scratch, std::max(f->n, f->n_global)));
+    A(dalloc(&f->logw_raw, f->n)); A(dalloc(&f->dlogw, f->n));
+    A(dalloc(&f->d_z, f->MM)); A(dalloc(&f->d_noise, f->n));
+    A(dalloc(&f->d_uniforms, std::max(f->n, f->n_global)));
+    A(dalloc(&f->cdf, std::max(f->n, f->n_global)));
+    A(dalloc(&f->idx, std::max(f->n, f->n_global)));
+    A(dalloc(&f->neff, 1)); A(dalloc(&f->did, 1));
+    A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
+    A(dalloc(&f->status, 1)); A(dalloc(&f->max_surv, 1)); A(dalloc(&f->max_map, 1));
+    A(dalloc(&f->d_tmp_int, f->n));
+    A(dalloc(&f->d_offsets, f->n + 1)); A(dalloc(&f->d_sizes, f->n));
+    if (e != hipSuccess) {
+        phd_destroy(f);
+        return fail(PHD_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(e));
+    }
+    hipMemsetAsync(f->maps[0], 0, slab * sizeof(float), f->stream);
+    hipMemsetAsync(f->maps[1], 0, slab * sizeof(float), f->stream);
+    hipMemsetAsync(f->counts[0], 0, f->n * sizeof(int), f->stream);
+    hipMemsetAsync(f->counts[1], 0, f->n * sizeof(int), f->stream);
+    hipMemsetAsync(f->status, 0, 4, f->stream);
+    hipMemsetAsync(f->max_surv, 0, 4, f->stream);
+    hipMemsetAsync(f->max_map, 0, 4, f->stream);
+    for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n, f->stream);
+    // initial particles: cfg pose, weights -log N (src/main.cpp:1130-1145)
+    std::vector<phd_pose> p0(f->n);
+    std::vector<float> w0(f->n, -logf((float)f->n_global));
+    for (auto& q : p0) { q.px = cfg->x0; q.py = cfg->y0; q.ptheta = cfg->yaw0; q.vx = cfg->vx0; q.vy = cfg->vy0; q.vtheta = cfg->vyaw0; }
+    hipMemcpyAsync(f->pose[0], p0.data(), f->n * sizeof(phd_pose), hipMemcpyHostToDevice, f->stream);
+    hipMemcpyAsync(f->logw, w0.data(), f->n * sizeof(float), hipMemcpyHostToDevice, f->stream);
+    if (hipStreamSynchronize(f->stream) != hipSuccess) {
+        phd_destroy(f);
+        return fail(PHD_ERR_HIP, "initialisation failed");
+    }
+    *out = f;
+    return PHD_OK;
+}
+
+extern "C" int phd_destroy(phd_filter* f)
+{
+    if (!f) return PHD_OK;
+    hipSetDevice(f->device);
+    if (f->stream) hipStreamSynchronize(f->stream);
+    for (auto& ev : f->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (int k = 0; k < 2; ++k) { hipFree(f->maps[k]); hipFree(f->counts[k]); }
+    for (int k = 0; k < 3; ++k) { hipFree(f->parent[k]); hipFree(f->pose[k]); }
+    hipFree(f->logw); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
+    hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
+    hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
+    hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int);
+    hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
+    hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin);
+    if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
+    delete f;
+    return PHD_OK;
+}
+
+#define CHECK_F(f)                                                       \
+    do {                                                                 \
+        if (!(f)) return fail(PHD_ERR_INVALID_ARG, "null filter handle"); \
+        HIPCHK(hipSetDevice((f)->device));                               \
+    } while (0)
+
+extern "C" int phd_set_config(phd_filter* f, const phd_slam_config* cfg)
+{
+    CHECK_F(f);
+    if (!cfg) return fail(PHD_ERR_INVALID_ARG, "null config");
+    int rc = check_supported(*cfg);
+    if (rc) return rc;
+    f->cfg = *cfg;
+    fill_devcfg(*cfg, f->dcfg); // kernel argument from now on; nothing to upload
+    return PHD_OK;
+}
+
+extern "C" int phd_seed(phd_filter* f, uint64_t seed)
+{
+    CHECK_F(f);
+    f->seed = seed;
+    f->counter = 0;
+    return PHD_OK;
+}
+
+extern "C" int phd_n_particles(const phd_filter* f) { return f ? f->n : PHD_ERR_INVALID_ARG; }
+extern "C" int phd_map_capacity(const phd_filter* f) { return f ? f->cap : PHD_ERR_INVALID_ARG; }
+extern "C" void* phd_stream(phd_filter* f) { return f ? (void*)f->stream : nullptr; }
+
+extern "C" int phd_sync(phd_filter* f)
+{
+    CHECK_F(f);
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// timing helpers
+// ---------------------------------------------------------------------------------------------
+static void t_begin(phd_filter* f, int kind)
+{
+    if (!f->timing) return;
+    TimedEvent ev;
+    ev.kind = kind;
+    hipEventCreate(&ev.a);
+    hipEventCreate(&ev.b);
+    hipEventRecord(ev.a, f->stream);
+    f->events.push_back(ev);
+}
+static void t_end(phd_filter* f)
+{
+    if (!f->timing) return;
+    hipEventRecord(f->events.back().b, f->stream);
+}
+static void t_collect(phd_filter* f)
+{
+    for (auto& ev : f->events) {
+        float ms = 0.f;
+        hipEventSynchronize(ev.b);
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { f->t_ms[ev.kind] += ms; f->t_n[ev.kind] += 1; }
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    f->events.clear();
+}
+
+extern "C" int phd_timing_enable(phd_filter* f, int enable)
+{
+    CHECK_F(f);
+    if (!enable) t_collect(f);
+    f->timing = enable != 0;
+    return PHD_OK;
+}
+extern "C" int phd_timing_reset(phd_filter* f)
+{
+    CHECK_F(f);
+    t_collect(f);
+    for (int k = 0; k < PHD_K_COUNT; ++k) { f->t_ms[k] = 0; f->t_n[k] = 0; }
+    return PHD_OK;
+}
+extern "C" int phd_timing_read(phd_filter* f, double* ms_total, int64_t* launches)
+{
+    CHECK_F(f);
+    t_collect(f);
+    for (int k = 0; k < PHD_K_COUNT; ++k) {
+        if (ms_total) ms_total[k] = f->t_ms[k];
+        if (launches) launches[k] = f->t_n[k];
+    }
+    return PHD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// state transfer
+// ---------------------------------------------------------------------------------------------
+static int materialize_parents(phd_filter* f)
+{
+    // resolve the map indirection left by a resample: maps[cur^1][p] = maps[cur][parent[p]]
+    if (!f->parent_dirty) return PHD_OK;
+    HIPCHK(launch_gather_maps(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], nullptr, f->maps[f->cur ^ 1],
+                              f->counts[f->cur ^ 1], nullptr, nullptr, f->cap, f->n, f->stream));
+    f->cur ^= 1;
+    HIPCHK(launch_iota(f->parent[f->pcur], f->n, f->stream));
+    f->parent_dirty = false;
+    return PHD_OK;
+}
+
+extern "C" int phd_set_particles(phd_filter* f, const phd_pose* poses, const float* log_weights, int n)
+{
+    CHECK_F(f);
+    if (n != f->n) return fail(PHD_ERR_INVALID_ARG, "phd_set_particles: n != n_particles");
+    if (poses) HIPCHK(hipMemcpyAsync(f->pose[f->pose_cur], poses, n * sizeof(phd_pose), hipMemcpyHostToDevice, f->stream));
+    if (log_weights) HIPCHK(hipMemcpyAsync(f->logw, log_weights, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_get_particles(phd_filter* f, phd_pose* poses_out, float* log_weights_out)
+{
+    CHECK_F(f);
+    if (poses_out) HIPCHK(hipMemcpyAsync(poses_out, f->pose[f->pose_cur], f->n * sizeof(phd_pose), hipMemcpyDeviceToHost, f->stream));
+    if (log_weights_out) HIPCHK(hipMemcpyAsync(log_weights_out, f->logw, f->n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+static int ensure_concat(phd_filter* f, size_t n)
+{
+    if (n <= f->concat_cap) return PHD_OK;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (f->d_concat) hipFree(f->d_concat);
+    f->d_concat = nullptr;
+    f->concat_cap = 0;
+    size_t want = std::max(n, (size_t)f->n * 16);
+    HIPCHK(dalloc(&f->d_concat, want));
+    f->concat_cap = want;
+    return PHD_OK;
+}
+
+extern "C" int phd_set_maps(phd_filter* f, const phd_gaussian2d* concat, const int32_t* sizes)
+{
+    CHECK_F(f);
+    if (!sizes) return fail(PHD_ERR_INVALID_ARG, "phd_set_maps: null sizes");
+    std::vector<int> off(f->n + 1, 0);
+    for (int p = 0; p < f->n; ++p) {
+        if (sizes[p] < 0 || sizes[p] > f->cap)
+            return fail(PHD_ERR_CAPACITY, "phd_set_maps: a map exceeds map_capacity");
+        off[p + 1] = off[p] + sizes[p];
+    }
+    const size_t total = off[f->n];
+    if (total && !concat) return fail(PHD_ERR_INVALID_ARG, "phd_set_maps: null maps");
+    int rc = ensure_concat(f, total);
+    if (rc) return rc;
+    if (total) HIPCHK(hipMemcpyAsync(f->d_concat, concat, total * sizeof(phd_gaussian2d), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_offsets, off.data(), (f->n + 1) * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->counts[f->cur], sizes, f->n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(launch_pack_maps(f->d_concat, f->d_offsets, f->counts[f->cur], f->maps[f->cur], f->cap, f->n, f->stream));
+    HIPCHK(launch_iota(f->parent[f->pcur], f->n, f->stream));
+    f->parent_dirty = false;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_get_map_sizes(phd_filter* f, int32_t* sizes_out)
+{
+    CHECK_F(f);
+    if (!sizes_out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    std::vector<int> cnt(f->n), par(f->n);
+    HIPCHK(hipMemcpyAsync(cnt.data(), f->counts[f->cur], f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(par.data(), f->parent[f->pcur], f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    for (int p = 0; p < f->n; ++p) sizes_out[p] = cnt[par[p]];
+    return PHD_OK;
+}
+
+extern "C" int phd_get_maps(phd_filter* f, phd_gaussian2d* concat_out, size_t concat_capacity, int32_t* sizes_out)
+{
+    CHECK_F(f);
+    std::vector<int32_t> sizes(f->n);
+    int rc = phd_get_map_sizes(f, sizes.data());
+    if (rc) return rc;
+    std::vector<int> off(f->n + 1, 0);
+    for (int p = 0; p < f->n; ++p) off[p + 1] = off[p] + sizes[p];
+    const size_t total = off[f->n];
+    if (sizes_out) memcpy(sizes_out, sizes.data(), f->n * sizeof(int32_t));
+    if (!concat_out) return PHD_OK;
+    if (total > concat_capacity) return fail(PHD_ERR_CAPACITY, "phd_get_maps: output buffer too small");
+    rc = ensure_concat(f, total);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(f->d_offsets, off.data(), (f->n + 1) * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(launch_unpack_maps(f->maps[f->cur], f->parent[f->pcur], f->d_offsets, f->counts[f->cur], f->d_concat, f->cap,
+                              f->n, f->stream));
+    if (total) HIPCHK(hipMemcpyAsync(concat_out, f->d_concat, total * sizeof(phd_gaussian2d), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_set_map(phd_filter* f, int particle, const phd_gaussian2d* g, int n)
+{
+    CHECK_F(f);
+    if (particle < 0 || particle >= f->n) return fail(PHD_ERR_INVALID_ARG, "phd_set_map: bad particle index");
+    if (n < 0 || n > f->cap) return fail(PHD_ERR_CAPACITY, "phd_set_map: map exceeds map_capacity");
+    int rc = materialize_parents(f);
+    if (rc) return rc;
+    std::vector<float> slab((size_t)6 * f->cap, 0.f);
+    for (int i = 0; i < n; ++i) {
+        slab[0 * f->cap + i] = g[i].weight;
+        slab[1 * f->cap + i] = g[i].mean[0];
+        slab[2 * f->cap + i] = g[i].mean[1];
+        slab[3 * f->cap + i] = g[i].cov[0];
+        slab[4 * f->cap + i] = (g[i].cov[1] + g[i].cov[2]) * 0.5f;
+        slab[5 * f->cap + i] = g[i].cov[3];
+    }
+    HIPCHK(hipMemcpyAsync(f->maps[f->cur] + (size_t)particle * 6 * f->cap, slab.data(), slab.size() * sizeof(float),
+                          hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->counts[f->cur] + particle, &n, sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_get_map(phd_filter* f, int particle, phd_gaussian2d* out, int capacity, int32_t* n_out)
+{
+    CHECK_F(f);
+    if (particle < 0 || particle >= f->n) return fail(PHD_ERR_INVALID_ARG, "phd_get_map: bad particle index");
+    int src = particle;
+    HIPCHK(hipMemcpyAsync(&src, f->parent[f->pcur] + particle, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, f->counts[f->cur] + src, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    std::vector<float> slab((size_t)6 * f->cap);
+    HIPCHK(hipMemcpyAsync(slab.data(), f->maps[f->cur] + (size_t)src * 6 * f->cap, slab.size() * sizeof(float),
+                          hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (n_out) *n_out = n;
+    if (!out) return PHD_OK;
+    if (n > capacity) return fail(PHD_ERR_CAPACITY, "phd_get_map: output buffer too small");
+    for (int i = 0; i < n; ++i) {
+        out[i].weight = slab[0 * f->cap + i];
+        out[i].mean[0] = slab[1 * f->cap + i];
+        out[i].mean[1] = slab[2 * f->cap + i];
+        out[i].cov[0] = slab[3 * f->cap + i];
+        out[i].cov[1] = slab[4 * f->cap + i];
+        out[i].cov[2] = slab[4 * f->cap + i];
+        out[i].cov[3] = slab[5 * f->cap + i];
+    }
+    return PHD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------------------------
+static int do_predict(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise)
+{
+    const phd_pose* in = f->pose[f->pose_cur];
+    phd_pose* out = f->frozen ? f->pose[(f->pose_cur + 1) % 3] : f->pose[f->pose_cur];
+    t_begin(f, PHD_K_PREDICT);
+    HIPCHK(launch_predict(in, out, f->n, u, d_noise, f->seed, f->counter, f->dcfg, f->stream));
+    t_end(f);
+    f->counter++;
+    f->pose_for_update = f->frozen ? out : nullptr;
+    return PHD_OK;
+}
+
+extern "C" int phd_predict_ackerman_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise)
+{
+    CHECK_F(f);
+    return do_predict(f, u, d_noise);
+}
+
+extern "C" int phd_predict_ackerman(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* noise)
+{
+    CHECK_F(f);
+    if (noise) {
+        HIPCHK(hipMemcpyAsync(f->d_noise, noise, f->n * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, f->stream));
+        return do_predict(f, u, f->d_noise);
+    }
+    return do_predict(f, u, nullptr);
+}
+
+static int ensure_debug(phd_filter* f)
+{
+    if (f->dbg_surv) return PHD_OK;
+    HIPCHK(dalloc(&f->dbg_surv, (size_t)f->n * 6 * f->S_cap));
+    HIPCHK(dalloc(&f->dbg_u, (size_t)f->n * f->S_cap));
+    HIPCHK(dalloc(&f->dbg_n, f->n));
+    HIPCHK(dalloc(&f->dbg_nin, f->n));
+    return PHD_OK;
+}
+
+static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M)
+{
+    UpdateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.map_in = f->maps[f->cur];
+    a.count_in = f->counts[f->cur];
+    a.map_out = f->maps[f->cur ^ 1];
+    a.count_out = f->counts[f->cur ^ 1];
+    a.parent = f->parent[f->pcur];
+    a.parent_reset = f->frozen ? nullptr : f->parent[f->pcur];
+    a.pose = f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur];
+    a.z = d_z;
+    a.dlogw = f->dlogw;
+    a.M = M;
+    a.MM = f->MM;
+    a.cap = f->cap;
+    a.S_cap = f->S_cap;
+    if (f->debug) {
+        int rc = ensure_debug(f);
+        if (rc) return rc;
+        a.dbg_surv = f->dbg_surv; a.dbg_u = f->dbg_u; a.dbg_n = f->dbg_n; a.dbg_nin = f->dbg_nin;
+    }
+    a.status = f->status;
+    a.max_surv = f->max_surv;
+    a.max_map = f->max_map;
+    a.cfg = f->dcfg;
+    t_begin(f, PHD_K_UPDATE_MERGE);
+    HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream));
+    t_end(f);
+    f->last_M = M;
+    if (!f->frozen) {
+        f->cur ^= 1;
+        f->parent_dirty = false;
+    }
+    return PHD_OK;
+}
+
+// weights kernel on the local shard
+static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0 = 0.0)
+{
+    WeightArgs w;
+    memset(&w, 0, sizeof(w));
+    w.logw_in = f->logw;
+    w.logw = f->frozen ? f->logw_scratch : f->logw;
+    w.dlogw = f->dlogw;
+    w.raw_out = (mode & WM_NORMALIZE) ? nullptr : ((mode & WM_ACCUMULATE) ? f->logw_raw : nullptr);
+    w.n = f->n;
+    w.n_new = f->n;
+    w.mode = mode;
+    w.resample_thresh = f->cfg.resampleThresh;
+    w.uniforms = d_uniforms ? d_uniforms : f->d_uniforms;
+    w.n_uniforms = n_uniforms;
+    w.u0 = u0;
+    w.cdf = f->cdf;
+    w.idx_out = f->idx;
+    w.neff_out = f->neff;
+    w.did_resample = f->did;
+    const phd_pose* pin = f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur];
+    int free_pose = 0;
+    while (f->pose[free_pose] == pin || free_pose == f->pose_cur) free_pose++;
+    w.pose_in = pin;
+    w.pose_out = f->pose[free_pose];
+    w.parent_in = f->parent[f->pcur];
+    w.parent_out = f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1];
+    w.n_weight_norm = f->n_global;
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights(w, f->stream));
+    t_end(f);
+    if ((mode & WM_COMMIT) && !f->frozen) {
+        f->pose_cur = free_pose;
+        f->pcur ^= 1;
+        f->parent_dirty = true; // conservatively: parents may be non-identity now
+    }
+    f->pose_for_update = nullptr;
+    return PHD_OK;
+}
+
+extern "C" int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_meas)
+{
+    CHECK_F(f);
+    if (n_meas <= 0) return PHD_OK; // the reference skips the update when Z is empty (src/main.cpp:1260)
+    int M = std::min(n_meas, f->MM); // reference clamps to 256 (src/phdfilter.cu:3390-3394)
+    int rc = do_update_merge(f, d_z, M);
+    if (rc) return rc;
+    return do_weights(f, WM_ACCUMULATE | WM_NORMALIZE, nullptr, 1);
+}
+
+extern "C" int phd_update(phd_filter* f, const phd_measurement* z, int n_meas)
+{
+    CHECK_F(f);
+    if (n_meas <= 0) return PHD_OK;
+    if (!z) return fail(PHD_ERR_INVALID_ARG, "phd_update: null measurements");
+    int M = std::min(n_meas, f->MM);
+    HIPCHK(hipMemcpyAsync(f->d_z, z, M * sizeof(phd_measurement), hipMemcpyHostToDevice, f->stream));
+    return phd_update_dev(f, f->d_z, M);
+}
+
+extern "C" int phd_neff(phd_filter* f, float* neff_out)
+{
+    CHECK_F(f);
+    if (!neff_out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    bool fr = f->frozen;
+    f->frozen = true; // read-only evaluation
+    int rc = do_weights(f, 0, nullptr, 1);
+    f->frozen = fr;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(neff_out, f->neff, sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (*neff_out != *neff_out) return fail(PHD_ERR_NAN, "nan weights detected"); // src/main.cpp:1307-1311
+    return PHD_OK;
+}
+
+extern "C" int phd_resample(phd_filter* f, const double* uniforms, int n_uniforms, int32_t* idx_out)
+{
+    CHECK_F(f);
+    if (!uniforms || (n_uniforms != 1 && n_uniforms != f->n))
+        return fail(PHD_ERR_INVALID_ARG, "phd_resample: n_uniforms must be 1 (systematic) or n_particles (stratified)");
+    if (n_uniforms != 1)
+        HIPCHK(hipMemcpyAsync(f->d_uniforms, uniforms, n_uniforms * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    int rc = do_weights(f, WM_RESAMPLE_FORCE | WM_COMMIT, f->d_uniforms, n_uniforms, uniforms[0]);
+    if (rc) return rc;
+    if (idx_out) {
+        HIPCHK(hipMemcpyAsync(idx_out, f->idx, f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_resample_if_needed(phd_filter* f, double uniform, int had_measurements, int32_t* did_resample_out,
+                                      int32_t* idx_out)
+{
+    CHECK_F(f);
+    int rc = do_weights(f, WM_RESAMPLE_AUTO | WM_COMMIT | (had_measurements ? WM_HAD_MEAS : 0), nullptr, 1, uniform);
+    if (rc) return rc;
+    if (did_resample_out) HIPCHK(hipMemcpyAsync(did_resample_out, f->did, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, f->idx, f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    if (did_resample_out || idx_out) HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_step_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
+                            const phd_measurement* d_z, int n_meas, double uniform, int force_resample)
+{
+    CHECK_F(f);
+    int rc = do_predict(f, u, d_noise);
+    if (rc) return rc;
+    int M = std::min(n_meas, f->MM);
+    int mode = WM_COMMIT | (force_resample ? WM_RESAMPLE_FORCE : WM_RESAMPLE_AUTO);
+    if (M > 0) {
+        rc = do_update_merge(f, d_z, M);
+        if (rc) return rc;
+        mode |= WM_ACCUMULATE | WM_NORMALIZE | WM_HAD_MEAS;
+    }
+    return do_weights(f, mode, nullptr, 1, uniform); // the uniform travels as a kernel argument
+}
+
+extern "C" int phd_expected_pose(phd_filter* f, phd_pose* out)
+{
+    CHECK_F(f);
+    if (!out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    HIPCHK(launch_state(f->pose[f->pose_cur], f->logw, f->n, f->state_pose, f->state_argmax, f->stream));
+    HIPCHK(hipMemcpyAsync(out, f->state_pose, sizeof(phd_pose), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_map_estimate(phd_filter* f, phd_gaussian2d* out, int capacity, int32_t* n_out, int32_t* particle_out)
+{
+    CHECK_F(f);
+    int am = -1;
+    HIPCHK(launch_state(f->pose[f->pose_cur], f->logw, f->n, f->state_pose, f->state_argmax, f->stream));
+    HIPCHK(hipMemcpyAsync(&am, f->state_argmax, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (am < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
+    if (particle_out) *particle_out = am;
+    return phd_get_map(f, am, out, capacity, n_out);
+}
+
+extern "C" int phd_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw; return PHD_OK; }
+extern "C" int phd_raw_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw_raw; return PHD_OK; }
+
+extern "C" int phd_set_frozen(phd_filter* f, int freeze)
+{
+    CHECK_F(f);
+    f->frozen = freeze != 0;
+    f->pose_for_update = nullptr;
+    return PHD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: global normalise / resample over the all-gathered weight vector
+// ---------------------------------------------------------------------------------------------
+// Per step on every rank:  predict -> phd_update_local_dev (update+merge, raw = logw + dlogw)
+//   -> all_gather(raw) [RCCL, by the caller] -> phd_global_normalize -> (if nEff says so)
+//   phd_global_resample_indices -> export / all_to_all / apply_parents / import -> phd_finish_resample
+extern "C" int phd_update_local_dev(phd_filter* f, const phd_measurement* d_z, int n_meas)
+{
+    CHECK_F(f);
+    if (n_meas <= 0) {
+        HIPCHK(hipMemcpyAsync(f->logw_raw, f->logw, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+        return PHD_OK;
+    }
+    int M = std::min(n_meas, f->MM);
+    int rc = do_update_merge(f, d_z, M);
+    if (rc) return rc;
+    return do_weights(f, WM_ACCUMULATE, nullptr, 1); // raw_out = logw + dlogw, no normalisation
+}
+
+extern "C" int phd_global_normalize(phd_filter* f, const float* d_all_logw, int n_global, float* neff_out)
+{
+    CHECK_F(f);
+    if (n_global != f->n_global) return fail(PHD_ERR_INVALID_ARG, "phd_global_normalize: n_global mismatch");
+    WeightArgs w;
+    memset(&w, 0, sizeof(w));
+    w.logw_in = d_all_logw;
+    w.logw = f->logw_scratch; // [n_global] normalised copy (identical on every rank)
+    w.n = n_global;
+    w.n_new = 0;
+    w.mode = WM_NORMALIZE;
+    w.idx_out = f->idx;
+    w.neff_out = f->neff;
+    w.did_resample = f->did;
+    w.n_weight_norm = f->n_global;
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights(w, f->stream));
+    t_end(f);
+    HIPCHK(hipMemcpyAsync(f->logw, f->logw_scratch + f->global_offset, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+    if (neff_out) {
+        HIPCHK(hipMemcpyAsync(neff_out, f->neff, sizeof(float), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+        if (*neff_out != *neff_out) return fail(PHD_ERR_NAN, "nan weights detected");
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_global_resample_indices(phd_filter* f, const float* d_all_logw_normalized, int n_global,
+                                           const double* uniforms, int n_uniforms, int32_t* idx_out)
+{
+    CHECK_F(f);
+    if (n_global != f->n_global) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_indices: n_global mismatch");
+    if (!uniforms || (n_uniforms != 1 && n_uniforms != n_global)) return fail(PHD_ERR_INVALID_ARG, "bad uniforms");
+    const float* src = d_all_logw_normalized ? d_all_logw_normalized : f->logw_scratch;
+    if (n_uniforms != 1)
+        HIPCHK(hipMemcpyAsync(f->d_uniforms, uniforms, n_uniforms * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    WeightArgs w;
+    memset(&w, 0, sizeof(w));
+    w.u0 = uniforms[0];
+    w.logw_in = src;
+    w.logw = const_cast<float*>(src);
+    w.n = n_global;
+    w.n_new = n_global;
+    w.mode = WM_RESAMPLE_FORCE;
+    w.uniforms = f->d_uniforms;
+    w.n_uniforms = n_uniforms;
+    w.cdf = f->cdf;
+    w.idx_out = f->idx;
+    w.neff_out = f->neff;
+    w.did_resample = f->did;
+    w.n_weight_norm = f->n_global;
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights(w, f->stream));
+    t_end(f);
+    if (idx_out) {
+        HIPCHK(hipMemcpyAsync(idx_out, f->idx, n_global * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
+    return PHD_OK;
+}
+
+extern "C" size_t phd_particle_pack_bytes(const phd_filter* f) { return f ? (size_t)(8 + 6 * f->cap) * 4 : 0; }
+
+extern "C" int phd_export_particles_dev(phd_filter* f, const int32_t* particles, int n, void* d_buffer)
+{
+    CHECK_F(f);
+    if (n <= 0) return PHD_OK;
+    if (n > f->n) return fail(PHD_ERR_INVALID_ARG, "phd_export_particles_dev: n > n_particles");
+    HIPCHK(hipMemcpyAsync(f->d_sizes, particles, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->pose[f->pose_cur], f->d_sizes,
+                         d_buffer, f->cap, phd_particle_pack_bytes(f), n, f->stream));
+    return PHD_OK;
+}
+
+// local part of copy_particles after a global resample: next buffers <- parents that live on this rank
+extern "C" int phd_apply_parents(phd_filter* f, const int32_t* local_parent)
+{
+    CHECK_F(f);
+    HIPCHK(hipMemcpyAsync(f->d_tmp_int, local_parent, f->n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    const int pnext = (f->pose_cur + 1) % 3;
+    HIPCHK(launch_gather_maps(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->d_tmp_int, f->maps[f->cur ^ 1],
+                              f->counts[f->cur ^ 1], f->pose[f->pose_cur], f->pose[pnext], f->cap, f->n, f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int n, const void* d_buffer)
+{
+    CHECK_F(f);
+    if (n <= 0) return PHD_OK;
+    if (n > f->n) return fail(PHD_ERR_INVALID_ARG, "phd_import_particles_dev: n > n_particles");
+    const int pnext = (f->pose_cur + 1) % 3;
+    HIPCHK(hipMemcpyAsync(f->d_sizes, slots, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(launch_import(f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], f->d_sizes, d_buffer, f->cap,
+                         phd_particle_pack_bytes(f), n, f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_finish_resample(phd_filter* f)
+{
+    CHECK_F(f);
+    f->cur ^= 1;
+    f->pose_cur = (f->pose_cur + 1) % 3;
+    HIPCHK(launch_iota(f->parent[f->pcur], f->n, f->stream));
+    f->parent_dirty = false;
+    std::vector<float> w(f->n, (float)(-log((double)f->n_global))); // src/slamtypes.h:327
+    HIPCHK(hipMemcpyAsync(f->logw, w.data(), f->n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inspection
+// ---------------------------------------------------------------------------------------------
+extern "C" int phd_debug_enable(phd_filter* f, int enable)
+{
+    CHECK_F(f);
+    f->debug = enable != 0;
+    if (f->debug) return ensure_debug(f);
+    return PHD_OK;
+}
+
+extern "C" int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, int32_t* slab_index_out,
+                                       int capacity, int32_t* n_out)
+{
+    CHECK_F(f);
+    if (!f->debug || !f->dbg_surv) return fail(PHD_ERR_INVALID_ARG, "phd_debug_get_survivors: call phd_debug_enable first");
+    if (particle < 0 || particle >= f->n) return fail(PHD_ERR_INVALID_ARG, "bad particle index");
+    int n = 0, nin = 0;
+    HIPCHK(hipMemcpyAsync(&n, f->dbg_n + particle, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(&nin, f->dbg_nin + particle, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    std::vector<float> s((size_t)6 * f->S_cap);
+    std::vector<int> u(f->S_cap);
+    HIPCHK(hipMemcpyAsync(s.data(), f->dbg_surv + (size_t)particle * 6 * f->S_cap, s.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(u.data(), f->dbg_u + (size_t)particle * f->S_cap, u.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (n_out) *n_out = n;
+    if (!out) return PHD_OK;
+    if (n > capacity) return fail(PHD_ERR_CAPACITY, "phd_debug_get_survivors: output buffer too small");
+    // the kernel appends survivors in arrival order; the slab order is recovered from the slab index
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return u[a] < u[b]; });
+    const int n_update = nin * (f->last_M + 1) + f->last_M;
+    int n_near = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        out[k].weight = s[0 * f->S_cap + i];
+        out[k].mean[0] = s[1 * f->S_cap + i];
+        out[k].mean[1] = s[2 * f->S_cap + i];
+        out[k].cov[0] = s[3 * f->S_cap + i];
+        out[k].cov[1] = s[4 * f->S_cap + i];
+        out[k].cov[2] = s[4 * f->S_cap + i];
+        out[k].cov[3] = s[5 * f->S_cap + i];
+        if (slab_index_out) slab_index_out[k] = (u[i] >= 0x40000000) ? (n_update + n_near++) : u[i];
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out)
+{
+    CHECK_F(f);
+    if (!dlogw_out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    HIPCHK(hipMemcpyAsync(dlogw_out, f->dlogw, f->n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out)
+{
+    CHECK_F(f);
+    uint32_t st = 0;
+    int ms = 0, mm = 0;
+    HIPCHK(hipMemcpyAsync(&st, f->status, 4, hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(&ms, f->max_surv, 4, hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(&mm, f->max_map, 4, hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (status_out) *status_out = st;
+    if (max_survivors_out) *max_survivors_out = ms;
+    if (max_map_out) *max_map_out = mm;
+    if (st) return fail(PHD_ERR_CAPACITY, std::string("device capacity overflow:") + ((st & 1) ? " map_capacity" : "") +
+                                              ((st & 2) ? " survivor_capacity" : ""));
+    return PHD_OK;
+}

@@ -1,0 +1,108 @@
+// phd_device.h — internal interface between the C-ABI host code (phd_api.cpp) and the gfx950
+// kernels (phd_kernels.hip).  Not installed; the public boundary is include/phdslam.h.
+#ifndef PHD_DEVICE_H
+#define PHD_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "phdslam.h"
+
+namespace phd {
+
+// the SlamConfig fields that reach the device (reference: __constant__ dev_config, the whole
+// 324-byte struct, src/phdfilter.cu:121,3885-3890) — passed as a kernel argument (SGPRs)
+struct DevConfig {
+    float dt;
+    float minRange, maxRange, maxBearing;
+    float stdRange, stdBearing;
+    float clutterDensity, pd;
+    float birthWeight, birthNoiseFactor;
+    float minFeatureWeight, minSeparation;
+    float l, h, a, b;
+    float stdAlpha, stdEncoder;
+    int subdividePredict;
+    int distanceMetric;
+    int labeledMeasurements;
+};
+
+enum { PHD_STATUS_MAP_OVERFLOW = 1u, PHD_STATUS_SURVIVOR_OVERFLOW = 2u };
+
+// Map slab layout in HBM: particle-major, then 6 SoA planes of `cap` floats:
+//   slab(p) = base + p*6*cap ; planes: 0 weight, 1 mean x, 2 mean y, 3 cov xx, 4 cov xy, 5 cov yy
+struct UpdateArgs {
+    const float* map_in;
+    const int* count_in;
+    float* map_out;
+    int* count_out;
+    const int* parent;          // map indirection left by the last resample
+    int* parent_reset;          // == parent unless frozen (NULL): parent[p] <- p once slab p is rewritten
+    const phd_pose* pose;       // [n_particles]
+    const phd_measurement* z;   // [M] device
+    float* dlogw;               // [n_particles] out
+    int M;
+    int MM;                     // max measurements (LDS sizing)
+    int cap;
+    int S_cap;
+    // inspection (NULL when disabled)
+    float* dbg_surv;            // [n][6][S_cap]
+    int* dbg_u;                 // [n][S_cap]
+    int* dbg_n;                 // [n]
+    int* dbg_nin;               // [n]
+    unsigned* status;
+    int* max_surv;
+    int* max_map;
+    DevConfig cfg;
+};
+
+struct WeightArgs {
+    const float* logw_in;       // [n]
+    float* logw;                // [n] working/out vector (== logw_in unless frozen)
+    const float* dlogw;         // [n]
+    float* raw_out;             // [n] optional: un-normalised accumulated weights
+    int n;
+    int n_new;
+    int mode;
+    float resample_thresh;
+    const double* uniforms;     // device, n_uniforms entries (stratified); unused when n_uniforms == 1
+    double u0;                  // the single uniform of systematic resampling (n_uniforms == 1)
+    int n_uniforms;
+    double* cdf;                // [n] scratch (used when n > 2048)
+    int* idx_out;               // [n_new]
+    float* neff_out;            // [1]
+    int* did_resample;          // [1]
+    // commit (copy_particles)
+    const phd_pose* pose_in;
+    phd_pose* pose_out;
+    const int* parent_in;
+    int* parent_out;
+    int n_weight_norm;
+};
+
+size_t update_lds_bytes(int S, int C, int MM);
+
+hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
+hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman_control u,
+                          const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,
+                          hipStream_t st);
+hipError_t launch_weights(const WeightArgs& a, hipStream_t st);
+hipError_t launch_pack_maps(const phd_gaussian2d* concat, const int* offsets, const int* sizes, float* slabs, int cap,
+                            int n, hipStream_t st);
+hipError_t launch_unpack_maps(const float* slabs, const int* parent, const int* offsets, const int* counts,
+                              phd_gaussian2d* concat, int cap, int n, hipStream_t st);
+hipError_t launch_state(const phd_pose* poses, const float* logw, int n, float* pose_out, int* argmax_out,
+                        hipStream_t st);
+hipError_t launch_export(const float* slabs, const int* counts, const int* parent, const phd_pose* poses,
+                         const int* which, void* buf, int cap, size_t stride, int n, hipStream_t st);
+hipError_t launch_import(float* slabs, int* counts, phd_pose* poses, const int* which, const void* buf, int cap,
+                         size_t stride, int n, hipStream_t st);
+hipError_t launch_gather_maps(const float* src, const int* counts_src, const int* parent, const int* sel, float* dst,
+                              int* counts_dst, const phd_pose* pose_src, phd_pose* pose_dst, int cap, int n,
+                              hipStream_t st);
+hipError_t launch_iota(int* a, int n, hipStream_t st);
+
+// weight-kernel mode bits (mirrors the enum in phd_kernels.hip)
+enum { WM_ACCUMULATE = 1, WM_NORMALIZE = 2, WM_RESAMPLE_FORCE = 4, WM_RESAMPLE_AUTO = 8, WM_HAD_MEAS = 16, WM_COMMIT = 32 };
+
+} // namespace phd
+#endif

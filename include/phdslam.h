@@ -1,0 +1,311 @@
+/*
+ * phdslam.h — C-ABI of the MI355X-native Rao-Blackwellised GM-PHD-SLAM hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its seam is
+ * the C++ header src/phdfilter.h:10-34 plus the POD types of src/slamtypes.h.  Every
+ * entry point below names the reference interface it replaces.  All types are POD with
+ * the reference's exact memory layout (checked by static asserts in the implementation
+ * and by tests/test_abi.py), all outputs are caller-allocated, all functions return an
+ * int status (0 = PHD_OK, <0 = error; text via phd_last_error()).
+ *
+ * The library needs a gfx950 device for every compute call: there is no CPU fallback.
+ * A compute call without a usable HIP device returns PHD_ERR_NO_DEVICE.
+ */
+#ifndef PHDSLAM_H
+#define PHDSLAM_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * POD types — byte-for-byte the layouts of the reference's src/slamtypes.h
+ * ---------------------------------------------------------------------------------- */
+
+/* src/slamtypes.h:44-51 ConstantVelocityState: the vehicle pose for both motion models */
+typedef struct {
+    float px, py, ptheta, vx, vy, vtheta;
+} phd_pose;
+
+/* src/slamtypes.h:84-87 AckermanControl (alpha first, then v_encoder) */
+typedef struct {
+    float alpha;
+    float v_encoder;
+} phd_ackerman_control;
+
+/* src/slamtypes.h:90-93 AckermanNoise */
+typedef struct {
+    float n_alpha;
+    float n_encoder;
+} phd_ackerman_noise;
+
+/* src/slamtypes.h:96-101 RangeBearingMeasurement */
+typedef struct {
+    float range;
+    float bearing;
+    int32_t label;
+} phd_measurement;
+
+/* src/slamtypes.h:123-127 Gaussian2D: cov first, column-major 2x2, then mean, then weight */
+typedef struct {
+    float cov[4];
+    float mean[2];
+    float weight;
+} phd_gaussian2d;
+
+/* src/slamtypes.h:142-250 SlamConfig — same field order, same 324-byte layout.
+ * (C has no bool: the reference's bool members are uint8_t here, same size/alignment.) */
+typedef struct {
+    uint8_t debug;
+    float x0, y0, z0, roll0, pitch0, yaw0;
+    float vx0, vy0, vz0, vroll0, vpitch0, vyaw0;
+    uint8_t followTrajectory;
+    float ax, ay, az, aroll, apitch, ayaw;
+    float dt;
+    float minRange, maxRange, maxBearing;
+    float stdRange, stdBearing;
+    float clutterRate, clutterDensity;
+    float pd;
+    float stdVxMap, stdVyMap;
+    float stdAxMap, stdAyMap;
+    float covVxBirth, covVyBirth;
+    float ps;
+    float tau, beta;
+    int32_t particlesPerFeature, imageWidth, imageHeight;
+    float stdU, stdV, disparityBirth, stdDBirth, fx, fy, u0, v0;
+    int32_t n_particles;
+    int32_t nPredictParticles;
+    int32_t subdividePredict;
+    float resampleThresh;
+    float birthWeight;
+    float birthNoiseFactor;
+    uint8_t gateBirths;
+    uint8_t gateMeasurements;
+    float gateThreshold;
+    float minExpectedFeatureWeight;
+    float minSeparation;
+    int32_t maxFeatures;
+    float minFeatureWeight;
+    int32_t particleWeighting;
+    int32_t daughterMixtureType;
+    int32_t nSamples;
+    int32_t maxCardinality;
+    int32_t filterType;
+    int32_t distanceMetric;
+    int32_t maxSteps;
+    int32_t featureModel;
+    int32_t motionType;
+    int32_t mapEstimate;
+    int32_t cphdDistType;
+    float nu;
+    uint8_t labeledMeasurements;
+    float l, h, a, b;
+    float stdAlpha, stdEncoder;
+    uint8_t saveAllMaps;
+    uint8_t savePrediction;
+} phd_slam_config;
+
+/* the reference caps the measurement set at 256 (src/phdfilter.cu:120,3390-3394) */
+#define PHD_MAX_MEASUREMENTS 256
+
+/* ------------------------------------------------------------------------------------
+ * Status codes (reference: checkCudaErrors -> exit(EXIT_FAILURE); here: return codes)
+ * ---------------------------------------------------------------------------------- */
+enum {
+    PHD_OK = 0,
+    PHD_ERR_INVALID_ARG = -1,
+    PHD_ERR_NO_DEVICE = -2,      /* no usable HIP device / HIP runtime error            */
+    PHD_ERR_HIP = -3,
+    PHD_ERR_UNSUPPORTED = -4,    /* config selects a branch SURVEY.md §2 marks out of scope */
+    PHD_ERR_CAPACITY = -5,       /* a map or survivor list exceeded its configured capacity */
+    PHD_ERR_NAN = -6,            /* NaN particle weights (reference: main.cpp:1307-1311)   */
+    PHD_ERR_IO = -7,
+    PHD_ERR_PARSE = -8
+};
+
+typedef struct phd_filter phd_filter; /* opaque: owns all device state of one rank's shard */
+
+/* creation options; zero-initialise and set what you need (0 = default) */
+typedef struct {
+    int32_t n_particles;      /* particles held by THIS filter (a rank's shard); 0 = cfg->n_particles */
+    int32_t map_capacity;     /* Gaussians per particle slab; 0 = 256                                   */
+    int32_t max_measurements; /* <= PHD_MAX_MEASUREMENTS; 0 = 256                                       */
+    int32_t survivor_capacity;/* pruned update components kept per particle before merging; 0 = auto   */
+    int32_t device;           /* HIP device ordinal                                                      */
+    void*   stream;           /* hipStream_t to enqueue on; NULL = the filter creates its own            */
+    int32_t global_particles; /* total particles over all ranks (for -log N after a global resample); 0 = n_particles */
+    int32_t global_offset;    /* index of this shard's first particle in the global ordering            */
+} phd_options;
+
+const char* phd_last_error(void);
+const char* phd_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Lifetime / configuration
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces: device-state setup spread over phdUpdateSynth/prepareUpdateInputs
+ * (src/phdfilter.cu:2966-3102,3403-3438: ~22 cudaMalloc per step) — one arena for the run */
+int phd_create(const phd_slam_config* cfg, const phd_options* opt, phd_filter** out);
+int phd_destroy(phd_filter* f);
+
+/* replaces: setDeviceConfig(const SlamConfig&) (src/phdfilter.h:33-34, src/phdfilter.cu:3885-3890) */
+int phd_set_config(phd_filter* f, const phd_slam_config* cfg);
+
+/* replaces: initRandomNumberGenerators() (src/phdfilter.h:10) + rng.cpp's wall-clock seed;
+ * seeds the counter-based generator used when predict is called without explicit noise */
+int phd_seed(phd_filter* f, uint64_t seed);
+
+/* ------------------------------------------------------------------------------------
+ * State transfer (SynthSLAM <-> device; src/slamtypes.h:288-311)
+ * ---------------------------------------------------------------------------------- */
+int phd_n_particles(const phd_filter* f);
+int phd_map_capacity(const phd_filter* f);
+
+/* SynthSLAM::states / ::weights (log-weights) */
+int phd_set_particles(phd_filter* f, const phd_pose* poses, const float* log_weights, int n);
+int phd_get_particles(phd_filter* f, phd_pose* poses_out, float* log_weights_out);
+
+/* SynthSLAM::maps_static — all maps at once: concat[sum sizes], sizes[n_particles] */
+int phd_set_maps(phd_filter* f, const phd_gaussian2d* concat, const int32_t* sizes);
+int phd_get_map_sizes(phd_filter* f, int32_t* sizes_out);
+int phd_get_maps(phd_filter* f, phd_gaussian2d* concat_out, size_t concat_capacity, int32_t* sizes_out);
+/* one particle's map */
+int phd_set_map(phd_filter* f, int particle, const phd_gaussian2d* g, int n);
+int phd_get_map(phd_filter* f, int particle, phd_gaussian2d* out, int capacity, int32_t* n_out);
+
+/* ------------------------------------------------------------------------------------
+ * The hot path
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces: phdPredict(SynthSLAM&, AckermanControl) (src/phdfilter.h:16-17,
+ * src/phdfilter.cu:1080-1257 + kernel :785-825).  noise: n_particles host entries drawn by the
+ * caller in the reference's order (n_alpha, n_encoder); NULL = draw on device from phd_seed(). */
+int phd_predict_ackerman(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* noise);
+
+/* replaces: SynthSLAM phdUpdateSynth(SynthSLAM&, measurementSet) (src/phdfilter.h:23-24,
+ * src/phdfilter.cu:3336-3761): in-range split, births, EKF pre-update, GM-PHD weight update,
+ * prune, merge, particle log-weight increment and logSumExp normalisation.
+ * n_meas > max_measurements is clamped like the reference (src/phdfilter.cu:3390-3394).
+ * Asynchronous on the filter's stream. */
+int phd_update(phd_filter* f, const phd_measurement* z, int n_meas);
+
+/* replaces: the nEff test of run_synth (src/main.cpp:1281-1284) */
+int phd_neff(phd_filter* f, float* neff_out);
+
+/* replaces: resampleParticles + SynthSLAM::copy_particles (src/main.cpp:453-501,
+ * src/slamtypes.h:313-333).  n_uniforms == 1: systematic (src/phdfilter.cu.bak:3279-3327);
+ * n_uniforms == n_new: stratified (HEAD, src/main.cpp:468).  idx_out (optional) receives the
+ * parent indices.  Weights become -log(n). Particle count is unchanged (n_new == n). */
+int phd_resample(phd_filter* f, const double* uniforms, int n_uniforms, int32_t* idx_out);
+
+/* run_synth's trigger (src/main.cpp:1286-1297): resample iff nEff <= resampleThresh (and the
+ * step had measurements); did_resample_out reports the decision; idx_out as above (identity
+ * when not resampled). */
+int phd_resample_if_needed(phd_filter* f, double uniform, int had_measurements,
+                           int32_t* did_resample_out, int32_t* idx_out);
+
+/* replaces: recoverSlamState (src/main.cpp:318-361): weighted-mean pose and the map of the
+ * arg-max-weight particle (MAP estimate). */
+int phd_expected_pose(phd_filter* f, phd_pose* out);
+int phd_map_estimate(phd_filter* f, phd_gaussian2d* out, int capacity, int32_t* n_out, int32_t* particle_out);
+
+/* ------------------------------------------------------------------------------------
+ * Device-resident variants (inputs already in HBM; used by bench.py and the multi-GPU host)
+ * ---------------------------------------------------------------------------------- */
+int phd_predict_ackerman_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise);
+int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_meas);
+/* device pointer to this shard's normalised log-weights (n_particles floats) */
+int phd_logweights_dev(phd_filter* f, float** d_logw_out);
+/* device pointer to the un-normalised log-weights after the update of the last phd_update
+ * (before logSumExp); used for the multi-GPU all-gather */
+int phd_raw_logweights_dev(phd_filter* f, float** d_logw_out);
+
+/* Multi-GPU: update + prune + merge of the local shard WITHOUT the local normalisation: leaves
+ * raw = logw + dlogw in the buffer of phd_raw_logweights_dev for the all-gather */
+int phd_update_local_dev(phd_filter* f, const phd_measurement* d_z, int n_meas);
+
+/* Multi-GPU: normalise / nEff / resample over the all-gathered vector of
+ * n_global un-normalised log-weights (device pointer, identical on every rank).  Every rank
+ * runs the identical routine -> identical indices.  Writes the shard's normalised weights
+ * into the filter, returns nEff, and (if resample) the n_global parent indices (host). */
+int phd_global_normalize(phd_filter* f, const float* d_all_logw, int n_global, float* neff_out);
+int phd_global_resample_indices(phd_filter* f, const float* d_all_logw_normalized, int n_global,
+                                const double* uniforms, int n_uniforms, int32_t* idx_out);
+/* adopt parents for the local shard after a global resample: local_parent[i] >= 0 selects a
+ * local particle; -1 means the slab arrives via phd_import_particle */
+int phd_apply_parents(phd_filter* f, const int32_t* local_parent);
+/* pack / unpack one particle (pose + map) for peer migration; buffer layout is private,
+ * size = phd_particle_pack_bytes() */
+size_t phd_particle_pack_bytes(const phd_filter* f);
+int phd_export_particles_dev(phd_filter* f, const int32_t* particles, int n, void* d_buffer);
+int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int n, const void* d_buffer);
+int phd_finish_resample(phd_filter* f); /* weights <- -log(global_particles) */
+
+/* ------------------------------------------------------------------------------------
+ * Bench / steady-state protocol and instrumentation
+ * ---------------------------------------------------------------------------------- */
+/* freeze != 0: steps read the current state but do not commit their outputs, so every
+ * iteration restarts from the same device-resident snapshot (constant work per iteration) */
+int phd_set_frozen(phd_filter* f, int freeze);
+/* one full filter step on device-resident inputs: predict -> update -> prune -> merge ->
+ * weight normalise -> nEff -> resample (forced if force_resample) */
+int phd_step_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
+                 const phd_measurement* d_z, int n_meas, double uniform, int force_resample);
+int phd_sync(phd_filter* f);
+void* phd_stream(phd_filter* f);
+
+/* per-kernel timing with HIP events on the filter's stream (reference: cudaEvent pair in
+ * phdPredict, src/phdfilter.cu:1083-1087,1244-1251).  enable, run steps, then read the
+ * accumulated milliseconds and launch counts. */
+enum { PHD_K_PREDICT = 0, PHD_K_UPDATE_MERGE = 1, PHD_K_WEIGHTS = 2, PHD_K_COUNT = 3 };
+int phd_timing_enable(phd_filter* f, int enable);
+int phd_timing_read(phd_filter* f, double* ms_total /*[PHD_K_COUNT]*/, int64_t* launches /*[PHD_K_COUNT]*/);
+int phd_timing_reset(phd_filter* f);
+
+/* ------------------------------------------------------------------------------------
+ * Inspection (parity tests): the pruned update components of one particle before merging,
+ * sorted into the reference's slab order [non-detect | detect m-major | births | near-range]
+ * (src/phdfilter.cu:2123-2172,3218-3257); slab_index_out (optional) = position in the
+ * un-pruned slab.  Valid after phd_update until the next hot-path call.
+ * Also the per-particle log-weight increments of the last update (src/phdfilter.cu:2260-2263).
+ * ---------------------------------------------------------------------------------- */
+int phd_debug_enable(phd_filter* f, int enable);
+int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, int32_t* slab_index_out,
+                            int capacity, int32_t* n_out);
+int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out);
+/* status word accumulated on the device: bit0 map overflow, bit1 survivor overflow */
+int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side boundary helpers (no device needed): config file, data files, log writer
+ * ---------------------------------------------------------------------------------- */
+/* replaces: loadConfig (src/main.cpp:956-1073): same keys, same defaults, derives
+ * clutterDensity (src/main.cpp:1065-1066).  data_dir_out/n_steps_out receive the two
+ * non-SlamConfig keys.  Unknown keys and malformed values are errors (reference ignores them). */
+int phd_config_defaults(phd_slam_config* cfg);
+int phd_config_load(const char* path, phd_slam_config* cfg, char* data_dir_out, size_t data_dir_cap,
+                    int32_t* n_steps_out);
+
+/* replaces: loadMeasurements/parseMeasurements (src/main.cpp:192-240): header line skipped,
+ * one step per line, pairs "r b" (README:21-24) or triples "r b label" (HEAD parser).
+ * Two-call protocol: first with out == NULL to get counts. */
+int phd_load_measurements(const char* path, int triples, phd_measurement* out, size_t out_capacity,
+                          int32_t* step_sizes_out, size_t steps_capacity, size_t* n_steps_out, size_t* n_total_out);
+/* replaces: loadControls (src/main.cpp:169-190): header skipped, "v_encoder alpha" per line,
+ * ',' tolerated as separator */
+int phd_load_controls(const char* path, int has_header, phd_ackerman_control* out, size_t capacity, size_t* n_out);
+
+/* replaces: the state_estimate%05d.log contract (README:31-39; writer src/main.cpp:848-954):
+ * 5 lines: pose / map (weight mx my c0 c1 c2 c3) / log-weights / poses / cardinality zeros */
+int phd_write_state_log(const char* dir, int step, const phd_pose* expected_pose,
+                        const phd_gaussian2d* map, int n_map, const float* log_weights,
+                        const phd_pose* poses, int n_particles, int max_cardinality);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHDSLAM_H */

@@ -1,0 +1,255 @@
+"""ctypes wrapper around oracle/libscphd_cpu.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libscphd_cpu.so")
+
+GAUSSIAN = np.dtype([("cov", np.float32, 4), ("mean", np.float32, 2), ("weight", np.float32)])
+POSE = np.dtype([("px", np.float32), ("py", np.float32), ("ptheta", np.float32),
+                 ("vx", np.float32), ("vy", np.float32), ("vtheta", np.float32)])
+MEAS = np.dtype([("range", np.float32), ("bearing", np.float32), ("label", np.int32)])
+assert GAUSSIAN.itemsize == 28 and POSE.itemsize == 24 and MEAS.itemsize == 12
+
+
+class OConfig(C.Structure):
+    _fields_ = [("dt", C.c_float),
+                ("minRange", C.c_float), ("maxRange", C.c_float), ("maxBearing", C.c_float),
+                ("stdRange", C.c_float), ("stdBearing", C.c_float),
+                ("clutterDensity", C.c_float), ("pd", C.c_float),
+                ("birthWeight", C.c_float), ("birthNoiseFactor", C.c_float),
+                ("minFeatureWeight", C.c_float), ("minSeparation", C.c_float),
+                ("resampleThresh", C.c_float),
+                ("l", C.c_float), ("h", C.c_float), ("a", C.c_float), ("b", C.c_float),
+                ("subdividePredict", C.c_int32), ("distanceMetric", C.c_int32),
+                ("labeledMeasurements", C.c_int32), ("particleWeighting", C.c_int32)]
+
+
+def default_config(**over):
+    """Parameter values of the reference's cfg/config.cfg:46-159."""
+    f32 = np.float32
+    max_range, max_bearing, clutter_rate = f32(15.0), f32(3.141593), f32(20.0)
+    cfg = OConfig(dt=0.1, minRange=0.0, maxRange=max_range, maxBearing=max_bearing,
+                  stdRange=0.25, stdBearing=0.008727,
+                  # src/main.cpp:1065-1066: clutterRate/(2*maxBearing*maxRange) in float
+                  clutterDensity=float(clutter_rate / (f32(2) * max_bearing * max_range)),
+                  pd=0.95, birthWeight=1e-4, birthNoiseFactor=1.0,
+                  minFeatureWeight=1e-6, minSeparation=10.0, resampleThresh=0.5,
+                  l=1.415, h=0.38, a=1.89, b=0.5,
+                  subdividePredict=1, distanceMetric=0, labeledMeasurements=0, particleWeighting=0)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "scphd_cpu.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i32, f32, f64 = C.c_void_p, C.c_int, C.c_float, C.c_double
+        cp = C.POINTER(OConfig)
+        L.o_safe_log.restype = f32; L.o_safe_log.argtypes = [f32]
+        L.o_wrap_angle.restype = f32; L.o_wrap_angle.argtypes = [f32]
+        L.o_det_exp.restype = f64; L.o_det_exp.argtypes = [f32]
+        L.o_predict_ackerman.restype = None; L.o_predict_ackerman.argtypes = [vp, i32, f32, f32, vp, cp]
+        L.o_predicted_measurement.restype = None; L.o_predicted_measurement.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.o_classify.restype = None; L.o_classify.argtypes = [vp, i32, vp, cp, vp]
+        L.o_births.restype = None; L.o_births.argtypes = [vp, vp, i32, cp, vp]
+        L.o_preupdate.restype = None; L.o_preupdate.argtypes = [vp, vp, i32, vp, i32, cp, vp, vp]
+        L.o_update.restype = None; L.o_update.argtypes = [vp, vp, vp, vp, i32, i32, cp, vp, vp, vp]
+        L.o_mahal_dist.restype = f32; L.o_mahal_dist.argtypes = [vp, vp]
+        L.o_hellinger_dist.restype = f32; L.o_hellinger_dist.argtypes = [vp, vp]
+        L.o_merge.restype = i32; L.o_merge.argtypes = [vp, i32, cp, vp, vp]
+        L.o_gm_reduce.restype = i32; L.o_gm_reduce.argtypes = [vp, i32, f32, vp]
+        L.o_update_particle.restype = i32
+        L.o_update_particle.argtypes = [vp, vp, i32, vp, i32, cp, vp, vp, vp, vp, vp, vp]
+        L.o_normalize_weights.restype = None; L.o_normalize_weights.argtypes = [vp, vp, i32]
+        L.o_neff.restype = f32; L.o_neff.argtypes = [vp, i32]
+        L.o_resample.restype = None; L.o_resample.argtypes = [vp, i32, vp, i32, i32, vp]
+        L.o_expected_pose.restype = None; L.o_expected_pose.argtypes = [vp, vp, i32, vp]
+        L.o_argmax_weight.restype = i32; L.o_argmax_weight.argtypes = [vp, i32]
+        L.o_step.restype = i32
+        L.o_step.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, cp, f64, i32, vp, vp, vp, vp, i32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ---------------------------------------------------------------------------------------------
+def wrap_angle(a):
+    return float(lib().o_wrap_angle(float(np.float32(a))))
+
+
+def det_exp(x):
+    return float(lib().o_det_exp(float(np.float32(x))))
+
+
+def predict_ackerman(poses, alpha, v_encoder, noise, cfg):
+    poses = _c(poses, POSE).copy()
+    noise = None if noise is None else _c(noise, np.float32)
+    lib().o_predict_ackerman(_p(poses), len(poses), float(alpha), float(v_encoder), _p(noise), C.byref(cfg))
+    return poses
+
+
+def predicted_measurement(pose, mean):
+    pose = _c(pose, POSE).reshape(1)
+    mean = _c(mean, np.float32)
+    r = C.c_float(); b = C.c_float()
+    lib().o_predicted_measurement(_p(pose), _p(mean), C.byref(r), None, C.byref(b), None, None)
+    return r.value, b.value
+
+
+def classify(gmap, pose, cfg):
+    gmap = _c(gmap, GAUSSIAN)
+    pose = _c(pose, POSE).reshape(1)
+    cls = np.zeros(len(gmap), np.int8)
+    lib().o_classify(_p(gmap), len(gmap), _p(pose), C.byref(cfg), _p(cls))
+    return cls
+
+
+def births(pose, z, cfg):
+    pose = _c(pose, POSE).reshape(1)
+    z = _c(z, MEAS)
+    out = np.zeros(len(z), GAUSSIAN)
+    lib().o_births(_p(pose), _p(z), len(z), C.byref(cfg), _p(out))
+    return out
+
+
+def preupdate(pose, feat, z, cfg):
+    pose = _c(pose, POSE).reshape(1)
+    feat = _c(feat, GAUSSIAN)
+    z = _c(z, MEAS)
+    n, M = len(feat), len(z)
+    pd = np.zeros(n, np.float32)
+    pre = np.zeros((M, n), GAUSSIAN)
+    lib().o_preupdate(_p(pose), _p(feat), n, _p(z), M, C.byref(cfg), _p(pd), _p(pre))
+    return pd, pre
+
+
+def update(feat, pd, pre, births_, cfg):
+    feat = _c(feat, GAUSSIAN)
+    n, M = len(feat), len(births_)
+    slab = np.zeros(n * (M + 1) + M, GAUSSIAN)
+    flag = np.zeros(len(slab), np.uint8)
+    dlw = np.zeros(1, np.float32)
+    lib().o_update(_p(feat), _p(_c(pd, np.float32)), _p(_c(pre, GAUSSIAN)), _p(_c(births_, GAUSSIAN)),
+                   n, M, C.byref(cfg), _p(slab), _p(flag), _p(dlw))
+    return slab, flag, float(dlw[0])
+
+
+def mahal_dist(a, b):
+    a = _c(a, GAUSSIAN).reshape(1); b = _c(b, GAUSSIAN).reshape(1)
+    return float(lib().o_mahal_dist(_p(a), _p(b)))
+
+
+def hellinger_dist(a, b):
+    a = _c(a, GAUSSIAN).reshape(1); b = _c(b, GAUSSIAN).reshape(1)
+    return float(lib().o_hellinger_dist(_p(a), _p(b)))
+
+
+def merge(comps, cfg, with_margin=False):
+    comps = _c(comps, GAUSSIAN)
+    out = np.zeros(max(len(comps), 1), GAUSSIAN)
+    margin = np.zeros(2, np.float32)
+    n = lib().o_merge(_p(comps), len(comps), C.byref(cfg), _p(out), _p(margin))
+    return (out[:n], margin) if with_margin else out[:n]
+
+
+def gm_reduce(comps, min_distance):
+    comps = _c(comps, GAUSSIAN)
+    out = np.zeros(max(len(comps), 1), GAUSSIAN)
+    n = lib().o_gm_reduce(_p(comps), len(comps), float(min_distance), _p(out))
+    return out[:n]
+
+
+def update_particle(pose, gmap, z, cfg):
+    """-> dict(map, dlogw, survivors, slab_idx, margin)"""
+    pose = _c(pose, POSE).reshape(1)
+    gmap = _c(gmap, GAUSSIAN)
+    z = _c(z, MEAS)
+    n, M = len(gmap), len(z)
+    cap = n * (M + 1) + M + n + 1
+    out = np.zeros(cap, GAUSSIAN)
+    surv = np.zeros(cap, GAUSSIAN)
+    sidx = np.zeros(cap, np.int32)
+    ns = C.c_int(0)
+    dlw = np.zeros(1, np.float32)
+    margin = np.zeros(2, np.float32)
+    nm = lib().o_update_particle(_p(pose), _p(gmap), n, _p(z), M, C.byref(cfg), _p(out), _p(dlw),
+                                 _p(surv), _p(sidx), C.byref(ns), _p(margin))
+    return dict(map=out[:nm].copy(), dlogw=float(dlw[0]), survivors=surv[:ns.value].copy(),
+                slab_idx=sidx[:ns.value].copy(), margin=margin)
+
+
+def normalize_weights(logw, dlogw=None):
+    logw = _c(logw, np.float32).copy()
+    d = None if dlogw is None else _c(dlogw, np.float32)
+    lib().o_normalize_weights(_p(logw), _p(d), len(logw))
+    return logw
+
+
+def neff(logw):
+    logw = _c(logw, np.float32)
+    return float(lib().o_neff(_p(logw), len(logw)))
+
+
+def resample(logw, uniforms, n_new=None):
+    logw = _c(logw, np.float32)
+    u = _c(np.atleast_1d(uniforms), np.float64)
+    n_new = len(logw) if n_new is None else n_new
+    idx = np.zeros(n_new, np.int32)
+    lib().o_resample(_p(logw), len(logw), _p(u), len(u), n_new, _p(idx))
+    return idx
+
+
+def expected_pose(poses, logw):
+    poses = _c(poses, POSE); logw = _c(logw, np.float32)
+    out = np.zeros(1, POSE)
+    lib().o_expected_pose(_p(poses), _p(logw), len(poses), _p(out))
+    return out[0]
+
+
+def argmax_weight(logw):
+    logw = _c(logw, np.float32)
+    return int(lib().o_argmax_weight(_p(logw), len(logw)))
+
+
+def step(poses, logw, maps, sizes, cap, alpha, v_encoder, noise, z, cfg, uniform, force_resample, n_threads=0):
+    """Whole filter step on fixed-capacity slabs (maps: [N, cap] GAUSSIAN).  Inputs are copied."""
+    poses = _c(poses, POSE).copy(); logw = _c(logw, np.float32).copy()
+    maps = _c(maps, GAUSSIAN).reshape(-1); sizes = _c(sizes, np.int32)
+    N = len(poses)
+    z = _c(z, MEAS)
+    noise = None if noise is None else _c(noise, np.float32)
+    maps_out = np.zeros(N * cap, GAUSSIAN); sizes_out = np.zeros(N, np.int32)
+    idx = np.zeros(N, np.int32); ne = np.zeros(1, np.float32)
+    rc = lib().o_step(_p(poses), _p(logw), _p(maps), _p(sizes), N, cap, float(alpha), float(v_encoder), _p(noise),
+                      _p(z), len(z), C.byref(cfg), float(uniform), int(force_resample),
+                      _p(maps_out), _p(sizes_out), _p(idx), _p(ne), int(n_threads))
+    return dict(rc=rc, poses=poses, logw=logw, maps=maps_out.reshape(N, cap), sizes=sizes_out, idx=idx,
+                neff=float(ne[0]))

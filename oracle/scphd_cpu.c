@@ -1,0 +1,663 @@
+/*
+ * scphd_cpu.c — CPU ORACLE (test infrastructure; see scphd_cpu.h for scope and pin status).
+ *
+ * Restates, function by function, the algorithm of cheesinglee/cuda-PHDSLAM's hot path.
+ * Arithmetic is fp32 like the reference (REAL = float, src/slamtypes.h:21) and follows the
+ * reference's expression order, including the places where C++ promotes to double because
+ * of a double literal or M_PI.  Sums that the reference does with a thread-strided tree
+ * reduction (sumByReduction, src/device_math.cuh:452-472) are done here sequentially in index
+ * order: the reference's order depends on blockDim and is not a property worth pinning.
+ *
+ * Compile with -ffp-contract=off (see Makefile) so that the merge stage — which has no
+ * transcendental in it — is reproducible bit for bit by any IEEE-754 implementation that
+ * performs the same operations in the same order.
+ */
+#define _GNU_SOURCE
+#include "scphd_cpu.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define O_LOG0 (-FLT_MAX) /* src/slamtypes.h:26 */
+
+/* src/device_math.cuh:9-16 */
+float o_safe_log(float x) { return (x <= 0) ? O_LOG0 : logf(x); }
+
+/* src/device_math.cuh:241-251.  M_PI is a double there: the comparisons and the +-2*pi are
+ * evaluated in double and rounded back to float. */
+float o_wrap_angle(float a)
+{
+    float remainder = fmodf(a, (float)(2 * M_PI));
+    if ((double)remainder > M_PI)
+        remainder = (float)((double)remainder - 2 * M_PI);
+    else if ((double)remainder < -M_PI)
+        remainder = (float)((double)remainder + 2 * M_PI);
+    return remainder;
+}
+
+/*
+ * Portable exponential used for the resampling CDF.  The reference calls libm exp() on the
+ * float log-weight and accumulates in double (src/main.cpp:463,495); libm's last-bit rounding
+ * is platform specific, which would make "resampling indices bit-exact" a matter of luck.
+ * This routine uses only IEEE-754 basic operations (mul, fma, rint, ldexp), so every
+ * conforming CPU and GPU produces the same double.  |error| < 1 ulp(double).
+ */
+double o_det_exp(float xf)
+{
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double x = (double)xf;
+    if (!(x >= -700.0)) return (x != x) ? x : 0.0;
+    if (x > 700.0) return INFINITY;
+    double kd = rint(x * LOG2E);
+    double r = fma(-kd, LN2_HI, x);
+    r = fma(-kd, LN2_LO, r);
+    /* Taylor, degree 13, |r| <= 0.3466 */
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kd);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* predict: phdPredictKernelAckerman, src/phdfilter.cu:785-825 (nPredictParticles = 1)   */
+/* ------------------------------------------------------------------------------------ */
+void o_predict_ackerman(o_pose* poses, int n, float alpha, float v_encoder,
+                        const float* noise, const o_config* cfg)
+{
+    for (int i = 0; i < n; i++) {
+        o_pose old = poses[i];
+        float n_alpha = noise ? noise[2 * i] : 0.0f;
+        float n_encoder = noise ? noise[2 * i + 1] : 0.0f;
+        float ve_noisy = v_encoder + n_encoder;                       /* :802 */
+        float alpha_noisy = alpha + n_alpha;                          /* :803 */
+        float vc = ve_noisy / (1 - tanf(alpha_noisy) * cfg->h / cfg->l); /* :804 */
+        float xc_dot = vc * cosf(old.ptheta);                         /* :805 */
+        float yc_dot = vc * sinf(old.ptheta);                         /* :806 */
+        float thetac_dot = vc * tanf(alpha_noisy) / cfg->l;           /* :807 */
+        float dt = cfg->dt / cfg->subdividePredict;                   /* :808 */
+        o_pose nw;
+        nw.px = old.px + dt * (xc_dot - thetac_dot * (cfg->a * sinf(old.ptheta) + cfg->b * cosf(old.ptheta)));
+        nw.py = old.py + dt * (yc_dot + thetac_dot * (cfg->a * cosf(old.ptheta) - cfg->b * sinf(old.ptheta)));
+        nw.ptheta = o_wrap_angle(old.ptheta + dt * thetac_dot);       /* :817 */
+        nw.vx = 0; nw.vy = 0; nw.vtheta = 0;                          /* :818-820 */
+        poses[i] = nw;
+    }
+}
+
+/* predicted range/bearing of a feature mean seen from a pose: the expression shared by
+ * computeInRangeKernel (src/phdfilter.cu:1328-1332) and preUpdateSynthKernel (:1841-1845) */
+void o_predicted_measurement(const o_pose* pose, const float* mean, float* r_out, float* r2_out,
+                             float* b_out, float* dx_out, float* dy_out)
+{
+    float dx = mean[0] - pose->px;
+    float dy = mean[1] - pose->py;
+    float r2 = dx * dx + dy * dy;
+    float r = sqrtf(r2);
+    float bearing = o_wrap_angle(atan2f(dy, dx) - pose->ptheta);
+    *r_out = r; *b_out = bearing;
+    if (r2_out) *r2_out = r2;
+    if (dx_out) *dx_out = dx;
+    if (dy_out) *dy_out = dy;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* in-range classification: computeInRangeKernel, src/phdfilter.cu:1328-1346              */
+/* ------------------------------------------------------------------------------------ */
+void o_classify(const o_gaussian* map, int n, const o_pose* pose, const o_config* cfg, int8_t* cls)
+{
+    for (int i = 0; i < n; i++) {
+        float r, bearing;
+        o_predicted_measurement(pose, map[i].mean, &r, NULL, &bearing, NULL, NULL);
+        cls[i] = 0;
+        if (r >= cfg->minRange && r <= cfg->maxRange && fabsf(bearing) <= cfg->maxBearing)
+            cls[i] = 1;
+        /* the 0.8 / 1.2 literals are doubles: comparison in double (:1340-1342) */
+        else if ((double)r >= 0.8 * (double)cfg->minRange && (double)r <= 1.2 * (double)cfg->maxRange &&
+                 (double)fabsf(bearing) <= 1.2 * (double)cfg->maxBearing)
+            cls[i] = 2;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* births: host loop src/phdfilter.cu:3470-3506                                           */
+/* (cos/sin of a float stay float under <cmath>)                                          */
+/* ------------------------------------------------------------------------------------ */
+void o_births(const o_pose* pose, const o_meas* z, int M, const o_config* cfg, o_gaussian* births)
+{
+    for (int j = 0; j < M; j++) {
+        float theta = pose->ptheta + z[j].bearing;
+        float dx = z[j].range * cosf(theta);
+        float dy = z[j].range * sinf(theta);
+        births[j].mean[0] = pose->px + dx;
+        births[j].mean[1] = pose->py + dy;
+        float J[4];
+        J[0] = dx / z[j].range;
+        J[1] = dy / z[j].range;
+        J[2] = -dy;
+        J[3] = dx;
+        /* pow(x,2) with a float x: CUDA's pow(float,int) overload is a float multiply */
+        float sr = cfg->stdRange * cfg->birthNoiseFactor;
+        float sb = cfg->stdBearing * cfg->birthNoiseFactor;
+        float var_range = sr * sr;
+        float var_bearing = sb * sb;
+        births[j].cov[0] = J[0] * J[0] * var_range + J[2] * J[2] * var_bearing;
+        births[j].cov[1] = J[0] * J[1] * var_range + J[2] * J[3] * var_bearing;
+        births[j].cov[2] = births[j].cov[1];
+        births[j].cov[3] = J[1] * J[1] * var_range + J[3] * J[3] * var_bearing;
+        if (z[j].label == 0 || !cfg->labeledMeasurements)
+            births[j].weight = o_safe_log(cfg->birthWeight);
+        else
+            births[j].weight = o_safe_log(0);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* EKF pre-update: preUpdateSynthKernel (2D), src/phdfilter.cu:1833-1924                   */
+/* ------------------------------------------------------------------------------------ */
+void o_preupdate(const o_pose* pose, const o_gaussian* feat, int n, const o_meas* z, int M,
+                 const o_config* cfg, float* pd, o_gaussian* preupdate)
+{
+    for (int i = 0; i < n; i++) {
+        const o_gaussian* f = &feat[i];
+        float dx, dy, r2, r, bearing;
+        o_predicted_measurement(pose, f->mean, &r, &r2, &bearing, &dx, &dy);
+
+        float feature_pd = 0;                                          /* :1848-1851 */
+        if (r <= cfg->maxRange && fabsf(bearing) <= cfg->maxBearing) feature_pd = cfg->pd;
+        pd[i] = feature_pd;
+
+        float J[4];                                                    /* :1854-1858 */
+        J[0] = dx / r;
+        J[2] = dy / r;
+        J[1] = -dy / r2;
+        J[3] = dx / r2;
+        const float* P = f->cov;
+
+        /* pow(stdRange,2) is CUDA's pow(float,int) overload: a float multiply (:1865,1868) */
+        float sigma[4];
+        sigma[0] = (P[0] * J[0] + J[2] * P[1]) * J[0] + (J[0] * P[2] + P[3] * J[2]) * J[2] + cfg->stdRange * cfg->stdRange;
+        sigma[1] = (P[0] * J[1] + J[3] * P[1]) * J[0] + (J[1] * P[2] + P[3] * J[3]) * J[2];
+        sigma[2] = (P[0] * J[0] + J[2] * P[1]) * J[1] + (J[0] * P[2] + P[3] * J[2]) * J[3];
+        sigma[3] = (P[0] * J[1] + J[3] * P[1]) * J[1] + (J[1] * P[2] + P[3] * J[3]) * J[3] + cfg->stdBearing * cfg->stdBearing;
+        sigma[1] = (sigma[1] + sigma[2]) / 2;                           /* :1871-1872 */
+        sigma[2] = sigma[1];
+        float det_sigma = sigma[0] * sigma[3] - sigma[1] * sigma[2];    /* :1874 */
+        float S[4];                                                    /* :1877-1881 */
+        S[0] = sigma[3] / det_sigma;
+        S[1] = -sigma[1] / det_sigma;
+        S[2] = -sigma[2] / det_sigma;
+        S[3] = sigma[0] / det_sigma;
+        float K[4];                                                    /* :1884-1888 */
+        K[0] = S[0] * (P[0] * J[0] + P[2] * J[2]) + S[1] * (P[0] * J[1] + P[2] * J[3]);
+        K[1] = S[0] * (P[1] * J[0] + P[3] * J[2]) + S[1] * (P[1] * J[1] + P[3] * J[3]);
+        K[2] = S[2] * (P[0] * J[0] + P[2] * J[2]) + S[3] * (P[0] * J[1] + P[2] * J[3]);
+        K[3] = S[2] * (P[1] * J[0] + P[3] * J[2]) + S[3] * (P[1] * J[1] + P[3] * J[3]);
+
+        /* Joseph form (I-KH)P(I-KH)^T + K R K^T, :1891-1894, same association as the reference */
+        float sr = cfg->stdRange, sb = cfg->stdBearing;
+        float a00 = 1 - K[0] * J[0] - K[2] * J[1];
+        float a01 = -K[0] * J[2] - K[2] * J[3];
+        float a10 = -K[1] * J[0] - K[3] * J[1];
+        float a11 = 1 - K[1] * J[2] - K[3] * J[3];
+        float cu[4];
+        cu[0] = (a00 * P[0] + a01 * P[1]) * a00 + (a00 * P[2] + a01 * P[3]) * a01 + K[0] * K[0] * sr * sr + K[2] * K[2] * sb * sb;
+        cu[2] = (a00 * P[0] + a01 * P[1]) * a10 + (a00 * P[2] + a01 * P[3]) * a11 + K[0] * sr * sr * K[1] + K[2] * sb * sb * K[3];
+        cu[1] = (a10 * P[0] + a11 * P[1]) * a00 + (a10 * P[2] + a11 * P[3]) * a01 + K[0] * sr * sr * K[1] + K[2] * sb * sb * K[3];
+        cu[3] = (a10 * P[0] + a11 * P[1]) * a10 + (a10 * P[2] + a11 * P[3]) * a11 + K[1] * K[1] * sr * sr + K[3] * K[3] * sb * sb;
+
+        float log_2pi = o_safe_log((float)(2 * M_PI));
+        float log_det = o_safe_log(det_sigma);
+        for (int m = 0; m < M; m++) {                                  /* :1898-1923 */
+            o_gaussian* g = &preupdate[(size_t)m * n + i];
+            float innov0 = z[m].range - r;
+            float innov1 = o_wrap_angle(z[m].bearing - bearing);
+            g->mean[0] = f->mean[0] + K[0] * innov0 + K[2] * innov1;
+            g->mean[1] = f->mean[1] + K[1] * innov0 + K[3] * innov1;
+            for (int k = 0; k < 4; k++) g->cov[k] = cu[k];
+            float dist = innov0 * innov0 * S[0] + innov0 * innov1 * (S[1] + S[2]) + innov1 * innov1 * S[3];
+            /* "- 0.5*dist - safeLog(2*M_PI) - 0.5*safeLog(det_sigma)": 0.5 is a double (:1911) */
+            float gl = (float)(-0.5 * (double)dist - (double)log_2pi - 0.5 * (double)log_det);
+            if (z[m].label == 0 || !cfg->labeledMeasurements)
+                g->weight = o_safe_log(feature_pd) + o_safe_log(f->weight) + gl; /* :1916-1917 */
+            else
+                g->weight = o_safe_log(0);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* GM-PHD update: phdUpdateKernel, src/phdfilter.cu:2119-2319 (particle_weighting == 0)    */
+/* ------------------------------------------------------------------------------------ */
+void o_update(const o_gaussian* feat, const float* pd, const o_gaussian* preupdate,
+              const o_gaussian* births, int n, int M, const o_config* cfg,
+              o_gaussian* slab, uint8_t* prune_flag, float* dlogw)
+{
+    int n_update = n * (M + 1) + M;
+    float cardinality_predict = 0;
+    /* slab order :2145-2172: [non-detect | detect m-major | births] */
+    for (int j = 0; j < n; j++) {
+        slab[j] = feat[j];
+        slab[j].weight = feat[j].weight * (1 - pd[j]);                  /* :2148 */
+        for (int m = 0; m < M; m++) slab[n + (size_t)m * n + j] = preupdate[(size_t)m * n + j];
+        cardinality_predict += pd[j] * feat[j].weight;                  /* :2160,2183-2184 */
+    }
+    for (int m = 0; m < M; m++) {
+        slab[n + (size_t)M * n + m] = births[m];
+        cardinality_predict += cfg->birthWeight;                        /* :2174 */
+    }
+    float particle_weight = 0;
+    for (int m = 0; m < M; m++) {                                       /* :2190-2253 */
+        o_gaussian* ptr = slab + n + (size_t)m * n;
+        float sum = 0;
+        for (int j = 0; j < n; j++) sum += expf(ptr[j].weight);         /* :2205-2209 */
+        sum += cfg->clutterDensity;                                      /* :2213 */
+        sum += cfg->birthWeight;                                         /* :2214 */
+        float log_normalizer = o_safe_log(sum);                          /* :2217 */
+        for (int j = 0; j < n; j++) ptr[j].weight = expf(ptr[j].weight - log_normalizer); /* :2242-2243 */
+        o_gaussian* b = slab + n + (size_t)M * n + m;                    /* :2239 */
+        b->weight = expf(b->weight - log_normalizer);
+        particle_weight += log_normalizer;                               /* :2251 */
+    }
+    particle_weight -= cardinality_predict;                              /* :2261 */
+    *dlogw = particle_weight;
+    for (int i = 0; i < n_update; i++)                                   /* :2308-2318 */
+        prune_flag[i] = (slab[i].weight < cfg->minFeatureWeight) ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* distances: src/device_math.cuh:62-69,308-325 and :373-413                               */
+/* ------------------------------------------------------------------------------------ */
+float o_mahal_dist(const o_gaussian* a, const o_gaussian* b)
+{
+    float sigma[4], inv[4];
+    for (int i = 0; i < 4; i++) sigma[i] = (a->cov[i] + b->cov[i]) / 2;
+    float det = sigma[0] * sigma[3] - sigma[2] * sigma[1];
+    inv[0] = sigma[3] / det;
+    inv[1] = -sigma[1] / det;
+    inv[2] = -sigma[2] / det;
+    inv[3] = sigma[0] / det;
+    float i0 = a->mean[0] - b->mean[0];
+    float i1 = a->mean[1] - b->mean[1];
+    return i0 * i0 * inv[0] + i0 * i1 * (inv[1] + inv[2]) + i1 * i1 * inv[3];
+}
+
+float o_hellinger_dist(const o_gaussian* a, const o_gaussian* b)
+{
+    float innov0 = a->mean[0] - b->mean[0];
+    float innov1 = a->mean[1] - b->mean[1];
+    float sigma[4], sinv[4] = {1, 0, 0, 1};
+    for (int i = 0; i < 4; i++) sigma[i] = a->cov[i] + b->cov[i];
+    float det = sigma[0] * sigma[3] - sigma[2] * sigma[1];
+    if (det > FLT_MIN) {
+        sinv[0] = sigma[3] / det;
+        sinv[1] = -sigma[1] / det;
+        sinv[2] = -sigma[2] / det;
+        sinv[3] = sigma[0] / det;
+    }
+    /* -0.25 is a double literal (:394) */
+    float epsilon = (float)(-0.25 * (double)(innov0 * innov0 * sinv[0] + innov0 * innov1 * (sinv[1] + sinv[2]) +
+                                              innov1 * innov1 * sinv[3]));
+    det /= 4;
+    float dist = 1 / det;
+    sigma[0] = a->cov[0] * b->cov[0] + a->cov[2] * b->cov[1];
+    sigma[1] = a->cov[1] * b->cov[0] + a->cov[3] * b->cov[1];
+    sigma[2] = a->cov[0] * b->cov[2] + a->cov[2] * b->cov[3];
+    sigma[3] = a->cov[1] * b->cov[2] + a->cov[3] * b->cov[3];
+    det = sigma[0] * sigma[3] - sigma[2] * sigma[1];
+    dist *= sqrtf(det);
+    dist = 1 - sqrtf(dist) * expf(epsilon);
+    return dist;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* merge: phdUpdateMergeKernel, src/phdfilter.cu:2739-2890                                 */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { float w; int idx; } o_sortkey;
+static int o_cmp_desc(const void* pa, const void* pb)
+{
+    const o_sortkey* a = (const o_sortkey*)pa;
+    const o_sortkey* b = (const o_sortkey*)pb;
+    if (a->w > b->w) return -1;
+    if (a->w < b->w) return 1;
+    return (a->idx > b->idx) - (a->idx < b->idx);
+}
+
+int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, float* margin_out)
+{
+    float margin_d = FLT_MAX, margin_w = FLT_MAX;
+    int n_out = 0;
+    if (n <= 0) {
+        if (margin_out) { margin_out[0] = margin_d; margin_out[1] = margin_w; }
+        return 0;
+    }
+    o_sortkey* order = (o_sortkey*)malloc(sizeof(o_sortkey) * n);
+    uint8_t* merged = (uint8_t*)calloc(n, 1);
+    uint8_t* member = (uint8_t*)malloc(n);
+    for (int i = 0; i < n; i++) { order[i].w = in[i].weight; order[i].idx = i; }
+    /* the arg-max of :2750-2788 with ties broken towards the lowest index == walking the
+     * components in (weight desc, index asc) order and taking the first unmerged one */
+    qsort(order, n, sizeof(o_sortkey), o_cmp_desc);
+    int first = 0;
+    while (1) {
+        while (first < n && merged[order[first].idx]) first++;
+        if (first >= n) break;                                          /* :2784 */
+        const o_gaussian* seed = &in[order[first].idx];
+        /* weight gap to the next unmerged candidate (tie-break sensitivity) */
+        for (int k = first + 1; k < n; k++) {
+            if (!merged[order[k].idx]) {
+                float gap = (seed->weight - in[order[k].idx].weight) / (fabsf(seed->weight) + FLT_MIN);
+                if (gap < margin_w) margin_w = gap;
+                break;
+            }
+        }
+        /* pass 1 (:2795-2830): members, weight, weighted mean — in sorted order, seed first */
+        float W = 0, sx = 0, sy = 0;
+        for (int k = first; k < n; k++) {
+            int i = order[k].idx;
+            member[i] = 0;
+            if (merged[i]) continue;
+            float d = (cfg->distanceMetric == 0) ? o_mahal_dist(seed, &in[i]) : o_hellinger_dist(seed, &in[i]);
+            if (k != first) {
+                float mg = fabsf(d - cfg->minSeparation) / (fabsf(cfg->minSeparation) + FLT_MIN);
+                if (mg < margin_d) margin_d = mg;
+            }
+            if (d < cfg->minSeparation) {                                /* :2806 */
+                member[i] = 1;
+                W += in[i].weight;
+                sx += in[i].weight * in[i].mean[0];
+                sy += in[i].weight * in[i].mean[1];
+            }
+        }
+        if (W == 0) break;                                              /* :2821 */
+        o_gaussian mg;
+        mg.weight = W;
+        mg.mean[0] = sx / W;                                            /* :2828 */
+        mg.mean[1] = sy / W;
+        /* pass 2 (:2837-2881) */
+        float c[4] = {0, 0, 0, 0};
+        for (int k = first; k < n; k++) {
+            int i = order[k].idx;
+            if (merged[i] || !member[i]) continue;
+            float d0 = mg.mean[0] - in[i].mean[0];                       /* :2854-2855 */
+            float d1 = mg.mean[1] - in[i].mean[1];
+            float dd[2] = {d0, d1};
+            for (int j = 0; j < 2; j++)
+                for (int kk = 0; kk < 2; kk++)
+                    c[j * 2 + kk] += in[i].weight * (in[i].cov[j * 2 + kk] + dd[j] * dd[kk]); /* :2863-2866 */
+            merged[i] = 1;                                              /* :2869 */
+        }
+        for (int j = 0; j < 4; j++) mg.cov[j] = c[j] / W;                /* :2879 */
+        /* force_symmetric_covariance, src/device_math.cuh:710-725: lower = (lower+upper)/2 */
+        mg.cov[1] = (mg.cov[1] + mg.cov[2]) / 2;
+        mg.cov[2] = mg.cov[1];
+        out[n_out++] = mg;                                              /* :2885-2887 */
+    }
+    free(order); free(merged); free(member);
+    if (margin_out) { margin_out[0] = margin_d; margin_out[1] = margin_w; }
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* literal transcription of reduceGaussianMixture, src/gm_reduce.cpp:57-134                */
+/* (Eigen LLT distance :30-37 written out for 2x2; std::sort is not stable, a stable sort   */
+/*  with index tie-break is used here)                                                     */
+/* ------------------------------------------------------------------------------------ */
+static float o_chol_dist(const o_gaussian* a, const o_gaussian* b)
+{
+    float d0 = a->mean[0] - b->mean[0], d1 = a->mean[1] - b->mean[1];
+    /* cov(i,j) = g.cov[i+dims*j] (:24): s00=cov[0], s10=cov[1], s01=cov[2], s11=cov[3] */
+    float s00 = 0.5f * (a->cov[0] + b->cov[0]);
+    float s10 = 0.5f * (a->cov[1] + b->cov[1]);
+    float s11 = 0.5f * (a->cov[3] + b->cov[3]);
+    float l00 = sqrtf(s00);
+    float l10 = s10 / l00;
+    float l11 = sqrtf(s11 - l10 * l10);
+    float x0 = d0 / l00;
+    float x1 = (d1 - l10 * x0) / l11;
+    return x0 * x0 + x1 * x1;
+}
+
+int o_gm_reduce(const o_gaussian* in, int n, float min_distance, o_gaussian* out)
+{
+    if (n <= 0) return 0;
+    o_sortkey* order = (o_sortkey*)malloc(sizeof(o_sortkey) * n);
+    uint8_t* gone = (uint8_t*)calloc(n, 1);
+    int* mlist = (int*)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) { order[i].w = in[i].weight; order[i].idx = i; }
+    qsort(order, n, sizeof(o_sortkey), o_cmp_desc);                       /* :75-77 */
+    int n_out = 0;
+    for (int f = 0; f < n; f++) {
+        if (gone[order[f].idx]) continue;
+        const o_gaussian* mx = &in[order[f].idx];                        /* :81-82 */
+        gone[order[f].idx] = 1;
+        int nm = 0;
+        for (int k = f + 1; k < n; k++) {                                /* :86-100 */
+            int i = order[k].idx;
+            if (gone[i]) continue;
+            if (o_chol_dist(mx, &in[i]) < min_distance) { mlist[nm++] = i; gone[i] = 1; }
+        }
+        float W = mx->weight;                                            /* :103-109 */
+        float m0 = mx->mean[0] * mx->weight, m1 = mx->mean[1] * mx->weight;
+        for (int k = 0; k < nm; k++) {
+            m0 += in[mlist[k]].weight * in[mlist[k]].mean[0];
+            m1 += in[mlist[k]].weight * in[mlist[k]].mean[1];
+            W += in[mlist[k]].weight;
+        }
+        m0 /= W; m1 /= W;
+        float d0 = m0 - mx->mean[0], d1 = m1 - mx->mean[1];              /* :110-112 */
+        float c00 = mx->weight * (mx->cov[0] + d0 * d0);
+        float c10 = mx->weight * (mx->cov[1] + d1 * d0);
+        float c01 = mx->weight * (mx->cov[2] + d0 * d1);
+        float c11 = mx->weight * (mx->cov[3] + d1 * d1);
+        for (int k = 0; k < nm; k++) {                                   /* :114-118 */
+            const o_gaussian* g = &in[mlist[k]];
+            d0 = m0 - g->mean[0]; d1 = m1 - g->mean[1];
+            c00 += g->weight * (g->cov[0] + d0 * d0);
+            c10 += g->weight * (g->cov[1] + d1 * d0);
+            c01 += g->weight * (g->cov[2] + d0 * d1);
+            c11 += g->weight * (g->cov[3] + d1 * d1);
+        }
+        o_gaussian r;
+        r.weight = W;
+        r.mean[0] = m0; r.mean[1] = m1;
+        r.cov[0] = c00 / W; r.cov[1] = c10 / W; r.cov[2] = c01 / W; r.cov[3] = c11 / W; /* :119-129 */
+        out[n_out++] = r;
+    }
+    free(order); free(gone); free(mlist);
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* one particle's measurement update, src/phdfilter.cu:3336-3761 restricted to one map     */
+/* ------------------------------------------------------------------------------------ */
+int o_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                      const o_config* cfg, o_gaussian* map_out, float* dlogw,
+                      o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
+                      float* margin_out)
+{
+    int8_t* cls = (int8_t*)malloc(n_map > 0 ? n_map : 1);
+    o_classify(map, n_map, pose, cfg, cls);
+    int n_in = 0, n_near = 0, n_out0 = 0;
+    for (int i = 0; i < n_map; i++) { n_in += cls[i] == 1; n_near += cls[i] == 2; n_out0 += cls[i] == 0; }
+    /* stable 3-way partition, src/phdfilter.cu:3048-3056 */
+    o_gaussian* f_in = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_in + 1));
+    o_gaussian* f_near = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_near + 1));
+    o_gaussian* f_out = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_out0 + 1));
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < n_map; i++) {
+        if (cls[i] == 1) f_in[a++] = map[i];
+        else if (cls[i] == 2) f_near[b++] = map[i];
+        else f_out[c++] = map[i];
+    }
+    size_t n_update = (size_t)n_in * (M + 1) + M;
+    o_gaussian* births = (o_gaussian*)malloc(sizeof(o_gaussian) * (M + 1));
+    o_gaussian* pre = (o_gaussian*)malloc(sizeof(o_gaussian) * ((size_t)n_in * M + 1));
+    float* pd = (float*)malloc(sizeof(float) * (n_in + 1));
+    o_gaussian* slab = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_update + n_near + 1));
+    uint8_t* flag = (uint8_t*)malloc(n_update + 1);
+    o_births(pose, z, M, cfg, births);
+    o_preupdate(pose, f_in, n_in, z, M, cfg, pd, pre);
+    o_update(f_in, pd, pre, births, n_in, M, cfg, slab, flag, dlogw);
+    /* prune: stable compaction (thrust::remove_copy_if, src/phdfilter.cu:3134-3137) */
+    int ns = 0;
+    for (size_t i = 0; i < n_update; i++) {
+        if (!flag[i]) {
+            if (surv_slab_idx) surv_slab_idx[ns] = (int32_t)i;
+            slab[ns++] = slab[i];
+        }
+    }
+    /* recombine with the nearly-in-range features (src/phdfilter.cu:3227-3257) */
+    for (int i = 0; i < n_near; i++) {
+        if (surv_slab_idx) surv_slab_idx[ns] = (int32_t)(n_update + i);
+        slab[ns++] = f_near[i];
+    }
+    if (survivors_out) memcpy(survivors_out, slab, sizeof(o_gaussian) * ns);
+    if (n_survivors_out) *n_survivors_out = ns;
+    int nm = o_merge(slab, ns, cfg, map_out, margin_out);
+    /* append the out-of-range features (src/phdfilter.cu:3311-3318) */
+    for (int i = 0; i < n_out0; i++) map_out[nm++] = f_out[i];
+    free(cls); free(f_in); free(f_near); free(f_out); free(births); free(pre); free(pd); free(slab); free(flag);
+    return nm;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* particle weights                                                                       */
+/* ------------------------------------------------------------------------------------ */
+void o_normalize_weights(float* logw, const float* dlogw, int n)
+{
+    if (dlogw) for (int i = 0; i < n; i++) logw[i] += dlogw[i];          /* src/phdfilter.cu:3741-3744 */
+    float maxval = logw[0];                                              /* logSumExp, device_math.cuh:549-558 */
+    for (int i = 1; i < n; i++) if (logw[i] > maxval) maxval = logw[i];
+    float sum = 0;
+    for (int i = 0; i < n; i++) sum += expf(logw[i] - maxval);
+    float lse = o_safe_log(sum) + maxval;
+    for (int i = 0; i < n; i++) logw[i] -= lse;                          /* :3751-3754 */
+}
+
+float o_neff(const float* logw, int n)
+{
+    float nEff = 0;                                                      /* src/main.cpp:1281-1284 */
+    for (int i = 0; i < n; i++) nEff += expf(2 * logw[i]);
+    nEff = (float)(1.0 / (double)nEff / (double)n);
+    return nEff;
+}
+
+void o_resample(const float* logw, int n, const double* uniforms, int n_uniforms, int n_new, int32_t* idx)
+{
+    double interval = 1.0 / n_new;                                       /* src/main.cpp:461 */
+    double r = uniforms[0] * interval;                                   /* :462 */
+    double c = o_det_exp(logw[0]);                                       /* :463 */
+    int i = 0;
+    for (int j = 0; j < n_new; j++) {
+        /* :468 "r = j*interval + randu01()*interval".  The RNG draw is an input here: one uniform
+         * per stratum (stratified, HEAD) or the same uniform for every j (n_uniforms == 1:
+         * systematic, the scheme of src/phdfilter.cu.bak:3279-3327 written in HEAD's expression) */
+        r = j * interval + uniforms[n_uniforms == 1 ? 0 : j] * interval;
+        while (r > c) {                                                  /* :469 */
+            i++;
+            if (i >= n || i < 0) {                                       /* :475-490 */
+                double max_weight = -1;
+                int max_idx = -1;
+                for (int k = 0; k < n; k++) {
+                    double e = o_det_exp(logw[k]);
+                    if (e > max_weight) { max_weight = e; max_idx = k; }
+                }
+                i = max_idx;
+                c = 2;
+                break;
+            }
+            c += o_det_exp(logw[i]);                                     /* :495 */
+        }
+        idx[j] = i;
+        r += interval;                                                   /* :497 (dead store, as in HEAD) */
+    }
+}
+
+void o_expected_pose(const o_pose* poses, const float* logw, int n, o_pose* out)
+{
+    if (n == 1) { *out = poses[0]; return; }                             /* src/main.cpp:381-384 */
+    o_pose e = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {                                        /* :331-340 */
+        float w = expf(logw[i]);
+        e.px += w * poses[i].px;
+        e.py += w * poses[i].py;
+        e.ptheta += w * poses[i].ptheta;
+        e.vx += w * poses[i].vx;
+        e.vy += w * poses[i].vy;
+        e.vtheta += w * poses[i].vtheta;
+    }
+    *out = e;
+}
+
+int o_argmax_weight(const float* logw, int n)
+{
+    float max_weight = -FLT_MAX;                                          /* src/main.cpp:347-356 */
+    int max_idx = -1;
+    for (int i = 0; i < n; i++)
+        if (logw[i] > max_weight) { max_idx = i; max_weight = logw[i]; }
+    return max_idx;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* whole step (run_synth loop body, src/main.cpp:1244-1297) on fixed-capacity slabs        */
+/* ------------------------------------------------------------------------------------ */
+int o_step(o_pose* poses, float* logw, o_gaussian* maps, int32_t* sizes, int n_particles, int cap,
+           float alpha, float v_encoder, const float* noise, const o_meas* z, int M,
+           const o_config* cfg, double uniform, int force_resample,
+           o_gaussian* maps_out, int32_t* sizes_out, int32_t* idx_out, float* neff_out, int n_threads)
+{
+    int overflow = 0;
+    o_predict_ackerman(poses, n_particles, alpha, v_encoder, noise, cfg);
+    float* dlogw = (float*)malloc(sizeof(float) * n_particles);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        size_t tmp_n = (size_t)cap * (M + 2) + M + 1;
+        o_gaussian* tmp = (o_gaussian*)malloc(sizeof(o_gaussian) * tmp_n);
+#pragma omp for schedule(dynamic, 4)
+        for (int p = 0; p < n_particles; p++) {
+            int nm = o_update_particle(&poses[p], maps + (size_t)p * cap, sizes[p], z, M, cfg, tmp, &dlogw[p],
+                                       NULL, NULL, NULL, NULL);
+            if (nm > cap) {
+#pragma omp atomic write
+                overflow = 1;
+                nm = cap;
+            }
+            memcpy(maps_out + (size_t)p * cap, tmp, sizeof(o_gaussian) * nm);
+            sizes_out[p] = nm;
+        }
+        free(tmp);
+    }
+    o_normalize_weights(logw, dlogw, n_particles);
+    float neff = o_neff(logw, n_particles);
+    if (neff_out) *neff_out = neff;
+    if (force_resample || (neff <= cfg->resampleThresh && M > 0)) {
+        o_resample(logw, n_particles, &uniform, 1, n_particles, idx_out);
+    } else {
+        for (int i = 0; i < n_particles; i++) idx_out[i] = i;
+    }
+    free(dlogw);
+    return overflow ? -1 : 0;
+}

@@ -1,0 +1,148 @@
+"""CPU tests: the C-ABI library loads, exports every symbol include/phdslam.h declares, keeps the
+reference's POD layouts, fails loudly without a GPU, and the host-side boundary helpers (config
+parser, loaders, state_estimate writer) behave like the reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from parity_utils import pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    P = pkg()
+    L = P._lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "phdslam.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(phd_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) > 40
+    for name in sorted(declared):
+        assert hasattr(L, name), "libphdslam.so does not export %s" % name
+    # the binding covers exactly the header
+    assert declared == set(P._lib.SYMBOLS), declared ^ set(P._lib.SYMBOLS)
+
+
+def test_pod_layouts_match_the_reference():
+    """sizes/offsets measured from the reference's src/slamtypes.h with the reference header itself"""
+    P = pkg()
+    assert C.sizeof(P.SlamConfig) == 324
+    for field, off in (("dt", 80), ("minRange", 84), ("n_particles", 196), ("birthWeight", 212),
+                       ("minSeparation", 232), ("filterType", 260), ("labeledMeasurements", 292), ("l", 296),
+                       ("saveAllMaps", 320)):
+        assert getattr(P.SlamConfig, field).offset == off, field
+    assert P.GAUSSIAN.itemsize == 28 and P.GAUSSIAN.fields["mean"][1] == 16 and P.GAUSSIAN.fields["weight"][1] == 24
+    assert P.POSE.itemsize == 24 and P.MEAS.itemsize == 12 and P.NOISE.itemsize == 8
+    assert C.sizeof(P.Control) == 8 and P.Control.alpha.offset == 0  # alpha first (slamtypes.h:84-87)
+
+
+def test_compute_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    P = pkg()
+    with pytest.raises(P.PhdError) as e:
+        P.PhdFilter(P.default_config(), n_particles=4)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_out_of_scope_configs_are_rejected():
+    P = pkg()
+    for over in (dict(featureModel=2), dict(particleWeighting=1), dict(filterType=1), dict(motionType=0),
+                 dict(nPredictParticles=4)):
+        with pytest.raises(P.PhdError) as e:
+            P.PhdFilter(P.default_config(**over), n_particles=4)
+        assert e.value.code == -4, over
+
+
+def test_config_parser():
+    P = pkg()
+    cfg, ddir, nsteps = P.load_config(os.path.join(GOLD, "config_sample.cfg"))
+    assert ddir == "/data/synth_bowtie/" and nsteps == -1
+    assert cfg.n_particles == 200 and cfg.motionType == 1 and cfg.filterType == 0 and cfg.mapEstimate == 1
+    f32 = np.float32
+    assert cfg.maxRange == 15.0 and f32(cfg.stdBearing) == f32(0.008727) and f32(cfg.minFeatureWeight) == f32(1e-6)
+    assert f32(cfg.birthWeight) == f32(1e-4) and cfg.minSeparation == 10 and cfg.gateBirths == 0
+    # derived clutter density (src/main.cpp:1065-1066)
+    assert f32(cfg.clutterDensity) == f32(20.0) / (f32(2) * f32(3.141593) * f32(15.0))
+    # keys not in the file keep loadConfig's defaults (src/main.cpp:960-1048)
+    assert f32(cfg.ps) == f32(0.98) and cfg.maxSteps == 10000 and cfg.imageWidth == 600
+    d = P.default_config()
+    assert f32(d.clutterDensity) == f32(cfg.clutterDensity)
+
+
+def test_config_parser_errors(tmp_path):
+    P = pkg()
+    bad = tmp_path / "bad.cfg"
+    bad.write_text("n_particles = 12\nno_such_key = 3\n")
+    with pytest.raises(P.PhdError) as e:
+        P.load_config(str(bad))
+    assert e.value.code == -8 and "no_such_key" in str(e.value)
+    bad.write_text("n_particles = twelve\n")
+    with pytest.raises(P.PhdError):
+        P.load_config(str(bad))
+    with pytest.raises(P.PhdError) as e:
+        P.load_config(str(tmp_path / "missing.cfg"))
+    assert e.value.code == -7
+
+
+def test_measurement_loader_kat():
+    """golden: sim.data(k).measurements of the reference's simData2_ackerman.mat (tests/golden/make_golden.py)"""
+    P = pkg()
+    k = np.load(os.path.join(GOLD, "meas_ackerman_head.npz"))
+    steps = P.load_measurements(os.path.join(GOLD, "meas_ackerman_head.txt"))
+    assert [len(s) for s in steps] == list(k["sizes"])
+    got = np.concatenate([np.stack([s["range"], s["bearing"]], 1) for s in steps])
+    assert np.array_equal(got, k["values"].astype(np.float32))
+    assert all(np.all(s["label"] == 0) for s in steps)
+
+
+def test_loaders_formats(tmp_path):
+    P = pkg()
+    m = tmp_path / "m.txt"
+    # no header, blank line = empty step, trailing blank dropped (README:21-24)
+    m.write_text("1.5 0.25 2.5 -0.5 \n\n3.0 1.0\n\n")
+    steps = P.load_measurements(str(m))
+    assert [len(s) for s in steps] == [2, 0, 1]
+    assert steps[0]["range"][1] == np.float32(2.5) and steps[2]["bearing"][0] == np.float32(1.0)
+    # HEAD's triples "r b label" (src/main.cpp:197-205)
+    m.write_text("% header\n1.5 0.25 0 2.5 -0.5 1\n")
+    steps = P.load_measurements(str(m), triples=True)
+    assert len(steps) == 1 and list(steps[0]["label"]) == [0, 1]
+    m.write_text("1.5 0.25 2.5\n")
+    with pytest.raises(P.PhdError):
+        P.load_measurements(str(m))
+    c = tmp_path / "c.txt"
+    c.write_text("% velocity\tsteering angle\n2.77796 -0.186915\n -1.86367 0.0325645\n")
+    u = P.load_controls(str(c))
+    assert len(u) == 2 and u["v_encoder"][0] == np.float32(2.77796) and u["alpha"][1] == np.float32(0.0325645)
+    c.write_text("-2.67593185455, 0.177010013139\n-2.28943695145, 0.0187330928094\n")  # comma separated, no header
+    u = P.load_controls(str(c))
+    assert len(u) == 2 and u["alpha"][0] == np.float32(0.177010013139)
+
+
+def test_state_log_format(tmp_path):
+    """the 5-line contract the reference's consumers parse (README:31-39; python/batch_analyze.py:16-24)"""
+    P = pkg()
+    e = np.zeros(1, P.POSE)
+    e["px"], e["py"], e["ptheta"] = 1.25, -2.5, 0.125
+    g = np.zeros(2, P.GAUSSIAN)
+    g["weight"] = [0.5, 1.5]
+    g["mean"] = [[1, 2], [3, 4]]
+    g["cov"] = [[0.1, 0.01, 0.01, 0.2], [0.3, 0.0, 0.0, 0.4]]
+    poses = np.zeros(3, P.POSE)
+    poses["px"] = [1, 2, 3]
+    lw = np.log(np.array([0.2, 0.3, 0.5], np.float32))
+    P.write_state_log(str(tmp_path), 7, e, g, lw, poses, max_cardinality=4)
+    lines = open(tmp_path / "state_estimate00007.log").read().split("\n")
+    assert len(lines) == 6 and lines[5] == ""
+    assert [float(x) for x in lines[0].split()] == [1.25, -2.5, 0.125, 0, 0, 0]
+    m = np.array(lines[1].split(), float).reshape(-1, 7)   # weight mx my c0 c1 c2 c3
+    assert np.allclose(m[:, 0], [0.5, 1.5]) and np.allclose(m[1, 1:3], [3, 4]) and np.allclose(m[0, 3:], [0.1, 0.01, 0.01, 0.2])
+    assert np.allclose(np.array(lines[2].split(), float), lw, rtol=1e-5)
+    assert len(lines[3].split()) == 18 and lines[4].split() == ["0"] * 5
+    assert all(l.endswith(" ") for l in lines[:5])

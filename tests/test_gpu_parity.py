@@ -1,0 +1,407 @@
+"""GPU parity tests: the hand-written gfx950 path (through the C-ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): floating point within a stated tolerance, resampling indices
+bit-exact; additionally the merge stage — which contains no transcendental — is checked BIT FOR
+BIT against the oracle on identical survivor inputs.
+
+Tolerances (fp32, both sides): component weights rtol 5e-4 (exp of a Mahalanobis distance up to
+~30 amplifies 1-ulp differences of atan2f/logf between glibc and the ROCm device library),
+means 2e-4 m, covariances rtol 2e-3, particle log-weight increments 2e-3 absolute.
+
+Structural decisions (prune w < minFeatureWeight, merge d < minSeparation, seed order) can flip
+under 1-ulp differences; the oracle reports how close each decision came to its threshold and a
+particle is compared structurally only when its margins are larger than the fp noise.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from parity_utils import assert_maps_close, oracle_config_from, oracle_full_update, pkg, synthetic
+
+pytestmark = pytest.mark.gpu
+
+PRUNE_MARGIN = 2e-3   # relative distance of a weight to minFeatureWeight below which the decision may flip
+MERGE_MARGIN = 2e-4   # relative distance of a merge distance to minSeparation
+
+
+def make_filter(cfg, w, cap=None, mm=64, scap=0):
+    P = pkg()
+    N, G = w["N"], w["G"]
+    f = P.PhdFilter(cfg, n_particles=N, map_capacity=cap or 2 * G, max_measurements=mm, survivor_capacity=scap)
+    f.set_particles(w["poses"], w["logw"])
+    f.set_maps(w["maps"], w["sizes"])
+    return f
+
+
+def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, scap=0):
+    """one measurement update of every particle: survivors, merged map, Δlog-weight"""
+    ocfg = oracle_config_from(cfg)
+    n_struct = 0
+    with make_filter(cfg, w, cap, mm, scap) as f:
+        f.debug(True)
+        f.update(z)
+        st = f.status()
+        maps = f.get_maps()
+        dlw = f.weight_increments()
+        _, logw = f.get_particles()
+        for p in range(w["N"]):
+            gmap = w["maps"][p, :w["sizes"][p]]
+            ref = oracle_full_update(w["poses"][p], gmap, z, ocfg)
+            surv, sidx = f.survivors(p)
+            assert abs(dlw[p] - ref["dlogw"]) < 2e-3 + 2e-4 * abs(ref["dlogw"]), (p, dlw[p], ref["dlogw"])
+            # merge stage bit for bit: the oracle's merge applied to the GPU's own survivors
+            out0 = gmap[ref["cls"] == 0]
+            om = O.merge(surv, ocfg)
+            want = np.concatenate([om, out0]) if len(out0) else om
+            assert len(maps[p]) == len(want), (p, len(maps[p]), len(want))
+            for fld in ("weight", "mean", "cov"):
+                assert np.array_equal(maps[p][fld].view(np.uint32), want[fld].view(np.uint32)), \
+                    "particle %d: merge not bit-exact in %s (max diff %g)" % (p, fld, np.abs(maps[p][fld] - want[fld]).max())
+            # update stage against the oracle, when no decision is fp-marginal
+            structural = ref["prune_margin"] > PRUNE_MARGIN
+            if structural:
+                assert np.array_equal(sidx, ref["slab_idx"]), "particle %d: survivor sets differ" % p
+                assert_maps_close(surv, ref["survivors"], ordered=True, what="survivors of particle %d" % p)
+                if ref["margin"][0] > MERGE_MARGIN:
+                    n_struct += 1
+                    assert_maps_close(maps[p], ref["map"], what="map of particle %d" % p)
+        # normalised particle weights
+        ref_lw = O.normalize_weights(w["logw"], dlw)
+        assert np.abs(logw - ref_lw).max() < 1e-5
+    assert n_struct >= min_structural * w["N"], "only %d of %d particles were structurally comparable" % (n_struct, w["N"])
+    return st
+
+
+# ----------------------------------------------------------------------------------------------
+def test_predict():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(300, 4, 4, seed=11)
+    cfg = P.default_config()
+    with make_filter(cfg, w) as f:
+        f.predict((2.0, 0.05), w["noise"][0])
+        poses, _ = f.get_particles()
+    ref = O.predict_ackerman(w["poses"], 0.05, 2.0, w["noise"][0], oracle_config_from(cfg))
+    for k in ("px", "py", "ptheta"):
+        assert np.abs(poses[k] - ref[k]).max() < 2e-6, k
+    assert np.all(poses["vx"] == 0) and np.all(poses["vtheta"] == 0)
+
+
+def test_predict_device_rng_is_seeded_and_reproducible():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(512, 4, 4, seed=12)
+    cfg = P.default_config()
+    outs = []
+    for seed in (1, 1, 2):
+        with make_filter(cfg, w) as f:
+            f.seed(seed)
+            f.predict((2.0, 0.05), None)
+            outs.append(f.get_particles()[0])
+    assert np.array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0]["px"], outs[2]["px"])
+    # the drawn noise has the configured spread: v_encoder noise std 1.0 -> dx std ~ dt * 1.0
+    dx = outs[0]["px"] - w["poses"]["px"]
+    assert 0.05 < dx.std() < 0.2
+
+
+@pytest.mark.parametrize("seed,N,G,M", [(21, 8, 24, 10), (22, 6, 64, 32), (23, 4, 100, 64), (24, 3, 40, 1)])
+def test_update_small(seed, N, G, M):
+    P, S = pkg(), synthetic()
+    w = S.make_workload(N, G, M, seed=seed)
+    check_update_against_oracle(P.default_config(), w, w["z"][0])
+
+
+def test_update_clustered_merge_stress():
+    """config-3 style landmarks (clusters of 8 at 0.2 m): heavy merging"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(4, 256, 64, seed=31, clustered=True)
+    st = check_update_against_oracle(P.default_config(), w, w["z"][0], cap=512, min_structural=0.25)
+    assert st["max_survivors"] > 400
+
+
+def test_update_max_measurements_and_full_map():
+    """M = 256 (the reference's cap) and a map that fills its slab"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(2, 48, 256, seed=32)
+    check_update_against_oracle(P.default_config(), w, w["z"][0], cap=48 * 2 + 160, mm=256, min_structural=0.0)
+
+
+def test_update_clamps_measurements_like_the_reference():
+    """more measurements than max_measurements: clamped (src/phdfilter.cu:3390-3394)"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(2, 16, 40, seed=33)
+    cfg = P.default_config()
+    with make_filter(cfg, w, mm=32) as f:
+        f.update(w["z"][0])
+        a = f.get_maps()
+    with make_filter(cfg, w, mm=32) as f:
+        f.update(w["z"][0][:32])
+        b = f.get_maps()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_update_ragged_empty_and_out_of_range():
+    """ragged map sizes incl. empty maps; narrow field of view -> in-range / nearly / out classes"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(8, 40, 12, seed=34)
+    w["sizes"] = np.array([0, 1, 5, 40, 17, 0, 33, 2], np.int32)
+    cfg = P.default_config(maxRange=9.0, maxBearing=1.2, minRange=1.5, clutterRate=5.0)
+    ocfg = oracle_config_from(cfg)
+    # all three classes occur
+    cls = np.concatenate([O.classify(w["maps"][p, :w["sizes"][p]], w["poses"][p], ocfg) for p in range(8)])
+    assert set(np.unique(cls)) == {0, 1, 2}
+    check_update_against_oracle(cfg, w, w["z"][0], min_structural=0.4)
+
+
+def test_update_labeled_measurements():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(4, 24, 10, seed=35)
+    z = w["z"][0].copy()
+    z["label"][::2] = 1  # dynamic-labelled measurements contribute nothing to static features (:1913)
+    check_update_against_oracle(P.default_config(labeledMeasurements=1), w, z)
+
+
+def test_update_hellinger_metric():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(4, 32, 12, seed=36)
+    check_update_against_oracle(P.default_config(distanceMetric=1, minSeparation=0.6), w, w["z"][0], min_structural=0.25)
+
+
+def test_merge_degenerate_thresholds():
+    """minSeparation <= 0: nothing merges, the reference's loop stops with an empty map"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(2, 16, 6, seed=37)
+    check_update_against_oracle(P.default_config(minSeparation=0.0), w, w["z"][0], min_structural=0.0)
+
+
+def test_no_measurements_is_a_noop():
+    """the reference skips phdUpdateSynth when Z is empty (src/main.cpp:1260)"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(4, 8, 4, seed=38)
+    with make_filter(P.default_config(), w) as f:
+        f.update(np.zeros(0, P.MEAS))
+        maps = f.get_maps()
+        _, lw = f.get_particles()
+    assert np.array_equal(lw, w["logw"])
+    for p in range(4):
+        assert np.array_equal(maps[p], w["maps"][p])
+
+
+def test_capacity_overflow_is_reported():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(2, 30, 12, seed=39)
+    cfg = P.default_config()
+    with make_filter(cfg, w, cap=32) as f:       # births push the map over 32
+        f.update(w["z"][0])
+        with pytest.raises(P.PhdError) as e:
+            f.status()
+        assert e.value.code == -5 and "map_capacity" in str(e.value)
+    with pytest.raises(P.PhdError):
+        P.PhdFilter(cfg, n_particles=2, map_capacity=16).set_maps(w["maps"], w["sizes"])
+
+
+# ----------------------------------------------------------------------------------------------
+# particle weights, nEff, resampling
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 2048, 2049, 5000])
+def test_resample_bit_exact(n):
+    P = pkg()
+    rng = np.random.default_rng(n)
+    cfg = P.default_config()
+    lw = O.normalize_weights(rng.normal(0, 2.0, n).astype(np.float32))
+    poses = np.zeros(n, P.POSE)
+    poses["px"] = np.arange(n)
+    with P.PhdFilter(cfg, n_particles=n, map_capacity=8, max_measurements=8) as f:
+        f.set_particles(poses, lw)
+        assert abs(f.neff() - O.neff(lw)) < 1e-5 * max(1.0, O.neff(lw))
+        u = float(rng.uniform())
+        idx = f.resample(u)
+        assert np.array_equal(idx, O.resample(lw, u)), "systematic"
+        p2, lw2 = f.get_particles()
+        assert np.array_equal(p2["px"], poses["px"][idx])                      # copy_particles
+        assert np.all(lw2 == np.float32(-np.log(float(n))))                     # slamtypes.h:327
+        # stratified (HEAD) on the fresh uniform weights
+        f.set_particles(poses, lw)
+        us = rng.uniform(0, 1, n)
+        idx = f.resample(us)
+        assert np.array_equal(idx, O.resample(lw, us)), "stratified"
+
+
+def test_resample_overflow_guard():
+    """weights summing to < 1: the tail goes to the arg-max particle (src/main.cpp:475-494)"""
+    P = pkg()
+    lw = np.log(np.array([0.1, 0.4, 0.2, 0.05], np.float32))
+    with P.PhdFilter(P.default_config(), n_particles=4, map_capacity=8, max_measurements=8) as f:
+        f.set_particles(None, lw)
+        idx = f.resample(0.9)
+        assert np.array_equal(idx, O.resample(lw, 0.9))
+        assert idx[-1] == 1
+
+
+def test_resample_carries_maps_and_composes():
+    """maps follow their parents through two resamples without an update in between"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(64, 6, 4, seed=41)
+    lw = O.normalize_weights(np.random.default_rng(5).normal(0, 2, 64).astype(np.float32))
+    with make_filter(P.default_config(), w) as f:
+        f.set_particles(None, lw)
+        i1 = f.resample(0.3)
+        f.set_particles(None, lw)
+        i2 = f.resample(0.8)
+        maps = f.get_maps()
+        f.set_map(5, w["maps"][0, :3])            # forces the indirection to be materialised
+        maps2 = f.get_maps()
+    comp = i1[i2]
+    for p in range(64):
+        assert np.array_equal(maps[p], w["maps"][comp[p]])
+        assert np.array_equal(maps2[p], w["maps"][0, :3] if p == 5 else w["maps"][comp[p]])
+
+
+def test_resample_if_needed_follows_neff():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(128, 4, 4, seed=42)
+    cfg = P.default_config()
+    uniform_lw = np.full(128, -np.log(128.0), np.float32)
+    skew = O.normalize_weights(np.random.default_rng(1).normal(0, 3, 128).astype(np.float32))
+    with make_filter(cfg, w) as f:
+        f.set_particles(None, uniform_lw)
+        did, idx = f.resample_if_needed(0.5)
+        assert not did and np.array_equal(idx, np.arange(128))
+        f.set_particles(None, skew)
+        assert O.neff(skew) < 0.5
+        did, idx = f.resample_if_needed(0.5, had_measurements=False)
+        assert not did                                                        # src/main.cpp:1286
+        did, idx = f.resample_if_needed(0.5)
+        assert did and np.array_equal(idx, O.resample(skew, 0.5))
+
+
+def test_state_estimate():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(500, 6, 4, seed=43)
+    with make_filter(P.default_config(), w) as f:
+        e = f.expected_pose()
+        m, who = f.map_estimate()
+    ref = O.expected_pose(w["poses"], w["logw"])
+    for k in ("px", "py", "ptheta"):
+        assert abs(e[k] - ref[k]) < 1e-5
+    assert who == O.argmax_weight(w["logw"])
+    assert np.array_equal(m, w["maps"][who])
+
+
+# ----------------------------------------------------------------------------------------------
+# whole steps
+# ----------------------------------------------------------------------------------------------
+def test_step_sequence_matches_staged_calls_and_oracle():
+    P, S = pkg(), synthetic()
+    w = S.make_workload(32, 20, 10, seed=51, n_meas_sets=3)
+    cfg = P.default_config()
+    ocfg = oracle_config_from(cfg)
+    import torch
+    dev = torch.device("cuda:0")
+    with make_filter(cfg, w, cap=96) as a, make_filter(cfg, w, cap=96) as b:
+        for k in range(3):
+            # a: fused step on device-resident inputs; b: staged host calls
+            dz = torch.from_numpy(w["z"][k].view(np.uint8).copy()).to(dev)
+            dn = torch.from_numpy(w["noise"][k].copy()).to(dev)
+            torch.cuda.synchronize()
+            a.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), len(w["z"][k]), w["uniform"][k], force_resample=True)
+            a.sync()
+            b.predict((2.0, 0.05), w["noise"][k])
+            b.update(w["z"][k])
+            _, lw_b = b.get_particles()
+            idx_b = b.resample(w["uniform"][k])
+            assert np.array_equal(idx_b, O.resample(lw_b, w["uniform"][k]))
+            pa, la = a.get_particles()
+            pb, lb = b.get_particles()
+            assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+            ma, mb = a.get_maps(), b.get_maps()
+            for x, y in zip(ma, mb):
+                assert np.array_equal(x, y)
+        a.status()
+    # oracle trajectory without resampling decisions entering (first step only is strictly comparable)
+    cap = 96
+    om = np.zeros((32, cap), O.GAUSSIAN)
+    om[:, :20] = w["maps"]
+    r = O.step(w["poses"], w["logw"], om, w["sizes"], cap, 0.05, 2.0, w["noise"][0], w["z"][0], ocfg, w["uniform"][0], False)
+    with make_filter(cfg, w, cap=96) as f:
+        f.predict((2.0, 0.05), w["noise"][0])
+        f.update(w["z"][0])
+        _, lw = f.get_particles()
+        sizes = f.map_sizes()
+    assert np.abs(lw - r["logw"]).max() < 2e-3
+    assert (sizes == r["sizes"]).mean() > 0.8
+
+
+def test_frozen_steps_restart_from_the_same_snapshot():
+    """the bench protocol: frozen steps do not commit, so every iteration does identical work"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(16, 12, 6, seed=52)
+    import torch
+    dev = torch.device("cuda:0")
+    dz = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    dn = torch.from_numpy(w["noise"][0].copy()).to(dev)
+    torch.cuda.synchronize()
+    with make_filter(P.default_config(), w, cap=64) as f:
+        f.set_frozen(True)
+        for _ in range(3):
+            f.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), 6, 0.4, force_resample=True)
+        f.sync()
+        p, lw = f.get_particles()
+        maps = f.get_maps()
+        assert np.array_equal(p, w["poses"]) and np.array_equal(lw, w["logw"])
+        for q in range(16):
+            assert np.array_equal(maps[q], w["maps"][q])
+        f.set_frozen(False)
+        f.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), 6, 0.4, force_resample=True)
+        f.sync()
+        assert not np.array_equal(f.get_particles()[0], w["poses"])
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + sampled oracle comparison
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_id,sample", [(2, 24), (3, 6)])
+def test_full_size_properties(cfg_id, sample):
+    P, S = pkg(), synthetic()
+    w = S.config_workload(cfg_id)
+    N, G, M = w["N"], w["G"], w["M"]
+    cfg = P.default_config()
+    ocfg = oracle_config_from(cfg)
+    outs = []
+    for rep in range(2):
+        with make_filter(cfg, w, cap=2 * G, mm=M) as f:
+            f.debug(rep == 0)
+            f.predict((2.0, 0.05), w["noise"][0])
+            f.update(w["z"][0])
+            st = f.status()
+            poses, lw = f.get_particles()
+            maps = f.get_maps()
+            if rep == 0:
+                # merge conserves mass: sum of map weights == sum of survivor weights (+ untouched features)
+                for p in range(0, N, max(N // 64, 1)):
+                    surv, _ = f.survivors(p)
+                    assert abs(maps[p]["weight"].astype(np.float64).sum() - surv["weight"].astype(np.float64).sum()) \
+                        < 1e-4 * max(1.0, surv["weight"].sum())
+                    # symmetric covariances, finite values
+                    assert np.all(np.isfinite(maps[p]["weight"])) and np.all(maps[p]["cov"][:, 1] == maps[p]["cov"][:, 2])
+            idx = f.resample(w["uniform"][0])
+            outs.append((poses, lw, maps, idx))
+        assert st["max_map"] <= 2 * G
+    # determinism: two runs are bit-identical
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][3], outs[1][3])
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(x, y)
+    poses, lw, maps, idx = outs[0]
+    assert abs(np.exp(lw.astype(np.float64)).sum() - 1) < 1e-4
+    assert np.all(np.diff(idx) >= 0) and idx.min() >= 0 and idx.max() < N
+    assert np.array_equal(idx, O.resample(lw, w["uniform"][0]))
+    # sampled particles against the oracle
+    ref_poses = O.predict_ackerman(w["poses"], 0.05, 2.0, w["noise"][0], ocfg)
+    n_ok = 0
+    for p in np.linspace(0, N - 1, sample).astype(int):
+        ref = oracle_full_update(ref_poses[p], w["maps"][p], w["z"][0], ocfg)
+        if ref["prune_margin"] > PRUNE_MARGIN and ref["margin"][0] > MERGE_MARGIN:
+            n_ok += 1
+            assert_maps_close(maps[p], ref["map"], what="cfg %d particle %d" % (cfg_id, p))
+    assert n_ok >= 1
