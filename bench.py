@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — filter-update steps/sec of the GM-PHD-SLAM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config 2|3]
+
+One "step" = one full filter step on one batch of synthetic input, inputs resident in HBM:
+predict -> update (in-range split, births, EKF, PHD weights) -> prune -> merge -> weight
+normalise -> nEff -> resample (forced every step).  Steady-state protocol: the
+filter is frozen, so every timed iteration restarts from the same device-resident snapshot and
+does identical work.
+
+N = 1: BASELINE.json configs[1] (256 particles x 64 Gaussians x 32 measurements).
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank holds a
+256-particle shard of one 256*N-particle filter; per step one RCCL all-gather of the
+un-normalised log-weights, the identical global normalise/resample on every rank and the
+migration of particles whose parent lives on another rank.  `value` counts shard-steps: N ranks x
+K steps / time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fused update+prune+merge
+kernel, algorithmic bytes of SURVEY.md §8d per launch / its average duration from HIP events on
+the filter's stream) and `cpu_baseline` (the CPU oracle timed on the host cores on the same
+workload, rank 0 at N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(w, cfg_id, budget_s):
+    """the CPU oracle (a port of the reference algorithm: kind "port") on the host cores"""
+    from oracle import oracle as O
+    N, G, M = w["N"], w["G"], w["M"]
+    cap = 2 * G
+    ocfg = O.default_config()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # bound the sample: the full particle set at config 2, a slice of it at the big configs
+    n = N if N <= 512 else 256
+    maps = np.zeros((n, cap), O.GAUSSIAN)
+    maps[:, :G] = w["maps"][:n]
+    lw = O.normalize_weights(w["logw"][:n])
+
+    def one():
+        return O.step(w["poses"][:n], lw, maps, w["sizes"][:n], cap, 0.05, 2.0, w["noise"][0][:n], w["z"][0], ocfg,
+                      w["uniform"][0], True, n_threads=cores)
+    one()
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        one()
+        k += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or (k >= 3 and el > 0.5 * budget_s):
+            break
+    steps_per_s = k / el * (n / N)  # a slice of n particles is n/N of a step
+    return {"value": steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the oracle (oracle/scphd_cpu.c, OpenMP over particles, %d threads) on %d of the %d "
+                      "particles of config %d (%dx%dx%d), %.1f s" % (k, cores, n, N, cfg_id, N, G, M, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (2 or 3)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    D = importlib.import_module("cuda-phdslam_amd.dist")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    c = S.CONFIGS[args.config]
+    N, G, M = c["N"], c["G"], c["M"]
+    # every rank's shard: the same distribution, a different seed
+    w = S.make_workload(N, G, M, seed=0x5EED0000 + args.config + 1000 * rank, clustered=c["clustered"])
+    cfg = P.default_config(n_particles=N * world)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = P.PhdFilter(cfg, n_particles=N, map_capacity=2 * G, max_measurements=M, device=local_rank, stream=stream,
+                    global_particles=N * world, global_offset=N * rank)
+    lw = w["logw"] - np.float32(np.log(world)) if world > 1 else w["logw"]  # the global set sums to one
+    f.set_particles(w["poses"], lw.astype(np.float32))
+    f.set_maps(w["maps"], w["sizes"])
+    d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    d_noise = torch.from_numpy(w["noise"][0].copy()).to(dev)
+    control = (2.0, 0.05)
+    u = float(w["uniform"][0])
+    torch.cuda.synchronize()
+
+    f.set_frozen(True)  # steady state: no step commits, every iteration restarts from the same snapshot
+    if world == 1:
+        def step():
+            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=True)
+    else:
+        shard = D.GpuShard(f, N * world)
+        sf = D.ShardedFilter(shard, N * world, rank, world)
+
+        def step():
+            f.predict_dev(control, d_noise.data_ptr())
+            shard.update_local_dev(d_z.data_ptr(), M)
+            allw = sf.gather_logweights()
+            sf.normalize(allw)
+            sf.resample(u)
+
+    def sync():
+        f.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = f.status()
+
+    # kernel durations from HIP events on the filter's stream (separate pass: events perturb the timed loop)
+    k_ev = min(args.steps, 100)
+    f.timing_reset()
+    f.timing(True)
+    for _ in range(k_ev):
+        step()
+    sync()
+    ms, cnt = f.timing_read()
+    f.timing(False)
+    avg_ms = ms / np.maximum(cnt, 1)
+
+    if rank == 0:
+        b_step = S.algorithmic_bytes(N, G, M)               # per launch of the update+merge kernel (one shard)
+        b_min = N * (28 * G + 28 * G + 32)                   # compulsory traffic
+        ker_s = avg_ms[P._lib.K_UPDATE_MERGE] * 1e-3
+        achieved = b_step / ker_s / 1e9 if ker_s > 0 else 0.0
+        out = {
+            "metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas",
+            "value": world * args.steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]: %d particles x %d Gaussians/particle x %d meas/step per GPU, "
+                                   "Ackerman motion, forced resample every step, frozen snapshot" % (args.config - 1, N, G, M),
+                       "particles_total": N * world, "gaussians_per_particle": G, "measurements_per_step": M,
+                       "value_counts": "shard-steps (ranks x steps) per second",
+                       "max_survivors": st["max_survivors"], "max_map": st["max_map"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * avg_ms[P._lib.K_UPDATE_MERGE],
+                         "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
+                         "other_kernels_avg_us": {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT],
+                                                  "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(w, args.config, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    f.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,7 @@ SYMBOLS = {
     "phd_timing_read": (_i, [_vp, _vp, _vp]),
     "phd_timing_reset": (_i, [_vp]),
     "phd_debug_enable": (_i, [_vp, _i]),
+    "phd_debug_get_stamps": (_i, [_vp, _vp]),
     "phd_debug_get_survivors": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "phd_debug_get_weight_increments": (_i, [_vp, _vp]),
     "phd_device_status": (_i, [_vp, _vp, _vp, _vp]),
@@ -139,6 +140,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libphdslam.so is not built (%s): the HIP extension is required, there is no "
                                "fallback.  Run __graft_entry__.build()." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME
+        # libamdhip64.so.7).  Loaded first, it satisfies this library's NEEDED entry and both share
+        # one runtime; loaded second, it would come up as a second runtime that sees no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -105,6 +105,8 @@ struct phd_filter {
     int* dbg_u = nullptr;
     int* dbg_n = nullptr;
     int* dbg_nin = nullptr;
+    unsigned long long* stamps = nullptr;
+    bool want_stamps = false;
     int last_M = 0;
 
     bool frozen = false;
@@ -183,7 +185,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     if (f->n <= 0) { delete f; return fail(PHD_ERR_INVALID_ARG, "phd_create: n_particles <= 0"); }
     if (f->cap > 65535) { delete f; return fail(PHD_ERR_INVALID_ARG, "phd_create: map_capacity > 65535"); }
     int S = o.survivor_capacity > 0 ? o.survivor_capacity : (f->cap + 8 * f->MM);
-    S = next_pow2(std::max(S, 64));
+    S = next_pow2(std::max(S, 256)); // the register sorts own 256*E slots
     if (S > 2048) S = 2048; // register-staged permutation in merge_in_lds handles <= 2048
     f->S_cap = S;
     f->lds_bytes = update_lds_bytes(f->S_cap, f->cap, f->MM);
@@ -215,7 +217,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
     A(dalloc(&f->status, 1)); A(dalloc(&f->max_surv, 1)); A(dalloc(&f->max_map, 1));
     A(dalloc(&f->d_tmp_int, f->n));
-    A(dalloc(&f->d_offsets, f->n + 1)); A(dalloc(&f->d_sizes, f->n));
+    A(dalloc(&f->d_offsets, f->n + 1)); A(dalloc(&f->d_sizes, std::max(f->n, f->n_global)));
     if (e != hipSuccess) {
         phd_destroy(f);
         return fail(PHD_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(e));
@@ -255,7 +257,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
     hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
-    hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin);
+    hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     delete f;
     return PHD_OK;
@@ -571,6 +573,13 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M)
         if (rc) return rc;
         a.dbg_surv = f->dbg_surv; a.dbg_u = f->dbg_u; a.dbg_n = f->dbg_n; a.dbg_nin = f->dbg_nin;
     }
+    if (f->want_stamps) {
+        if (!f->stamps) {
+            HIPCHK(dalloc(&f->stamps, (size_t)f->n * 16));
+            HIPCHK(hipMemsetAsync(f->stamps, 0, (size_t)f->n * 16 * 8, f->stream));
+        }
+        a.stamps = f->stamps;
+    }
     a.status = f->status;
     a.max_surv = f->max_surv;
     a.max_map = f->max_map;
@@ -775,7 +784,8 @@ extern "C" int phd_global_normalize(phd_filter* f, const float* d_all_logw, int 
     t_begin(f, PHD_K_WEIGHTS);
     HIPCHK(launch_weights(w, f->stream));
     t_end(f);
-    HIPCHK(hipMemcpyAsync(f->logw, f->logw_scratch + f->global_offset, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+    if (!f->frozen)
+        HIPCHK(hipMemcpyAsync(f->logw, f->logw_scratch + f->global_offset, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
     if (neff_out) {
         HIPCHK(hipMemcpyAsync(neff_out, f->neff, sizeof(float), hipMemcpyDeviceToHost, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
@@ -824,7 +834,8 @@ extern "C" int phd_export_particles_dev(phd_filter* f, const int32_t* particles,
 {
     CHECK_F(f);
     if (n <= 0) return PHD_OK;
-    if (n > f->n) return fail(PHD_ERR_INVALID_ARG, "phd_export_particles_dev: n > n_particles");
+    // one particle may be the parent of slots on every other rank: up to n_global exports
+    if (n > std::max(f->n, f->n_global)) return fail(PHD_ERR_INVALID_ARG, "phd_export_particles_dev: n > n_global");
     HIPCHK(hipMemcpyAsync(f->d_sizes, particles, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
     HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->pose[f->pose_cur], f->d_sizes,
                          d_buffer, f->cap, phd_particle_pack_bytes(f), n, f->stream));
@@ -857,6 +868,10 @@ extern "C" int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int
 extern "C" int phd_finish_resample(phd_filter* f)
 {
     CHECK_F(f);
+    if (f->frozen) { // bench protocol: the exchange ran, the snapshot stays
+        HIPCHK(hipStreamSynchronize(f->stream));
+        return PHD_OK;
+    }
     f->cur ^= 1;
     f->pose_cur = (f->pose_cur + 1) % 3;
     HIPCHK(launch_iota(f->parent[f->pcur], f->n, f->stream));
@@ -873,8 +888,18 @@ extern "C" int phd_finish_resample(phd_filter* f)
 extern "C" int phd_debug_enable(phd_filter* f, int enable)
 {
     CHECK_F(f);
-    f->debug = enable != 0;
+    f->debug = (enable & 1) != 0;
+    f->want_stamps = (enable & 2) != 0; // diagnostic instantiation with phase stamps
     if (f->debug) return ensure_debug(f);
+    return PHD_OK;
+}
+
+extern "C" int phd_debug_get_stamps(phd_filter* f, uint64_t* out)
+{
+    CHECK_F(f);
+    if (!f->stamps || !out) return fail(PHD_ERR_INVALID_ARG, "phd_debug_get_stamps: enable stamps with phd_debug_enable(f, 2) and run an update first");
+    HIPCHK(hipMemcpyAsync(out, f->stamps, (size_t)f->n * 16 * 8, hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
     return PHD_OK;
 }
 

@@ -49,6 +49,7 @@ struct UpdateArgs {
     int* dbg_u;                 // [n][S_cap]
     int* dbg_n;                 // [n]
     int* dbg_nin;               // [n]
+    unsigned long long* stamps; // [n][16] phase stamps (diagnostic instantiation) or NULL
     unsigned* status;
     int* max_surv;
     int* max_map;

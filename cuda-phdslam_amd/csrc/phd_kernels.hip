@@ -42,6 +42,8 @@ namespace phd {
 #define PHD_T 256
 #define PHD_NW 4
 #define NEAR_U_BASE 0x40000000
+// phase stamps of the diagnostic instantiation (100 MHz s_memrealtime), thread 0 of each workgroup
+#define STAMP(k) do { if (STAMPS && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 typedef unsigned int u32;
 typedef unsigned long long u64;
@@ -222,7 +224,7 @@ typedef LDS_T(unsigned char)* lds_u8;
 struct LdsOffsets {
     u32 w, mx, my, xx, xy, yy, tr, u;
     u32 alias;      // start of the aliased region
-    u32 out_idx, z_r, z_b, logZ, zpart, zok, part, red, ctr;
+    u32 out_idx, z_r, z_b, logZ, zpart, zok, part, win, red, ctr;
     u32 total;
 };
 
@@ -248,7 +250,8 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.logZ = p; p += align16u(4u * (u32)MM);
     o.zpart = p; p += align16u(16u * (u32)MM);
     o.zok = p; p += align16u(4u * (u32)MM);
-    o.part = p; p += 4u * 2u * 4u * 64u;
+    o.part = p; p += 4u * 4u * 64u;
+    o.win = p; p += 4u * 7u * 64u;
     o.red = p; p += align16u(4u * (PHD_NW + 4));
     o.ctr = p; p += 4u * 16u;
     o.total = p;
@@ -257,7 +260,8 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
 
 struct Lds {
     // survivors (SoA), S entries each
-    lds_f32 w, mx, my, xx, xy, yy, tr;
+    lds_f32 w, mx, my, xx, xy, yy;
+    lds_f32 tr; // trace of the covariance (+inf if not SPD): cheap far-pair filter of the merge
     lds_i32 u; // slab index (sort tie-break); after the sort: cluster assignment
     // aliased region
     lds_f32 f_r, f_b, f_s00, f_s12, f_s11, f_lwb; // per in-range feature, C entries
@@ -269,7 +273,8 @@ struct Lds {
     lds_u16 out_idx;                  // C
     lds_f32 z_r, z_b, logZ, zpart;    // MM, MM, MM, 4*MM
     lds_u32 zok;                      // MM
-    lds_u32 part;                     // 2*4*64 row parts of the window closeness matrix
+    lds_u32 part;                     // 4*64 row parts of the window closeness matrix
+    lds_f32 win;                      // 7*64: the window's candidates (pos, mx, my, tr, xx, xy, yy)
     lds_f32 red;                      // PHD_NW + 4
     lds_i32 ctr;                      // 16 counters
 };
@@ -300,6 +305,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.z_r = (lds_f32)(base + o.z_r); L.z_b = (lds_f32)(base + o.z_b); L.logZ = (lds_f32)(base + o.logZ);
     L.zpart = (lds_f32)(base + o.zpart); L.zok = (lds_u32)(base + o.zok);
     L.part = (lds_u32)(base + o.part);
+    L.win = (lds_f32)(base + o.win);
     L.red = (lds_f32)(base + o.red);
     L.ctr = (lds_i32)(base + o.ctr);
     return L;
@@ -337,79 +343,268 @@ __device__ __forceinline__ void store_survivor(const Lds& L, int slot, int S, fl
 }
 
 // ------------------------------------------------------------------------------------------
-// bitonic sorts in LDS (n a power of two)
+// bitonic sorts held in registers: thread t owns elements i = t*E + e (e < E), n = sorted prefix
+// (power of two, <= 256*E).  Strides below E are compare-exchanges between a thread's own
+// registers, strides below 64*E are wave shuffles (no LDS traffic, no barrier); only the few
+// strides that cross waves go through LDS.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sort_desc_64(lds_u32 khi, lds_u32 klo, lds_u32 pay, int n, int tid)
+template <int E>
+__device__ __forceinline__ void reg_sort_desc64(u32 (&khi)[E], u32 (&klo)[E], u32 (&pay)[E], int n, int tid,
+                                                lds_u32 xhi, lds_u32 xlo, lds_u32 xpay)
 {
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n; i += PHD_T) {
-                int l = i ^ j;
-                if (l > i) {
-                    u64 a = ((u64)khi[i] << 32) | klo[i];
-                    u64 b = ((u64)khi[l] << 32) | klo[l];
-                    bool desc = ((i & k) == 0);
-                    bool sw = desc ? (a < b) : (a > b);
-                    if (sw) {
-                        u32 pa = pay[i], pb = pay[l];
-                        khi[i] = (u32)(b >> 32); klo[i] = (u32)b; pay[i] = pb;
-                        khi[l] = (u32)(a >> 32); klo[l] = (u32)a; pay[l] = pa;
+            if (j >= E * 64) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    if (i < n) { xhi[i] = khi[e]; xlo[i] = klo[e]; xpay[i] = pay[e]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    if (i < n) {
+                        const int l = i ^ j;
+                        const u64 mine = ((u64)khi[e] << 32) | klo[e];
+                        const u64 oth = ((u64)xhi[l] << 32) | xlo[l];
+                        const bool want_max = (((i & k) == 0) == ((i & j) == 0));
+                        if (want_max ? (oth > mine) : (oth < mine)) { khi[e] = (u32)(oth >> 32); klo[e] = (u32)oth; pay[e] = xpay[l]; }
+                    }
+                }
+                __syncthreads();
+            } else if (j >= E) {
+                const int lm = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const u32 ohi = __shfl_xor(khi[e], lm), olo = __shfl_xor(klo[e], lm), op = __shfl_xor(pay[e], lm);
+                    const u64 mine = ((u64)khi[e] << 32) | klo[e];
+                    const u64 oth = ((u64)ohi << 32) | olo;
+                    const bool want_max = (((i & k) == 0) == ((i & j) == 0));
+                    if (want_max ? (oth > mine) : (oth < mine)) { khi[e] = ohi; klo[e] = olo; pay[e] = op; }
+                }
+            } else {
+#pragma unroll
+                for (int jj = E / 2; jj > 0; jj >>= 1) {
+                    if (j == jj) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            if ((e & jj) == 0) {
+                                const int i = tid * E + e;
+                                const u64 a = ((u64)khi[e] << 32) | klo[e];
+                                const u64 b = ((u64)khi[e | jj] << 32) | klo[e | jj];
+                                const bool desc = ((i & k) == 0);
+                                if (desc ? (a < b) : (a > b)) {
+                                    const u32 th = khi[e], tl = klo[e], tp = pay[e];
+                                    khi[e] = khi[e | jj]; klo[e] = klo[e | jj]; pay[e] = pay[e | jj];
+                                    khi[e | jj] = th; klo[e | jj] = tl; pay[e | jj] = tp;
+                                }
+                            }
+                        }
                     }
                 }
             }
-            __syncthreads();
         }
     }
 }
 
-__device__ __forceinline__ void sort_asc_32(lds_u32 key, int n, int tid)
+template <int E>
+__device__ __forceinline__ void reg_sort_asc32(u32 (&key)[E], int n, int tid, lds_u32 x)
 {
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n; i += PHD_T) {
-                int l = i ^ j;
-                if (l > i) {
-                    u32 a = key[i], b = key[l];
-                    bool asc = ((i & k) == 0);
-                    bool sw = asc ? (a > b) : (a < b);
-                    if (sw) { key[i] = b; key[l] = a; }
+            if (j >= E * 64) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    if (i < n) x[i] = key[e];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    if (i < n) {
+                        const u32 oth = x[i ^ j];
+                        const bool want_min = (((i & k) == 0) == ((i & j) == 0));
+                        if (want_min ? (oth < key[e]) : (oth > key[e])) key[e] = oth;
+                    }
+                }
+                __syncthreads();
+            } else if (j >= E) {
+                const int lm = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const u32 oth = __shfl_xor(key[e], lm);
+                    const bool want_min = (((i & k) == 0) == ((i & j) == 0));
+                    if (want_min ? (oth < key[e]) : (oth > key[e])) key[e] = oth;
+                }
+            } else {
+#pragma unroll
+                for (int jj = E / 2; jj > 0; jj >>= 1) {
+                    if (j == jj) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            if ((e & jj) == 0) {
+                                const int i = tid * E + e;
+                                const u32 a = key[e], b = key[e | jj];
+                                const bool asc = ((i & k) == 0);
+                                if (asc ? (a > b) : (a < b)) { key[e] = b; key[e | jj] = a; }
+                            }
+                        }
+                    }
                 }
             }
-            __syncthreads();
         }
     }
 }
 
-// closeness of survivor i to seed s (sorted arrays).  Conservative pre-test then exact test.
-template <bool HELLINGER>
-__device__ __forceinline__ bool is_close(const Lds& L, int s, float smx, float smy, float sxx, float sxy, float syy,
-                                         float str, float emx, float emy, float exx, float exy, float eyy, float etr,
-                                         float T, float Tpre)
+// sort 1 of the merge: survivors by (weight desc, slab index asc), then permute the SoA arrays into
+// that order (in place, staged through registers) and clear the assignment array.
+template <int E>
+__device__ __forceinline__ void sort_survivors(const Lds& L, int S, int n_pad, int tid)
 {
-    (void)s;
-    if (!HELLINGER) {
-        float dx = smx - emx, dy = smy - emy;
-        float d2 = dx * dx + dy * dy;
-        // d >= 2|dm|^2 / (tr Ps + tr Pe) for SPD covariances: far if 2 d2 >= 1.01 T (trs + tre)
-        if (2.f * d2 >= Tpre * (str + etr)) return false;
-        return mahal_dist(smx, smy, sxx, sxy, syy, emx, emy, exx, exy, eyy) < T;
-    } else {
-        return hellinger_dist(smx, smy, sxx, sxy, syy, emx, emy, exx, exy, eyy) < T;
+    u32 khi[E], klo[E], pay[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        if (i < S) { khi[e] = orderable(L.w[i]); klo[e] = 0xFFFFFFFFu - (u32)L.u[i]; pay[e] = (u32)i; }
+        else { khi[e] = 0; klo[e] = 0; pay[e] = 0; }
     }
+    reg_sort_desc64<E>(khi, klo, pay, n_pad, tid, L.khi, L.klo, L.pay);
+    float rw[E], rmx[E], rmy[E], rxx[E], rxy[E], ryy[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        if (i < S) {
+            const int s = (int)pay[e];
+            rw[e] = L.w[s]; rmx[e] = L.mx[s]; rmy[e] = L.my[s];
+            rxx[e] = L.xx[s]; rxy[e] = L.xy[s]; ryy[e] = L.yy[s];
+        }
+    }
+    __syncthreads(); // every read of the old order precedes every write of the new one
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        if (i < S) {
+            L.w[i] = rw[e]; L.mx[i] = rmx[e]; L.my[i] = rmy[e];
+            L.xx[i] = rxx[e]; L.xy[i] = rxy[e]; L.yy[i] = ryy[e];
+            const bool spd = (rxx[e] > 0.f) && (ryy[e] > 0.f) && (rxx[e] * ryy[e] - rxy[e] * rxy[e] > 0.f);
+            L.tr[i] = spd ? (rxx[e] + ryy[e]) : INFINITY;
+            L.u[i] = -1; // unassigned
+        }
+    }
+    __syncthreads();
+}
+
+// small mixtures (S <= 256): rank by counting instead of a sorting network — every thread reads all
+// keys (LDS broadcast reads, independent, no barriers), rank = number of keys that sort before its own
+__device__ __forceinline__ void rank_sort_survivors(const Lds& L, int S, int tid)
+{
+    u32 mh = 0, ml = 0;
+    if (tid < S) { mh = orderable(L.w[tid]); ml = 0xFFFFFFFFu - (u32)L.u[tid]; L.khi[tid] = mh; L.klo[tid] = ml; }
+    float rw = 0, rmx = 0, rmy = 0, rxx = 0, rxy = 0, ryy = 0;
+    if (tid < S) { rw = L.w[tid]; rmx = L.mx[tid]; rmy = L.my[tid]; rxx = L.xx[tid]; rxy = L.xy[tid]; ryy = L.yy[tid]; }
+    __syncthreads();
+    if (tid < S) {
+        const u64 mine = ((u64)mh << 32) | ml;
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < S; ++j) {
+            const u64 o = ((u64)L.khi[j] << 32) | L.klo[j];
+            rank += (o > mine) ? 1 : 0; // keys are unique: (weight, slab index)
+        }
+        L.w[rank] = rw; L.mx[rank] = rmx; L.my[rank] = rmy;
+        L.xx[rank] = rxx; L.xy[rank] = rxy; L.yy[rank] = ryy;
+        const bool spd = (rxx > 0.f) && (ryy > 0.f) && (rxx * ryy - rxy * rxy > 0.f);
+        L.tr[rank] = spd ? (rxx + ryy) : INFINITY;
+        L.u[rank] = -1;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void rank_sort_assignments(const Lds& L, int S, int tid)
+{
+    u32 mine = 0;
+    if (tid < S) { mine = ((u32)L.u[tid] << 16) | (u32)tid; L.pay[tid] = mine; }
+    __syncthreads();
+    if (tid < S) {
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < S; ++j) rank += (L.pay[j] < mine) ? 1 : 0;
+        L.key2[rank] = mine;
+    }
+    __syncthreads();
+}
+
+// sort 2 of the merge: (seed position, own position) ascending -> clusters become contiguous,
+// members in (weight desc) order, seed first
+template <int E>
+__device__ __forceinline__ void sort_assignments(const Lds& L, int S, int n_pad, int tid)
+{
+    u32 key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        key[e] = (i < S) ? (((u32)L.u[i] << 16) | (u32)i) : 0xFFFFFFFFu;
+    }
+    reg_sort_asc32<E>(key, n_pad, tid, L.key2);
+    __syncthreads(); // L.key2 aliases nothing that is still read, but waves may lag in the last exchange
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        if (i < n_pad) L.key2[i] = key[e];
+    }
+    __syncthreads();
+}
+
+// Is survivor e within the merge distance of seed s?  (d(s,e) < T, src/phdfilter.cu:2802-2806)
+//
+// Mahalanobis: the decision is taken WITHOUT the four divisions of the reference formula whenever it
+// is not marginal.  With s0,s1,s3,det,d0,d1 computed exactly as mahal_dist() computes them (FMA
+// contraction off -> bitwise the same values), the reference's d differs from q/det,
+// q = d0^2 s3 - 2 d0 d1 s1 + d1^2 s0, by at most ~6 ulp of A/det, A = sum of |terms|; q itself is
+// computed here with the same bound.  So |q - T det| > 4e-6 (A + T det)  (67 ulp) decides the
+// comparison d < T exactly as the reference formula would; inside that band — or if det <= 0 or
+// anything is non-finite — the reference formula itself is evaluated.
+template <bool HELLINGER>
+__device__ __forceinline__ bool is_close(float smx, float smy, float sxx, float sxy, float syy,
+                                         float emx, float emy, float exx, float exy, float eyy, float T)
+{
+#pragma clang fp contract(off)
+    if (HELLINGER) return hellinger_dist(smx, smy, sxx, sxy, syy, emx, emy, exx, exy, eyy) < T;
+    const float s0 = (sxx + exx) * 0.5f;
+    const float s1 = (sxy + exy) * 0.5f;
+    const float s3 = (syy + eyy) * 0.5f;
+    const float det = s0 * s3 - s1 * s1;
+    const float d0 = smx - emx;
+    const float d1 = smy - emy;
+    const float t1 = d0 * d0 * s3, t2 = d0 * d1 * s1, t3 = d1 * d1 * s0;
+    const float q = t1 - 2.f * t2 + t3;
+    const float A = fabsf(t1) + 2.f * fabsf(t2) + fabsf(t3);
+    const float Td = T * det;
+    const float tol = 4e-6f * (A + fabsf(Td));
+    if (det > 0.f && T > 0.f) {
+        const float diff = q - Td;
+        if (diff > tol) return false;
+        if (diff < -tol) return true;
+    }
+    return mahal_dist(smx, smy, sxx, sxy, syy, emx, emy, exx, exy, eyy) < T;
 }
 
 // ------------------------------------------------------------------------------------------
 // the greedy merge on the survivors held in LDS; writes the merged map to the output slab.
 // Returns (in ctr[CTR_KOUT]) the number of merged Gaussians.
 // ------------------------------------------------------------------------------------------
-template <bool HELLINGER>
+template <bool HELLINGER, bool STAMPS>
 __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv, const DevConfig& cfg, float* __restrict__ out_slab,
-                             int cap, int tid)
+                             int cap, int tid, u64* st)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const float T = cfg.minSeparation;
-    // the trace bound needs T > 0; Tpre = +inf-safe guard band
-    const float Tpre = (T > 0.f) ? T * 1.01f : -1.f; // T <= 0: "2 d2 >= -(..)" is always true -> far, like the exact test
+    // guard band of the trace filter; T <= 0: "2 d2 >= -(..)" always holds -> far, like the exact test
+    const float Tpre = (T > 0.f) ? T * 1.01f : -1.f;
     const int S = n_surv;
     if (tid == 0) { L.ctr[CTR_KOUT] = 0; L.ctr[CTR_NHEAD] = 0; }
     if (S == 0) { __syncthreads(); return; }
@@ -417,125 +612,187 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
     int n_pad = 2;
     while (n_pad < S) n_pad <<= 1;
-    for (int i = tid; i < n_pad; i += PHD_T) {
-        if (i < S) {
-            L.khi[i] = orderable(L.w[i]);
-            L.klo[i] = 0xFFFFFFFFu - (u32)L.u[i];
-            L.pay[i] = (u32)i;
-        } else {
-            L.khi[i] = 0; L.klo[i] = 0; L.pay[i] = 0xFFFFFFFFu;
-        }
-    }
-    __syncthreads();
-    sort_desc_64(L.khi, L.klo, L.pay, n_pad, tid);
-    // permute the survivor arrays into sorted order through registers (8 elements per thread per trip)
-    for (int i0 = 0; i0 < S; i0 += PHD_T * 8) {
-        float rw[8], rmx[8], rmy[8], rxx[8], rxy[8], ryy[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int i = i0 + e * PHD_T + tid;
-            if (i < S) {
-                int s = (int)L.pay[i];
-                rw[e] = L.w[s]; rmx[e] = L.mx[s]; rmy[e] = L.my[s];
-                rxx[e] = L.xx[s]; rxy[e] = L.xy[s]; ryy[e] = L.yy[s];
-            }
-        }
-        // a trip only touches positions [i0, i0+2048) as destination but reads arbitrary sources:
-        // all reads of ALL trips must precede any write, so S_cap <= 2048 is required (host checks).
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int i = i0 + e * PHD_T + tid;
-            if (i < S) {
-                L.w[i] = rw[e]; L.mx[i] = rmx[e]; L.my[i] = rmy[e];
-                L.xx[i] = rxx[e]; L.xy[i] = rxy[e]; L.yy[i] = ryy[e];
-                bool spd = (rxx[e] > 0.f) && (ryy[e] > 0.f) && (rxx[e] * ryy[e] - rxy[e] * rxy[e] > 0.f);
-                L.tr[i] = spd ? (rxx[e] + ryy[e]) : INFINITY;
-                L.u[i] = -1; // unassigned
-            }
-        }
-    }
-    __syncthreads();
+    if (n_pad <= 256) rank_sort_survivors(L, S, tid);
+    else if (n_pad <= 512) sort_survivors<2>(L, S, n_pad, tid);
+    else if (n_pad <= 1024) sort_survivors<4>(L, S, n_pad, tid);
+    else sort_survivors<8>(L, S, n_pad, tid);
+    STAMP(6);
 
-    // ---- rounds: 64 candidates at a time --------------------------------------------------------
+    // ---- rounds: 64 live candidates at a time ---------------------------------------------------
+    // `cur` lists the still-unmerged survivors in (weight desc) order.  Per round the first 64 of
+    // them form the window: their pairwise closeness decides which are seeds (a candidate is a seed
+    // iff no earlier seed is close to it), every later survivor is assigned to the first seed it is
+    // close to, and the list is compacted.  Exactly the reference's greedy loop, 64 seeds at a time.
     lds_i32 assign = L.u;
-    int round = 0;
-    for (int base = 0; base < S; base += 64, ++round) {
-        lds_u32 part = L.part + (round & 1) * (4 * 64);
-        // (1) closeness matrix rows: lane = candidate k, wave = column block [16*wave, 16*wave+16)
+    lds_u16 ul_a = (lds_u16)L.pay, ul_b = ul_a + S_cap;  // two u16 lists in the (free) sort-payload region
+    LDS_T(u64)* cmask = (LDS_T(u64)*)L.khi;              // candidate-seed mask per listed survivor (khi+klo)
+    lds_u16 cm16 = (lds_u16)L.khi;
+    lds_i32 wpos = (lds_i32)L.win;
+    lds_f32 wmx = L.win + 64, wmy = L.win + 128, wtr = L.win + 192, wxx = L.win + 256, wxy = L.win + 320,
+            wyy = L.win + 384;
+    for (int i = tid; i < S; i += PHD_T) ul_a[i] = (u16)i;
+    int n_u = S;
+    lds_u16 cur = ul_a, nxt = ul_b;
+    __syncthreads();
+    while (n_u > 0) {
+        u64 tq0 = 0, tq1 = 0, tq2 = 0;
+        if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
+        const int nwin = n_u < 64 ? n_u : 64;
+        const int nrest = n_u - nwin;
+        // (0) window buffer: broadcast-friendly copy of the candidates
+        if (tid < 64) {
+            const int i = cur[tid < nwin ? tid : nwin - 1];
+            wpos[tid] = i;
+            wmx[tid] = L.mx[i]; wmy[tid] = L.my[i]; wtr[tid] = (tid < nwin) ? L.tr[i] : -INFINITY;
+            wxx[tid] = L.xx[i]; wxy[tid] = L.xy[i]; wyy[tid] = L.yy[i];
+        }
+        __syncthreads();
+        // (1) closeness matrix rows: lane = candidate k, wave = column block [16*wave, 16*wave+16).
+        //     A cheap conservative filter (d >= 2|dm|^2/(tr Pa + tr Pb) for SPD covariances, 1 % guard
+        //     band) marks candidate columns; the exact test runs on the marked bits only.
         {
             const int k = lane;
-            const int ik = base + k;
-            u32 bits = 0;
-            const bool kvalid = (ik < S) && (assign[ik] < 0);
-            float kmx = 0, kmy = 0, kxx = 0, kxy = 0, kyy = 0, ktr = 0;
-            if (kvalid) { kmx = L.mx[ik]; kmy = L.my[ik]; kxx = L.xx[ik]; kxy = L.xy[ik]; kyy = L.yy[ik]; ktr = L.tr[ik]; }
+            const bool kvalid = k < nwin;
+            const float kmx = wmx[k], kmy = wmy[k], ktr = wtr[k];
+            u32 cand = 0;
+#pragma unroll 4
             for (int c = 0; c < 16; ++c) {
                 const int l = wave * 16 + c;
-                const int il = base + l;
-                if (il >= S) break;              // uniform
-                if (assign[il] >= 0) continue;   // uniform (broadcast read): merged columns cannot be seeds
-                const float lmx = L.mx[il], lmy = L.my[il], lxx = L.xx[il], lxy = L.xy[il], lyy = L.yy[il], ltr = L.tr[il];
-                if (kvalid && l < k) {
-                    if (is_close<HELLINGER>(L, il, lmx, lmy, lxx, lxy, lyy, ltr, kmx, kmy, kxx, kxy, kyy, ktr, T, Tpre))
+                const float dx = wmx[l] - kmx, dy = wmy[l] - kmy;
+                const bool near = HELLINGER || !(2.f * (dx * dx + dy * dy) >= Tpre * (wtr[l] + ktr));
+                if (kvalid && l < k && near) cand |= (1u << c);
+            }
+            u32 bits = 0;
+            if (cand) {
+                const float kxx = wxx[k], kxy = wxy[k], kyy = wyy[k];
+                while (cand) {
+                    const int c = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    const int l = wave * 16 + c;
+                    if (is_close<HELLINGER>(wmx[l], wmy[l], wxx[l], wxy[l], wyy[l], kmx, kmy, kxx, kxy, kyy, T))
                         bits |= (1u << c);
                 }
             }
-            part[wave * 64 + k] = bits;
+            L.part[wave * 64 + k] = bits;
         }
         __syncthreads();
-        // (2) seeds of this window (every wave computes the same uniform mask)
-        u64 seeds = 0;
+        if (STAMPS && tid == 0) tq1 = __builtin_amdgcn_s_memrealtime();
+        // (2) seeds: s_k = not exists l < k : close(k,l) and s_l.  The recursion is well founded, so the
+        //     parallel iteration s <- F(s) reaches its unique fixed point (position k is final after k+1
+        //     sweeps; in practice a handful).  Every wave computes the same mask.
+        u64 seeds;
         {
-            const int ik = base + lane;
-            const bool unm = (ik < S) && (assign[ik] < 0);
-            u32 lo = (part[0 * 64 + lane] & 0xFFFFu) | (part[1 * 64 + lane] << 16);
-            u32 hi = (part[2 * 64 + lane] & 0xFFFFu) | (part[3 * 64 + lane] << 16);
-            const u64 unmerged = __ballot(unm);
-#pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                u32 rlo = __builtin_amdgcn_readlane(lo, k);
-                u32 rhi = __builtin_amdgcn_readlane(hi, k);
-                u64 rk = ((u64)rhi << 32) | rlo;
-                if (((unmerged >> k) & 1ull) && !(rk & seeds)) seeds |= (1ull << k);
+            const u32 lo = (L.part[0 * 64 + lane] & 0xFFFFu) | (L.part[1 * 64 + lane] << 16);
+            const u32 hi = (L.part[2 * 64 + lane] & 0xFFFFu) | (L.part[3 * 64 + lane] << 16);
+            const u64 row = ((u64)hi << 32) | lo;
+            const u64 live = (nwin == 64) ? ~0ull : ((1ull << nwin) - 1ull);
+            seeds = live;
+            for (int it = 0; it < 65; ++it) {
+                const u64 blocked = __ballot((row & seeds) != 0ull);
+                const u64 nx = live & ~blocked;
+                if (nx == seeds) break;
+                seeds = nx;
             }
-            if (wave == 0 && unm) {
-                u64 row = ((u64)hi << 32) | lo;
-                int owner = ((seeds >> lane) & 1ull) ? lane : __builtin_ctzll(row & seeds);
-                assign[ik] = base + owner;
+            if (wave == 0 && lane < nwin) {
+                const int owner = ((seeds >> lane) & 1ull) ? lane : __builtin_ctzll(row & seeds);
+                assign[wpos[lane]] = wpos[owner];
             }
         }
-        // (3) survivors beyond the window: first seed (in order) that is close
-        if (seeds) {
-            for (int i = base + 64 + tid; i < S; i += PHD_T) {
-                if (assign[i] >= 0) continue;
-                const float emx = L.mx[i], emy = L.my[i], exx = L.xx[i], exy = L.xy[i], eyy = L.yy[i], etr = L.tr[i];
-                u64 rem = seeds;
-                int found = -1;
-                while (rem) {
-                    const int s = __builtin_ctzll(rem);
-                    rem &= rem - 1;
-                    const int is = base + s;
-                    if (is_close<HELLINGER>(L, is, L.mx[is], L.my[is], L.xx[is], L.xy[is], L.yy[is], L.tr[is],
-                                            emx, emy, exx, exy, eyy, etr, T, Tpre)) {
-                        found = is;
-                        break;
+        if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
+        // (3a) cheap filter for the survivors after the window: wave w owns the window's candidates
+        //      [16w, 16w+16) and sweeps all listed survivors, 64 (one per lane) at a time ->
+        //      16 candidate-seed bits per (survivor, wave)
+        {
+            const u32 myseeds = (u32)(seeds >> (16 * wave)) & 0xFFFFu;
+            for (int e0 = 0; e0 < nrest; e0 += 64) {
+                const int e = e0 + lane;
+                u32 m16 = 0;
+                if (myseeds) {
+                    float emx = 0, emy = 0, etr = -INFINITY; // -inf trace: the filter rejects
+                    if (e < nrest) { const int i = cur[64 + e]; emx = L.mx[i]; emy = L.my[i]; etr = L.tr[i]; }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (!((myseeds >> (4 * g)) & 0xFu)) continue; // uniform
+                        float smx[4], smy[4], str[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int l = 16 * wave + 4 * g + q;
+                            smx[q] = wmx[l]; smy[q] = wmy[l]; str[q] = wtr[l];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float dx = smx[q] - emx, dy = smy[q] - emy;
+                            const bool near = HELLINGER ? (etr > -INFINITY) : !(2.f * (dx * dx + dy * dy) >= Tpre * (str[q] + etr));
+                            if (near) m16 |= (1u << (4 * g + q));
+                        }
+                    }
+                    m16 &= myseeds;
+                }
+                if (e < nrest) cm16[e * 4 + wave] = (u16)m16;
+            }
+        }
+        __syncthreads();
+        // (3b) exact test on the candidates only, in seed order, until the first hit; then the ordered
+        //      compaction of the list (thread t owns the contiguous entries [t*per, (t+1)*per))
+        {
+            const int per = (nrest + PHD_T - 1) / PHD_T;
+            const int e_lo = tid * per, e_hi = (e_lo + per < nrest) ? e_lo + per : nrest;
+            int kept = 0;
+            for (int e = e_lo; e < e_hi; ++e) {
+                const int i = cur[64 + e];
+                u64 m = cmask[e];
+                bool merged = false;
+                if (m) {
+                    const float fmx = L.mx[i], fmy = L.my[i], fxx = L.xx[i], fxy = L.xy[i], fyy = L.yy[i];
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (is_close<HELLINGER>(wmx[l], wmy[l], wxx[l], wxy[l], wyy[l], fmx, fmy, fxx, fxy, fyy, T)) {
+                            assign[i] = wpos[l];
+                            merged = true;
+                            break;
+                        }
                     }
                 }
-                if (found >= 0) assign[i] = found;
+                if (!merged) kept++;
+                cmask[e] = merged ? 0ull : 1ull; // reuse as the keep flag of the compaction
             }
+            // exclusive scan of `kept` over the workgroup (wave shuffle scan + wave totals)
+            int incl = kept;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63) L.ctr[CTR_TMP + wave] = incl;
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < PHD_NW; ++w) {
+                const int c = L.ctr[CTR_TMP + w];
+                if (w < wave) woff += c;
+                total += c;
+            }
+            int o = woff + incl - kept;
+            for (int e = e_lo; e < e_hi; ++e)
+                if (cmask[e]) nxt[o++] = cur[64 + e];
+            n_u = total;
+            __syncthreads();
+            lds_u16 t2 = cur; cur = nxt; nxt = t2;
         }
-        // no barrier here: the next round writes the other half of `part`, and its barrier
-        // (after step 1) orders this round's assign[] writes before they are read in step 2.
-        // Step 1 of the next round reads assign[] of its own window: elements written in step 3
-        // by other waves -> needs ordering.
-        __syncthreads();
+        if (STAMPS && tid == 0) {
+            const u64 tq3 = __builtin_amdgcn_s_memrealtime();
+            st[12] += tq1 - tq0; st[13] += tq2 - tq1; st[14] += tq3 - tq2; st[15] += 1;
+        }
     }
 
+    STAMP(7);
     // ---- sort 2: group by seed, members in sorted-position order ---------------------------------
-    for (int i = tid; i < n_pad; i += PHD_T) L.key2[i] = (i < S) ? (((u32)assign[i] << 16) | (u32)i) : 0xFFFFFFFFu;
-    __syncthreads();
-    sort_asc_32(L.key2, n_pad, tid);
+    if (n_pad <= 256) rank_sort_assignments(L, S, tid);
+    else if (n_pad <= 512) sort_assignments<2>(L, S, n_pad, tid);
+    else if (n_pad <= 1024) sort_assignments<4>(L, S, n_pad, tid);
+    else sort_assignments<8>(L, S, n_pad, tid);
+    STAMP(8);
     // cluster heads -> seg[]
     {
         int running = 0;
@@ -558,6 +815,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         __syncthreads();
     }
     const int n_clusters = L.ctr[CTR_NHEAD];
+    STAMP(9);
 
     // ---- moment matching: one lane per cluster, sequential in (weight desc) order ----------------
     // (two trips over the lanes' clusters: first find where the reference's loop would stop)
@@ -608,6 +866,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         }
     }
     __syncthreads();
+    STAMP(10);
     if (tid == 0) {
         int k = L.ctr[CTR_KOUT];
         if (k > n_clusters) k = n_clusters;
@@ -619,6 +878,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 // ------------------------------------------------------------------------------------------
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
+template <bool STAMPS>
 __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -634,6 +894,9 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
     float* __restrict__ out = A.map_out + (size_t)p * 6 * cap;
     const phd_pose pose = A.pose[p];
+    u64* st = STAMPS ? (A.stamps + (size_t)p * 16) : nullptr;
+    if (STAMPS && tid == 0) { st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0; }
+    STAMP(0);
 
     if (tid < 16) L.ctr[tid] = 0;
     // measurements -> LDS (the reference keeps them in __constant__ Z[256], src/phdfilter.cu:120)
@@ -701,6 +964,7 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     __syncthreads();
     const int n_in = L.ctr[CTR_NIN];
     const int n_out0 = L.ctr[CTR_NOUT];
+    STAMP(1);
 
     // lane <-> measurement mapping
     int Mp = 1;
@@ -749,6 +1013,7 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     }
     __syncthreads();
 
+    STAMP(2);
     // ---- pass 2: final weights; prune before store --------------------------------------------------
     // non-detection terms
     for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
@@ -767,6 +1032,7 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         const int slot = alloc_slots(keep, L.ctr);
         if (keep) store_survivor(L, slot, S_cap, w, mx, my, pxx, pxy, pyy, j);
     }
+    STAMP(3);
     // detection terms
     for (int mt = 0; mt < m_tiles; ++mt) {
         const int m = mt * 64 + lm;
@@ -782,20 +1048,39 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
             const float lw = L.f_lwb[jj] - 0.5f * dist;
             const float w = zok ? __expf(lw - lz) : 0.f;                                              // :2242-2243
             const bool keep = mvalid && (j < n_in) && !(w < cfg.minFeatureWeight);                    // :2314
+            // survivors are sparse (~1 %): the hot loop only records (weight, slab index); mean and
+            // covariance are filled in by the dense finalise pass below, one lane per survivor
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
-                // rare: rebuild gain and Joseph covariance from the prior feature
-                const int i = L.f_idx[jj];
-                const float fmx = in[1 * cap + i], fmy = in[2 * cap + i];
-                const float pxx = in[3 * cap + i], pxy = in[4 * cap + i], pyy = in[5 * cap + i];
-                EkfTerms t;
-                ekf_terms(fmx, fmy, pxx, pxy, pyy, pose, cfg, t);
-                float oxx, oxy, oyy;
-                joseph_cov(t, pxx, pxy, pyy, cfg, oxx, oxy, oyy);
-                const float nmx = fmx + t.K0 * i0 + t.K2 * i1;                                       // :1903-1904
-                const float nmy = fmy + t.K1 * i0 + t.K3 * i1;
-                store_survivor(L, slot, S_cap, w, nmx, nmy, oxx, oxy, oyy, n_in + m * n_in + j);
+                if (slot < S_cap) { L.w[slot] = w; L.u[slot] = n_in + m * n_in + j; }
+                else L.ctr[CTR_OVERFLOW] = 1;
             }
+        }
+    }
+    STAMP(4);
+    __syncthreads();
+    {
+        // dense finalise of the detection terms: rebuild gain, updated mean and Joseph covariance
+        // from the prior feature (src/phdfilter.cu:1884-1906)
+        const int n_now = min(L.ctr[CTR_NSURV], S_cap);
+        const int u_det_lo = n_in, u_det_hi = n_in + M * n_in;
+        for (int s = tid; s < n_now; s += PHD_T) {
+            const int u = L.u[s];
+            if (u < u_det_lo || u >= u_det_hi) continue;
+            const int m = (u - n_in) / n_in;
+            const int j = (u - n_in) - m * n_in;
+            const int i = L.f_idx[j];
+            const float fmx = in[1 * cap + i], fmy = in[2 * cap + i];
+            const float pxx = in[3 * cap + i], pxy = in[4 * cap + i], pyy = in[5 * cap + i];
+            EkfTerms t;
+            ekf_terms(fmx, fmy, pxx, pxy, pyy, pose, cfg, t);
+            float oxx, oxy, oyy;
+            joseph_cov(t, pxx, pxy, pyy, cfg, oxx, oxy, oyy);
+            const float i0 = L.z_r[m] - t.r;
+            const float i1 = wrap_angle(L.z_b[m] - t.b);
+            L.mx[s] = fmx + t.K0 * i0 + t.K2 * i1;                                                   // :1903-1904
+            L.my[s] = fmy + t.K1 * i0 + t.K3 * i1;
+            L.xx[s] = oxx; L.xy[s] = oxy; L.yy[s] = oyy;
         }
     }
     // births (host loop src/phdfilter.cu:3470-3506; weight :2239-2243)
@@ -826,6 +1111,7 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         if (keep) store_survivor(L, slot, S_cap, w, bmx, bmy, bxx, bxy, byy, n_in + M * n_in + m);
     }
     __syncthreads();
+    STAMP(5);
     int n_surv = L.ctr[CTR_NSURV];
     unsigned status = 0;
     if (n_surv > S_cap) { n_surv = S_cap; status |= PHD_STATUS_SURVIVOR_OVERFLOW; }
@@ -845,8 +1131,8 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     __syncthreads();
 
     // ---- merge ----------------------------------------------------------------------------------------
-    if (cfg.distanceMetric == 0) merge_in_lds<false>(L, S_cap, n_surv, cfg, out, cap, tid);
-    else merge_in_lds<true>(L, S_cap, n_surv, cfg, out, cap, tid);
+    if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st);
+    else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st);
     int k_out = L.ctr[CTR_KOUT];
     if (k_out > cap) { k_out = cap; status |= PHD_STATUS_MAP_OVERFLOW; }
     // append the untouched out-of-range features (src/phdfilter.cu:3311-3318)
@@ -864,6 +1150,7 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         atomicMax(A.max_surv, L.ctr[CTR_NSURV]);
         atomicMax(A.max_map, k_out + n_out0);
     }
+    STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1272,12 +1559,16 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)phd_update_merge_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)phd_update_merge_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)phd_update_merge_kernel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(phd_update_merge_kernel, dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    if (a.stamps) hipLaunchKernelGGL(phd_update_merge_kernel<true>, dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else hipLaunchKernelGGL(phd_update_merge_kernel<false>, dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     return hipGetLastError();
 }
 

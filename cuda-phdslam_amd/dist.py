@@ -1,0 +1,171 @@
+"""Multi-GPU host glue: particles shard contiguously over ranks, one process per
+GPU, torch.distributed (backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests).
+
+Per step and rank:
+    predict -> update + prune + merge of the local shard      (no communication)
+    all-gather of the un-normalised log-weights                (RCCL; N floats in total)
+    identical normalise / nEff / resample-index routine on every rank (bit-identical results)
+    particle migration for parents that live on another rank   (all_to_all of packed particles,
+                                                                point-to-point over xGMI)
+
+The exchange logic is written against a small backend interface so that the same code runs on the
+gfx950 filter (GpuShard) and — in the world_size-2 gloo tests — on a numpy stand-in.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except ImportError:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def shard_range(n_global, world, rank):
+    """contiguous blocks: rank r owns [r*n/P, (r+1)*n/P)"""
+    if n_global % world:
+        raise ValueError("n_global must be divisible by the world size")
+    n = n_global // world
+    return rank * n, n
+
+
+def plan_migration(idx, n_global, world, rank):
+    """Given the global parent indices (identical on every rank) return this rank's part of the
+    exchange:
+        local_parent[j]  : local index of slot j's parent, or -1 if the parent is remote
+        send[r]          : local particle indices to export to rank r (in the order r expects)
+        recv_slots[r]    : local slots filled by what rank r sends (same order)
+    Slot j of rank q (global index g = q*n + j) receives particle idx[g]; rank idx[g] // n owns it.
+    A parent needed by several slots of the same remote rank is sent once per slot: systematic
+    indices are non-decreasing, so duplicates are rare and the plan stays a pure function of idx.
+    """
+    off, n = shard_range(n_global, world, rank)
+    idx = np.asarray(idx, np.int64)
+    owner = idx // n
+    dest_rank = np.arange(n_global) // n
+    local_parent = np.full(n, -1, np.int32)
+    mine = idx[off:off + n]
+    is_local = owner[off:off + n] == rank
+    local_parent[is_local] = (mine[is_local] - off).astype(np.int32)
+    send, recv_slots = [], []
+    for r in range(world):
+        if r == rank:
+            send.append(np.zeros(0, np.int32))
+            recv_slots.append(np.zeros(0, np.int32))
+            continue
+        # what rank r needs from me: its slots whose parent I own, in slot order
+        need = (dest_rank == r) & (owner == rank)
+        send.append((idx[need] - off).astype(np.int32))
+        # what I need from rank r: my slots whose parent r owns, in slot order
+        got = np.nonzero(owner[off:off + n] == r)[0]
+        recv_slots.append(got.astype(np.int32))
+    return local_parent, send, recv_slots
+
+
+class ShardedFilter:
+    """One rank's view of a particle filter sharded over `world` ranks."""
+
+    def __init__(self, backend, n_global, rank, world, group=None):
+        self.b = backend
+        self.n_global = n_global
+        self.rank = rank
+        self.world = world
+        self.group = group
+        self.offset, self.n = shard_range(n_global, world, rank)
+
+    def gather_logweights(self):
+        raw = self.b.raw_logweights()                       # tensor [n] on the backend's device
+        if self.world == 1:
+            return raw.clone()
+        allw = torch.empty(self.n_global, dtype=raw.dtype, device=raw.device)
+        dist.all_gather_into_tensor(allw, raw.contiguous(), group=self.group)
+        return allw
+
+    def normalize(self, all_logw):
+        """-> nEff of the global particle set; the shard's normalised weights are adopted"""
+        return self.b.global_normalize(all_logw)
+
+    def resample(self, uniform):
+        """global systematic resample + migration.  Returns the global parent indices."""
+        idx = self.b.global_resample_indices(uniform)       # numpy [n_global], identical on all ranks
+        local_parent, send, recv_slots = plan_migration(idx, self.n_global, self.world, self.rank)
+        if self.world > 1:
+            send_counts = [len(s) for s in send]
+            recv_counts = [len(s) for s in recv_slots]
+            order = np.concatenate(send) if sum(send_counts) else np.zeros(0, np.int32)
+            out_buf = self.b.export_particles(order)        # tensor [n_send, pack] (uint8)
+            pack = self.b.pack_bytes()
+            in_buf = torch.empty((sum(recv_counts), pack), dtype=torch.uint8, device=out_buf.device)
+            dist.all_to_all_single(in_buf, out_buf, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                   group=self.group)
+            self.b.apply_parents(local_parent)
+            slots = np.concatenate(recv_slots) if sum(recv_counts) else np.zeros(0, np.int32)
+            self.b.import_particles(slots, in_buf)
+        else:
+            self.b.apply_parents(local_parent)
+        self.b.finish_resample()
+        return idx
+
+
+class GpuShard:
+    """ShardedFilter backend over the gfx950 filter (C-ABI calls; torch only wraps device memory)."""
+
+    def __init__(self, flt, n_global):
+        import ctypes as C
+        from ._lib import check, lib, ptr
+        self._C, self._check, self._lib, self._ptr = C, check, lib, ptr
+        self.f = flt
+        self.n_global = n_global
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._all = None
+
+    def _wrap(self, ptr_value, n, dtype=torch.float32):
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr_value), False), "version": 2}
+        return torch.as_tensor(h, device=self.device)
+
+    def raw_logweights(self):
+        p = self._C.c_void_p()
+        self._check(self._lib().phd_raw_logweights_dev(self.f._h, self._C.byref(p)), "phd_raw_logweights_dev")
+        return self._wrap(p.value, self.f.n)
+
+    def update_local_dev(self, d_z, n_meas):
+        self._check(self._lib().phd_update_local_dev(self.f._h, self._ptr(d_z), int(n_meas)), "phd_update_local_dev")
+
+    def global_normalize(self, all_logw):
+        self._all = all_logw
+        ne = self._C.c_float(0)
+        self._check(self._lib().phd_global_normalize(self.f._h, self._ptr(all_logw.data_ptr()), self.n_global,
+                                                     self._C.byref(ne)), "phd_global_normalize")
+        return ne.value
+
+    def global_resample_indices(self, uniform):
+        u = np.ascontiguousarray(np.atleast_1d(uniform), np.float64)
+        idx = np.zeros(self.n_global, np.int32)
+        self._check(self._lib().phd_global_resample_indices(self.f._h, None, self.n_global, self._ptr(u), len(u),
+                                                            self._ptr(idx)), "phd_global_resample_indices")
+        return idx
+
+    def pack_bytes(self):
+        return int(self._lib().phd_particle_pack_bytes(self.f._h))
+
+    def export_particles(self, which):
+        which = np.ascontiguousarray(which, np.int32)
+        buf = torch.empty((len(which), self.pack_bytes()), dtype=torch.uint8, device=self.device)
+        self._check(self._lib().phd_export_particles_dev(self.f._h, self._ptr(which), len(which),
+                                                         self._ptr(buf.data_ptr())), "phd_export_particles_dev")
+        return buf
+
+    def apply_parents(self, local_parent):
+        lp = np.ascontiguousarray(local_parent, np.int32)
+        self._check(self._lib().phd_apply_parents(self.f._h, self._ptr(lp)), "phd_apply_parents")
+
+    def import_particles(self, slots, buf):
+        slots = np.ascontiguousarray(slots, np.int32)
+        self._check(self._lib().phd_import_particles_dev(self.f._h, self._ptr(slots), len(slots),
+                                                         self._ptr(buf.data_ptr())), "phd_import_particles_dev")
+
+    def finish_resample(self):
+        self._check(self._lib().phd_finish_resample(self.f._h), "phd_finish_resample")

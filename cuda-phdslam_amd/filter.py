@@ -193,6 +193,12 @@ class PhdFilter:
     def debug(self, enable=True):
         check(lib().phd_debug_enable(self._h, int(enable)), "phd_debug_enable")
 
+    def stamps(self):
+        """phase stamps of the last update (after debug(2)): [n, 16] ticks of 10 ns"""
+        out = np.zeros((self.n, 16), np.uint64)
+        check(lib().phd_debug_get_stamps(self._h, ptr(out)), "phd_debug_get_stamps")
+        return out
+
     def survivors(self, particle):
         """pruned update components (+ nearly-in-range features) of one particle in slab order"""
         n = C.c_int32(0)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-phase time of the fused update+merge kernel from in-kernel stamps (diagnostic build of the
+kernel: shares, not absolute run time).  usage: python tools/phase_profile.py [config ids...]"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+P = importlib.import_module("cuda-phdslam_amd"); S = importlib.import_module("cuda-phdslam_amd.synthetic")
+NAMES = ["classify+ekf", "pass1 normalisers", "nondetect emit", "pass2 detect emit", "finalise+births", "sort1+permute",
+         "merge rounds", "sort2", "heads/segments", "moment matching", "append+tail"]
+for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
+    w = S.config_workload(cid)
+    N, G, M = w["N"], w["G"], w["M"]
+    with P.PhdFilter(P.default_config(), n_particles=N, map_capacity=2 * G, max_measurements=M) as f:
+        f.set_particles(w["poses"], w["logw"]); f.set_maps(w["maps"], w["sizes"])
+        f.set_frozen(True)
+        f.debug(2)
+        for _ in range(3):
+            f.update(w["z"][0])
+        f.sync()
+        st = f.stamps().astype(np.int64)
+        d = np.diff(st[:, :12], axis=1) * 0.01  # us
+        tot = (st[:, 11] - st[:, 0]) * 0.01
+        span = (st[:, 11].max() - st[:, 0].min()) * 0.01
+        print("config %d (%dx%dx%d): per-workgroup mean %.1f us, max %.1f us; kernel span %.1f us; status %s" %
+              (cid, N, G, M, tot.mean(), tot.max(), span, f.status()))
+        for k, name in enumerate(NAMES):
+            print("   %-20s mean %8.2f us  (%5.1f %%)   max %8.2f" % (name, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean(), d[:, k].max()))
+        r = st[:, 12:16].astype(np.float64)
+        print("   rounds: %.1f per particle; matrix %.2f us, resolve %.2f us, assign %.2f us (sums over rounds)" %
+              (r[:, 3].mean(), r[:, 0].mean() * 0.01, r[:, 1].mean() * 0.01, r[:, 2].mean() * 0.01))
