@@ -551,7 +551,12 @@ static int ensure_debug(phd_filter* f)
     return PHD_OK;
 }
 
-static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M)
+struct FusedPredict {
+    phd_ackerman_control u;
+    const phd_ackerman_noise* d_noise;
+};
+
+static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, const FusedPredict* fp = nullptr)
 {
     UpdateArgs a;
     memset(&a, 0, sizeof(a));
@@ -562,6 +567,17 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M)
     a.parent = f->parent[f->pcur];
     a.parent_reset = f->frozen ? nullptr : f->parent[f->pcur];
     a.pose = f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur];
+    if (fp) {
+        // vehicle predict fused into the update kernel: reads the live pose, writes the predicted one
+        a.pose = f->pose[f->pose_cur];
+        a.pose_out = f->frozen ? f->pose[(f->pose_cur + 1) % 3] : f->pose[f->pose_cur];
+        a.do_predict = 1;
+        a.control = fp->u;
+        a.noise = fp->d_noise;
+        a.seed = f->seed;
+        a.counter = f->counter++;
+        f->pose_for_update = f->frozen ? a.pose_out : nullptr; // what the weights kernel gathers from
+    }
     a.z = d_z;
     a.dlogw = f->dlogw;
     a.M = M;
@@ -702,12 +718,15 @@ extern "C" int phd_step_dev(phd_filter* f, phd_ackerman_control u, const phd_ack
                             const phd_measurement* d_z, int n_meas, double uniform, int force_resample)
 {
     CHECK_F(f);
-    int rc = do_predict(f, u, d_noise);
-    if (rc) return rc;
+    int rc;
     int M = std::min(n_meas, f->MM);
     int mode = WM_COMMIT | (force_resample ? WM_RESAMPLE_FORCE : WM_RESAMPLE_AUTO);
-    if (M > 0) {
-        rc = do_update_merge(f, d_z, M);
+    if (M <= 0) {
+        rc = do_predict(f, u, d_noise); // no measurements: predict only (src/main.cpp:1244-1260)
+        if (rc) return rc;
+    } else {
+        FusedPredict fp = {u, d_noise};
+        rc = do_update_merge(f, d_z, M, &fp);
         if (rc) return rc;
         mode |= WM_ACCUMULATE | WM_NORMALIZE | WM_HAD_MEAS;
     }

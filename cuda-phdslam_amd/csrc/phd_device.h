@@ -50,6 +50,12 @@ struct UpdateArgs {
     int* dbg_n;                 // [n]
     int* dbg_nin;               // [n]
     unsigned long long* stamps; // [n][16] phase stamps (diagnostic instantiation) or NULL
+    // fused vehicle predict (phd_step_dev): pose <- f(pose, control, noise) before the update
+    int do_predict;
+    phd_ackerman_control control;
+    const phd_ackerman_noise* noise; // NULL: draw from (seed, counter)
+    phd_pose* pose_out;
+    unsigned long long seed, counter;
     unsigned* status;
     int* max_surv;
     int* max_map;

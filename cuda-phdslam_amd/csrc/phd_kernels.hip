@@ -39,8 +39,12 @@
 
 namespace phd {
 
-#define PHD_T 256
-#define PHD_NW 4
+#ifndef PHD_NW
+#define PHD_NW 8            // waves per workgroup (512 threads: two waves per SIMD hide LDS/ALU latency
+                            // when a CU holds a single particle; throughput-neutral at 4096 particles)
+#endif
+#define PHD_T (64 * PHD_NW)
+#define PHD_COLS (64 / PHD_NW) // window columns (= candidate seeds) owned by one wave
 #define NEAR_U_BASE 0x40000000
 // phase stamps of the diagnostic instantiation (100 MHz s_memrealtime), thread 0 of each workgroup
 #define STAMP(k) do { if (STAMPS && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -48,6 +52,8 @@ namespace phd {
 typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef unsigned short u16;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 #define LDS_T(T) __attribute__((address_space(3))) T
 
 // ------------------------------------------------------------------------------------------
@@ -238,7 +244,7 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.w = p; p += sv; o.mx = p; p += sv; o.my = p; p += sv; o.xx = p; p += sv;
     o.xy = p; p += sv; o.yy = p; p += sv; o.tr = p; p += sv; o.u = p; p += sv;
     o.alias = p;
-    const u32 feat = 6u * align16u(4u * (u32)C) + align16u(2u * (u32)C);
+    const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C);
     const u32 sort1 = 3u * sv;
     const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
     u32 amax = feat > sort1 ? feat : sort1;
@@ -248,12 +254,12 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.z_r = p; p += align16u(4u * (u32)MM);
     o.z_b = p; p += align16u(4u * (u32)MM);
     o.logZ = p; p += align16u(4u * (u32)MM);
-    o.zpart = p; p += align16u(16u * (u32)MM);
+    o.zpart = p; p += align16u(4u * PHD_NW * (u32)MM);
     o.zok = p; p += align16u(4u * (u32)MM);
-    o.part = p; p += 4u * 4u * 64u;
+    o.part = p; p += 4u * PHD_NW * 64u;
     o.win = p; p += 4u * 7u * 64u;
     o.red = p; p += align16u(4u * (PHD_NW + 4));
-    o.ctr = p; p += 4u * 16u;
+    o.ctr = p; p += 4u * 32u;
     o.total = p;
     return o;
 }
@@ -264,7 +270,8 @@ struct Lds {
     lds_f32 tr; // trace of the covariance (+inf if not SPD): cheap far-pair filter of the merge
     lds_i32 u; // slab index (sort tie-break); after the sort: cluster assignment
     // aliased region
-    lds_f32 f_r, f_b, f_s00, f_s12, f_s11, f_lwb; // per in-range feature, C entries
+    LDS_T(v4f)* f_a;                           // per in-range feature: (r, b, S00, S01+S10)
+    LDS_T(v2f)* f_c;                           //                       (S11, folded log-weight base)
     lds_u16 f_idx;                                // map index of in-range feature j
     lds_u32 khi, klo, pay;                        // sort 1
     lds_u32 key2;                                 // sort 2
@@ -276,7 +283,7 @@ struct Lds {
     lds_u32 part;                     // 4*64 row parts of the window closeness matrix
     lds_f32 win;                      // 7*64: the window's candidates (pos, mx, my, tr, xx, xy, yy)
     lds_f32 red;                      // PHD_NW + 4
-    lds_i32 ctr;                      // 16 counters
+    lds_i32 ctr;                      // 32 counters
 };
 
 __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
@@ -286,14 +293,9 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.w = (lds_f32)(base + o.w); L.mx = (lds_f32)(base + o.mx); L.my = (lds_f32)(base + o.my);
     L.xx = (lds_f32)(base + o.xx); L.xy = (lds_f32)(base + o.xy); L.yy = (lds_f32)(base + o.yy);
     L.tr = (lds_f32)(base + o.tr); L.u = (lds_i32)(base + o.u);
-    const u32 fc = align16u(4u * (u32)C);
     u32 f = o.alias;
-    L.f_r = (lds_f32)(base + f); f += fc;
-    L.f_b = (lds_f32)(base + f); f += fc;
-    L.f_s00 = (lds_f32)(base + f); f += fc;
-    L.f_s12 = (lds_f32)(base + f); f += fc;
-    L.f_s11 = (lds_f32)(base + f); f += fc;
-    L.f_lwb = (lds_f32)(base + f); f += fc;
+    L.f_a = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
+    L.f_c = (LDS_T(v2f)*)(base + f); f += align16u(8u * (u32)C);
     L.f_idx = (lds_u16)(base + f);
     const u32 sv = align16u(4u * (u32)S);
     L.khi = (lds_u32)(base + o.alias);
@@ -313,7 +315,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
 
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total; }
 
-enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*3 */ };
+enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */ };
 
 // append one survivor; slot allocation is wave-aggregated (one LDS atomic per wave per call site)
 __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
@@ -612,9 +614,9 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
     int n_pad = 2;
     while (n_pad < S) n_pad <<= 1;
-    if (n_pad <= 256) rank_sort_survivors(L, S, tid);
-    else if (n_pad <= 512) sort_survivors<2>(L, S, n_pad, tid);
-    else if (n_pad <= 1024) sort_survivors<4>(L, S, n_pad, tid);
+    if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid);
+    else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid);
+    else if (n_pad <= 4 * PHD_T) sort_survivors<4>(L, S, n_pad, tid);
     else sort_survivors<8>(L, S, n_pad, tid);
     STAMP(6);
 
@@ -626,7 +628,12 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     lds_i32 assign = L.u;
     lds_u16 ul_a = (lds_u16)L.pay, ul_b = ul_a + S_cap;  // two u16 lists in the (free) sort-payload region
     LDS_T(u64)* cmask = (LDS_T(u64)*)L.khi;              // candidate-seed mask per listed survivor (khi+klo)
-    lds_u16 cm16 = (lds_u16)L.khi;
+#if PHD_NW == 4
+    typedef u16 cmw_t;
+#else
+    typedef unsigned char cmw_t;
+#endif
+    LDS_T(cmw_t)* cmw = (LDS_T(cmw_t)*)L.khi;
     lds_i32 wpos = (lds_i32)L.win;
     lds_f32 wmx = L.win + 64, wmy = L.win + 128, wtr = L.win + 192, wxx = L.win + 256, wxy = L.win + 320,
             wyy = L.win + 384;
@@ -647,7 +654,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             wxx[tid] = L.xx[i]; wxy[tid] = L.xy[i]; wyy[tid] = L.yy[i];
         }
         __syncthreads();
-        // (1) closeness matrix rows: lane = candidate k, wave = column block [16*wave, 16*wave+16).
+        // (1) closeness matrix rows: lane = candidate k, wave = column block [COLS*wave, COLS*(wave+1)).
         //     A cheap conservative filter (d >= 2|dm|^2/(tr Pa + tr Pb) for SPD covariances, 1 % guard
         //     band) marks candidate columns; the exact test runs on the marked bits only.
         {
@@ -656,8 +663,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             const float kmx = wmx[k], kmy = wmy[k], ktr = wtr[k];
             u32 cand = 0;
 #pragma unroll 4
-            for (int c = 0; c < 16; ++c) {
-                const int l = wave * 16 + c;
+            for (int c = 0; c < PHD_COLS; ++c) {
+                const int l = wave * PHD_COLS + c;
                 const float dx = wmx[l] - kmx, dy = wmy[l] - kmy;
                 const bool near = HELLINGER || !(2.f * (dx * dx + dy * dy) >= Tpre * (wtr[l] + ktr));
                 if (kvalid && l < k && near) cand |= (1u << c);
@@ -668,7 +675,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 while (cand) {
                     const int c = __builtin_ctz(cand);
                     cand &= cand - 1;
-                    const int l = wave * 16 + c;
+                    const int l = wave * PHD_COLS + c;
                     if (is_close<HELLINGER>(wmx[l], wmy[l], wxx[l], wxy[l], wyy[l], kmx, kmy, kxx, kxy, kyy, T))
                         bits |= (1u << c);
                 }
@@ -682,9 +689,9 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         //     sweeps; in practice a handful).  Every wave computes the same mask.
         u64 seeds;
         {
-            const u32 lo = (L.part[0 * 64 + lane] & 0xFFFFu) | (L.part[1 * 64 + lane] << 16);
-            const u32 hi = (L.part[2 * 64 + lane] & 0xFFFFu) | (L.part[3 * 64 + lane] << 16);
-            const u64 row = ((u64)hi << 32) | lo;
+            u64 row = 0;
+#pragma unroll
+            for (int wv = 0; wv < PHD_NW; ++wv) row |= (u64)L.part[wv * 64 + lane] << (PHD_COLS * wv);
             const u64 live = (nwin == 64) ? ~0ull : ((1ull << nwin) - 1ull);
             seeds = live;
             for (int it = 0; it < 65; ++it) {
@@ -700,35 +707,35 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         }
         if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
         // (3a) cheap filter for the survivors after the window: wave w owns the window's candidates
-        //      [16w, 16w+16) and sweeps all listed survivors, 64 (one per lane) at a time ->
-        //      16 candidate-seed bits per (survivor, wave)
+        //      [COLS*w, COLS*(w+1)) and sweeps all listed survivors, 64 (one per lane) at a time ->
+        //      COLS candidate-seed bits per (survivor, wave), stored as one field of the survivor's u64
         {
-            const u32 myseeds = (u32)(seeds >> (16 * wave)) & 0xFFFFu;
+            const u32 myseeds = (u32)(seeds >> (PHD_COLS * wave)) & ((1u << PHD_COLS) - 1u);
             for (int e0 = 0; e0 < nrest; e0 += 64) {
                 const int e = e0 + lane;
-                u32 m16 = 0;
+                u32 mbits = 0;
                 if (myseeds) {
                     float emx = 0, emy = 0, etr = -INFINITY; // -inf trace: the filter rejects
                     if (e < nrest) { const int i = cur[64 + e]; emx = L.mx[i]; emy = L.my[i]; etr = L.tr[i]; }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                    for (int g = 0; g < PHD_COLS / 4; ++g) {
                         if (!((myseeds >> (4 * g)) & 0xFu)) continue; // uniform
                         float smx[4], smy[4], str[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int l = 16 * wave + 4 * g + q;
+                            const int l = PHD_COLS * wave + 4 * g + q;
                             smx[q] = wmx[l]; smy[q] = wmy[l]; str[q] = wtr[l];
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float dx = smx[q] - emx, dy = smy[q] - emy;
                             const bool near = HELLINGER ? (etr > -INFINITY) : !(2.f * (dx * dx + dy * dy) >= Tpre * (str[q] + etr));
-                            if (near) m16 |= (1u << (4 * g + q));
+                            if (near) mbits |= (1u << (4 * g + q));
                         }
                     }
-                    m16 &= myseeds;
+                    mbits &= myseeds;
                 }
-                if (e < nrest) cm16[e * 4 + wave] = (u16)m16;
+                if (e < nrest) cmw[e * PHD_NW + wave] = (cmw_t)mbits;
             }
         }
         __syncthreads();
@@ -788,9 +795,9 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 
     STAMP(7);
     // ---- sort 2: group by seed, members in sorted-position order ---------------------------------
-    if (n_pad <= 256) rank_sort_assignments(L, S, tid);
-    else if (n_pad <= 512) sort_assignments<2>(L, S, n_pad, tid);
-    else if (n_pad <= 1024) sort_assignments<4>(L, S, n_pad, tid);
+    if (n_pad <= PHD_T) rank_sort_assignments(L, S, tid);
+    else if (n_pad <= 2 * PHD_T) sort_assignments<2>(L, S, n_pad, tid);
+    else if (n_pad <= 4 * PHD_T) sort_assignments<4>(L, S, n_pad, tid);
     else sort_assignments<8>(L, S, n_pad, tid);
     STAMP(8);
     // cluster heads -> seg[]
@@ -876,6 +883,54 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 }
 
 // ------------------------------------------------------------------------------------------
+// vehicle predict (phdPredictKernelAckerman, src/phdfilter.cu:785-825) — shared by the stand-alone
+// predict kernel and the fused step
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 splitmix64(u64 x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// counter-based generator: Box-Muller on two splitmix64 outputs (replaces rng.cpp's wall-clock
+// seeded boost::mt19937; draw order (n_alpha, n_encoder), src/phdfilter.cu:1148-1152)
+__device__ __forceinline__ void draw_noise(u64 seed, u64 counter, int i, const DevConfig& cfg, float& n_alpha,
+                                           float& n_encoder)
+{
+    u64 a = splitmix64(seed ^ splitmix64(counter * 0x100000001B3ull + (u64)i * 2ull));
+    u64 b = splitmix64(a);
+    float u1 = ((float)((a >> 40) + 1)) * (1.0f / 16777216.0f);
+    float u2 = ((float)(b >> 40)) * (1.0f / 16777216.0f);
+    float rad = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831855f * u2, &sn, &cs);
+    n_alpha = cfg.stdAlpha * (rad * cs);
+    n_encoder = cfg.stdEncoder * (rad * sn);
+}
+
+__device__ __forceinline__ phd_pose predict_pose(const phd_pose& o, phd_ackerman_control u, float n_alpha,
+                                                 float n_encoder, const DevConfig& cfg)
+{
+    const float ve = u.v_encoder + n_encoder;                                   // :802
+    const float al = u.alpha + n_alpha;                                         // :803
+    const float tn = tanf(al);
+    const float vc = ve / (1 - tn * cfg.h / cfg.l);                             // :804
+    float sn, cs;
+    sincosf(o.ptheta, &sn, &cs);
+    const float xc_dot = vc * cs, yc_dot = vc * sn;                             // :805-806
+    const float thetac_dot = vc * tn / cfg.l;                                   // :807
+    const float dt = cfg.dt / cfg.subdividePredict;                             // :808
+    phd_pose nw;
+    nw.px = o.px + dt * (xc_dot - thetac_dot * (cfg.a * sn + cfg.b * cs));     // :809-812
+    nw.py = o.py + dt * (yc_dot + thetac_dot * (cfg.a * cs - cfg.b * sn));     // :813-816
+    nw.ptheta = wrap_angle(o.ptheta + dt * thetac_dot);                         // :817
+    nw.vx = 0; nw.vy = 0; nw.vtheta = 0;                                        // :818-820
+    return nw;
+}
+
+// ------------------------------------------------------------------------------------------
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
 template <bool STAMPS>
@@ -893,12 +948,20 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     const int n_map = A.count_in[src];
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
     float* __restrict__ out = A.map_out + (size_t)p * 6 * cap;
-    const phd_pose pose = A.pose[p];
+    phd_pose pose = A.pose[p];
+    if (A.do_predict) {
+        // fused vehicle predict: every lane computes the same pose (no broadcast needed), lane 0 stores it
+        float n_alpha, n_encoder;
+        if (A.noise) { n_alpha = A.noise[p].n_alpha; n_encoder = A.noise[p].n_encoder; }
+        else draw_noise(A.seed, A.counter, p, cfg, n_alpha, n_encoder);
+        pose = predict_pose(pose, A.control, n_alpha, n_encoder, cfg);
+        if (tid == 0) A.pose_out[p] = pose;
+    }
     u64* st = STAMPS ? (A.stamps + (size_t)p * 16) : nullptr;
     if (STAMPS && tid == 0) { st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0; }
     STAMP(0);
 
-    if (tid < 16) L.ctr[tid] = 0;
+    if (tid < 32) L.ctr[tid] = 0;
     // measurements -> LDS (the reference keeps them in __constant__ Z[256], src/phdfilter.cu:120)
     for (int m = tid; m < M; m += PHD_T) {
         phd_measurement z = A.z[m];
@@ -914,9 +977,10 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         int n_in = 0, n_out0 = 0;
         for (int i0 = 0; i0 < n_map; i0 += PHD_T) {
             const int i = i0 + tid;
-            int cls = -1;
+            int cls = -1, nd_j = 0;
             float w = 0, mx = 0, my = 0, pxx = 0, pxy = 0, pyy = 0;
             EkfTerms t;
+            t.pd = 0.f;
             if (i < n_map) {
                 w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
                 pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
@@ -939,22 +1003,25 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
             }
             if (cls == 1) {
                 const int j = off_in + __popcll(b_in & lanemask_lt());
-                L.f_r[j] = t.r; L.f_b[j] = t.b;
-                L.f_s00[j] = t.s00; L.f_s12[j] = t.s12; L.f_s11[j] = t.s11;
                 // log pd + log w + (-log 2pi - 0.5 log det)   (:1911,1916-1917), folded per feature
                 const float lw0 = safe_log(t.pd) + safe_log(w);
-                L.f_lwb[j] = lw0 - safe_log(6.2831855f) - 0.5f * safe_log(t.det);
+                L.f_a[j] = (v4f){t.r, t.b, t.s00, t.s12};
+                L.f_c[j] = (v2f){t.s11, lw0 - safe_log(6.2831855f) - 0.5f * safe_log(t.det)};
                 L.f_idx[j] = (u16)i;
                 pdw_local += t.pd * w;
-                // non-detection term (:2145-2148): prior with weight w(1-pd); prune test (:2314)
+                nd_j = j;
             } else if (cls == 0) {
                 L.out_idx[off_out + __popcll(b_out & lanemask_lt())] = (u16)i;
             }
-            // nearly-in-range features skip the update and join the merge (:3242-3257)
+            // straight into the survivor list: nearly-in-range features, which skip the update and join
+            // the merge (:3242-3257), and the non-detection term of an in-range feature — the prior
+            // with weight w(1-pd) (:2145-2148) — unless it is pruned (:2314)
             {
-                const bool keep = (cls == 2);
+                const float wnd = w * (1 - t.pd);
+                const bool keep = (cls == 2) || (cls == 1 && !(wnd < cfg.minFeatureWeight));
                 const int slot = alloc_slots(keep, L.ctr);
-                if (keep) store_survivor(L, slot, S_cap, w, mx, my, pxx, pxy, pyy, NEAR_U_BASE + i);
+                if (keep) store_survivor(L, slot, S_cap, cls == 2 ? w : wnd, mx, my, pxx, pxy, pyy,
+                                         cls == 2 ? NEAR_U_BASE + i : nd_j);
             }
             n_in += tot_in; n_out0 += tot_out;
             __syncthreads();
@@ -983,10 +1050,12 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         for (int jb = wave * JS; jb < n_in; jb += PHD_NW * JS) {
             const int j = jb + js;
             const int jj = j < n_in ? j : n_in - 1;
-            const float i0 = zr - L.f_r[jj];
-            const float i1 = wrap_angle(zb - L.f_b[jj]);
-            const float dist = i0 * i0 * L.f_s00[jj] + i0 * i1 * L.f_s12[jj] + i1 * i1 * L.f_s11[jj]; // :1908-1910
-            const float lw = L.f_lwb[jj] - 0.5f * dist;
+            const v4f fa = L.f_a[jj];
+            const v2f fc = L.f_c[jj];
+            const float i0 = zr - fa.x;
+            const float i1 = wrap_angle(zb - fa.y);
+            const float dist = i0 * i0 * fa.z + i0 * i1 * fa.w + i1 * i1 * fc.x;                       // :1908-1910
+            const float lw = fc.y - 0.5f * dist;
             const float e = __expf(lw);                                                               // :2205
             acc += (mvalid && j < n_in) ? e : 0.f;
         }
@@ -1015,23 +1084,6 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
 
     STAMP(2);
     // ---- pass 2: final weights; prune before store --------------------------------------------------
-    // non-detection terms
-    for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
-        const int j = j0 + tid;
-        bool keep = false;
-        float w = 0, mx = 0, my = 0, pxx = 0, pxy = 0, pyy = 0;
-        if (j < n_in) {
-            const int i = L.f_idx[j];
-            w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
-            pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
-            // pd of an in-range feature (:1849-1850)
-            const float pd = (L.f_r[j] <= cfg.maxRange && fabsf(L.f_b[j]) <= cfg.maxBearing) ? cfg.pd : 0.f;
-            w = w * (1 - pd);                                                                         // :2148
-            keep = !(w < cfg.minFeatureWeight);                                                       // :2314
-        }
-        const int slot = alloc_slots(keep, L.ctr);
-        if (keep) store_survivor(L, slot, S_cap, w, mx, my, pxx, pxy, pyy, j);
-    }
     STAMP(3);
     // detection terms
     for (int mt = 0; mt < m_tiles; ++mt) {
@@ -1042,10 +1094,12 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         for (int jb = wave * JS; jb < n_in; jb += PHD_NW * JS) {
             const int j = jb + js;
             const int jj = j < n_in ? j : n_in - 1;
-            const float i0 = zr - L.f_r[jj];
-            const float i1 = wrap_angle(zb - L.f_b[jj]);
-            const float dist = i0 * i0 * L.f_s00[jj] + i0 * i1 * L.f_s12[jj] + i1 * i1 * L.f_s11[jj];
-            const float lw = L.f_lwb[jj] - 0.5f * dist;
+            const v4f fa = L.f_a[jj];
+            const v2f fc = L.f_c[jj];
+            const float i0 = zr - fa.x;
+            const float i1 = wrap_angle(zb - fa.y);
+            const float dist = i0 * i0 * fa.z + i0 * i1 * fa.w + i1 * i1 * fc.x;
+            const float lw = fc.y - 0.5f * dist;
             const float w = zok ? __expf(lw - lz) : 0.f;                                              // :2242-2243
             const bool keep = mvalid && (j < n_in) && !(w < cfg.minFeatureWeight);                    // :2314
             // survivors are sparse (~1 %): the hot loop only records (weight, slab index); mean and
@@ -1153,56 +1207,16 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     STAMP(11);
 }
 
-// ------------------------------------------------------------------------------------------
-// vehicle predict (phdPredictKernelAckerman, src/phdfilter.cu:785-825)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 splitmix64(u64 x)
-{
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
                                    u64 seed, u64 counter, DevConfig cfg)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    phd_pose o = in[i];
     float n_alpha, n_encoder;
-    if (noise) {
-        n_alpha = noise[i].n_alpha;
-        n_encoder = noise[i].n_encoder;
-    } else {
-        // counter-based generator: Box-Muller on two splitmix64 outputs (replaces rng.cpp's
-        // wall-clock seeded boost::mt19937; draw order (n_alpha, n_encoder), phdfilter.cu:1148-1152)
-        u64 a = splitmix64(seed ^ splitmix64(counter * 0x100000001B3ull + (u64)i * 2ull));
-        u64 b = splitmix64(a);
-        float u1 = ((float)((a >> 40) + 1)) * (1.0f / 16777216.0f);
-        float u2 = ((float)(b >> 40)) * (1.0f / 16777216.0f);
-        float rad = sqrtf(-2.f * logf(u1));
-        float sn, cs;
-        sincosf(6.2831855f * u2, &sn, &cs);
-        n_alpha = cfg.stdAlpha * (rad * cs);
-        n_encoder = cfg.stdEncoder * (rad * sn);
-    }
-    const float ve = u.v_encoder + n_encoder;                                   // :802
-    const float al = u.alpha + n_alpha;                                         // :803
-    const float tn = tanf(al);
-    const float vc = ve / (1 - tn * cfg.h / cfg.l);                             // :804
-    float sn, cs;
-    sincosf(o.ptheta, &sn, &cs);
-    const float xc_dot = vc * cs, yc_dot = vc * sn;                             // :805-806
-    const float thetac_dot = vc * tn / cfg.l;                                   // :807
-    const float dt = cfg.dt / cfg.subdividePredict;                             // :808
-    phd_pose nw;
-    nw.px = o.px + dt * (xc_dot - thetac_dot * (cfg.a * sn + cfg.b * cs));     // :809-812
-    nw.py = o.py + dt * (yc_dot + thetac_dot * (cfg.a * cs - cfg.b * sn));     // :813-816
-    nw.ptheta = wrap_angle(o.ptheta + dt * thetac_dot);                         // :817
-    nw.vx = 0; nw.vy = 0; nw.vtheta = 0;                                        // :818-820
-    out[i] = nw;
+    if (noise) { n_alpha = noise[i].n_alpha; n_encoder = noise[i].n_encoder; }
+    else draw_noise(seed, counter, i, cfg, n_alpha, n_encoder);
+    out[i] = predict_pose(in[i], u, n_alpha, n_encoder, cfg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1238,9 +1252,9 @@ __device__ __forceinline__ double det_exp(float xf)
     return ldexp(p, (int)kd);
 }
 
-#define PHD_WT 1024
 #define PHD_CDF_CHUNK 2048
 
+template <int PHD_WT>
 __device__ __forceinline__ float block_reduce_w(float v, float* sc, int tid, bool is_max)
 {
 #pragma unroll
@@ -1259,6 +1273,7 @@ __device__ __forceinline__ float block_reduce_w(float v, float* sc, int tid, boo
 // mode bits
 enum { W_ACCUMULATE = 1, W_NORMALIZE = 2, W_RESAMPLE_FORCE = 4, W_RESAMPLE_AUTO = 8, W_HAD_MEAS = 16, W_COMMIT = 32 };
 
+template <int PHD_WT>
 __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
 {
     __shared__ float sc[PHD_WT / 64];
@@ -1285,10 +1300,10 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     if (A.mode & W_NORMALIZE) {
         float mx = -FLT_MAX;
         for (int i = tid; i < n; i += PHD_WT) mx = fmaxf(mx, logw[i]);
-        mx = block_reduce_w(mx, sc, tid, true);
+        mx = block_reduce_w<PHD_WT>(mx, sc, tid, true);
         float s = 0.f;
         for (int i = tid; i < n; i += PHD_WT) s += expf(logw[i] - mx);
-        s = block_reduce_w(s, sc, tid, false);
+        s = block_reduce_w<PHD_WT>(s, sc, tid, false);
         const float lse = safe_log(s) + mx;
         for (int i = tid; i < n; i += PHD_WT) logw[i] -= lse;
         __syncthreads();
@@ -1296,7 +1311,7 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     // 3. nEff = 1 / sum exp(2w) / N (src/main.cpp:1281-1284)
     float s2 = 0.f;
     for (int i = tid; i < n; i += PHD_WT) s2 += expf(2 * logw[i]);
-    s2 = block_reduce_w(s2, sc, tid, false);
+    s2 = block_reduce_w<PHD_WT>(s2, sc, tid, false);
     const float neff = (float)(1.0 / (double)s2 / (double)n);
     if (tid == 0) {
         A.neff_out[0] = neff;
@@ -1410,6 +1425,157 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// the same routine for n <= BT*R with the weights held in registers from load to commit: one
+// global read of (logw, dlogw), three block reductions, the sequential CDF in LDS, one global
+// write.  n <= PHD_CDF_CHUNK.  Results are a pure function of (inputs, BT): every rank of a
+// multi-GPU run launches the same instantiation on the same gathered vector.
+// ------------------------------------------------------------------------------------------
+template <int BT, int R>
+__global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
+{
+    __shared__ float sc[BT / 64];
+    __shared__ int s_flag;
+    __shared__ int s_argmax;
+    __shared__ double s_chunk[PHD_CDF_CHUNK];
+    __shared__ double s_bestv[BT / 64];
+    __shared__ int s_besti[BT / 64];
+    const int tid = threadIdx.x;
+    const int n = A.n;
+    float w[R];
+    // 1. load + accumulate (src/phdfilter.cu:3741-3744)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * BT;
+        w[r] = -FLT_MAX;
+        if (i < n) {
+            w[r] = A.logw_in[i];
+            if (A.mode & W_ACCUMULATE) w[r] += A.dlogw[i];
+            if (A.raw_out) A.raw_out[i] = w[r];
+        }
+    }
+    // 2. logSumExp normalise (src/device_math.cuh:549-558, src/phdfilter.cu:3749-3754)
+    if (A.mode & W_NORMALIZE) {
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int r = 0; r < R; ++r) mx = fmaxf(mx, w[r]);
+        mx = block_reduce_w<BT>(mx, sc, tid, true);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (tid + r * BT < n) s += expf(w[r] - mx);
+        s = block_reduce_w<BT>(s, sc, tid, false);
+        const float lse = safe_log(s) + mx;
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] -= lse;
+    }
+    // 3. nEff (src/main.cpp:1281-1284)
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (tid + r * BT < n) s2 += expf(2 * w[r]);
+    s2 = block_reduce_w<BT>(s2, sc, tid, false);
+    const float neff = (float)(1.0 / (double)s2 / (double)n);
+    int doit = 0;
+    if (A.mode & W_RESAMPLE_FORCE) doit = 1;
+    else if ((A.mode & W_RESAMPLE_AUTO) && (neff <= A.resample_thresh) && (A.mode & W_HAD_MEAS)) doit = 1; // :1286
+    if (tid == 0) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
+    const int n_new = A.n_new;
+    if (!doit) { // uniform: neff is the same in every thread
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * BT;
+            if (i < n) A.logw[i] = w[r];
+        }
+        for (int j = tid; j < n_new; j += BT) {
+            A.idx_out[j] = j;                                                                          // :1292-1296
+            if (A.mode & W_COMMIT) { A.pose_out[j] = A.pose_in[j]; A.parent_out[j] = A.parent_in[j]; }
+        }
+        return;
+    }
+    // 4. resample: p_i = det_exp(w_i); sequential double CDF by one lane (src/main.cpp:463,495)
+    double best = -1.0;
+    int besti = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * BT;
+        if (i < n) {
+            const double e = det_exp(w[r]);
+            s_chunk[i] = e;
+            if (e > best) { best = e; besti = i; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double c = 0.0;
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            const double e0 = s_chunk[i], e1 = s_chunk[i + 1], e2 = s_chunk[i + 2], e3 = s_chunk[i + 3];
+            const double e4 = s_chunk[i + 4], e5 = s_chunk[i + 5], e6 = s_chunk[i + 6], e7 = s_chunk[i + 7];
+            c += e0; s_chunk[i] = c;
+            c += e1; s_chunk[i + 1] = c;
+            c += e2; s_chunk[i + 2] = c;
+            c += e3; s_chunk[i + 3] = c;
+            c += e4; s_chunk[i + 4] = c;
+            c += e5; s_chunk[i + 5] = c;
+            c += e6; s_chunk[i + 6] = c;
+            c += e7; s_chunk[i + 7] = c;
+        }
+        for (; i < n; ++i) { c += s_chunk[i]; s_chunk[i] = c; }
+    }
+    __syncthreads();
+    const double ctot = s_chunk[n - 1];
+    const double interval = 1.0 / n_new;
+    // the overflow guard (src/main.cpp:475-494) needs the arg-max of p only if the last threshold
+    // exceeds the total mass (weights that do not sum to one): thresholds increase with j
+    {
+        const int jl = n_new - 1;
+        const double ul = (A.n_uniforms == 1) ? A.u0 : A.uniforms[jl];
+        const bool overflow = (jl * interval + ul * interval) > ctot;
+        if (overflow) { // uniform
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(besti, off);
+                if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+            }
+            if ((tid & 63) == 0) { s_bestv[tid >> 6] = best; s_besti[tid >> 6] = besti; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int wv = 1; wv < BT / 64; ++wv)
+                    if (s_bestv[wv] > best || (s_bestv[wv] == best && s_besti[wv] < besti)) { best = s_bestv[wv]; besti = s_besti[wv]; }
+                s_argmax = besti;
+            }
+            __syncthreads();
+        }
+    }
+    const float nlw = (float)(-log((double)A.n_weight_norm));
+    for (int j = tid; j < n_new; j += BT) {
+        const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
+        const double r = j * interval + u * interval;                                                  // :468
+        int idx;
+        if (r > ctot) {
+            idx = s_argmax;
+        } else {
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (r > s_chunk[mid]) lo = mid + 1; else hi = mid;
+            }
+            idx = lo;
+        }
+        A.idx_out[j] = idx;
+        if (A.mode & W_COMMIT) { // copy_particles (src/slamtypes.h:313-333)
+            A.pose_out[j] = A.pose_in[idx];
+            A.parent_out[j] = A.parent_in[idx];
+        }
+    }
+    // weights: -log(N) after a committed resample (slamtypes.h:327), else the normalised values
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * BT;
+        if (i < n) A.logw[i] = (A.mode & W_COMMIT) ? nlw : w[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
 // AoS Gaussian2D (28 B, reference layout) <-> SoA slab planes [w, mx, my, pxx, pxy, pyy][cap]
@@ -1454,6 +1620,7 @@ __global__ void phd_unpack_maps_kernel(const float* __restrict__ slabs, const in
 }
 
 // weighted-mean pose (src/main.cpp:331-340) and arg-max weight (:347-356); one workgroup
+#define PHD_WT 1024
 __global__ __launch_bounds__(PHD_WT) void phd_state_kernel(const phd_pose* __restrict__ poses,
                                                            const float* __restrict__ logw, int n,
                                                            float* __restrict__ pose_out, int* __restrict__ argmax_out)
@@ -1474,7 +1641,7 @@ __global__ __launch_bounds__(PHD_WT) void phd_state_kernel(const phd_pose* __res
         if (lw > best) { best = lw; besti = i; }
     }
     for (int k = 0; k < 6; ++k) {
-        const float r = block_reduce_w(acc[k], sc, tid, false);
+        const float r = block_reduce_w<PHD_WT>(acc[k], sc, tid, false);
         if (tid == 0) pose_out[k] = r;
     }
     // arg-max with ties to the lowest index (strict '>' scan in the reference)
@@ -1583,7 +1750,13 @@ hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(phd_weights_kernel, dim3(1), dim3(PHD_WT), 0, st, a);
+    // one workgroup; small particle sets use a small one (cheaper barriers, same results: the
+    // reductions are fixed trees per block size)
+    // (the commit of the small kernel writes logw[j] for j < n: it needs n_new <= n, true for every caller)
+    if (a.n <= 512 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), 0, st, a);
+    else if (a.n <= 2048 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 8>), dim3(1), dim3(256), 0, st, a);
+    else if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(phd_weights_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 

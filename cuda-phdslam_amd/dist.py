@@ -77,6 +77,11 @@ class ShardedFilter:
         raw = self.b.raw_logweights()                       # tensor [n] on the backend's device
         if self.world == 1:
             return raw.clone()
+        if dist.get_backend(self.group) == "gloo" and raw.is_cuda:
+            # test transport (several ranks sharing one GPU): stage through host memory
+            host = torch.empty(self.n_global, dtype=raw.dtype)
+            dist.all_gather_into_tensor(host, raw.cpu().contiguous(), group=self.group)
+            return host.to(raw.device)
         allw = torch.empty(self.n_global, dtype=raw.dtype, device=raw.device)
         dist.all_gather_into_tensor(allw, raw.contiguous(), group=self.group)
         return allw
@@ -95,9 +100,28 @@ class ShardedFilter:
             order = np.concatenate(send) if sum(send_counts) else np.zeros(0, np.int32)
             out_buf = self.b.export_particles(order)        # tensor [n_send, pack] (uint8)
             pack = self.b.pack_bytes()
-            in_buf = torch.empty((sum(recv_counts), pack), dtype=torch.uint8, device=out_buf.device)
-            dist.all_to_all_single(in_buf, out_buf, output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                   group=self.group)
+            if dist.get_backend(self.group) == "gloo":
+                # gloo has no all_to_all: pairwise exchange through host memory (CPU tests, and several
+                # ranks sharing one GPU); rank order breaks the send/recv symmetry
+                host_out = out_buf.cpu()
+                so = np.concatenate([[0], np.cumsum(send_counts)])
+                pieces = []
+                for r in range(self.world):
+                    piece = torch.empty((recv_counts[r], pack), dtype=torch.uint8)
+                    if r != self.rank:
+                        mine = host_out[so[r]:so[r + 1]].contiguous()
+                        if self.rank < r:
+                            dist.send(mine, r, group=self.group)
+                            dist.recv(piece, r, group=self.group)
+                        else:
+                            dist.recv(piece, r, group=self.group)
+                            dist.send(mine, r, group=self.group)
+                    pieces.append(piece)
+                in_buf = torch.cat(pieces).to(out_buf.device)
+            else:
+                in_buf = torch.empty((sum(recv_counts), pack), dtype=torch.uint8, device=out_buf.device)
+                dist.all_to_all_single(in_buf, out_buf, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                       group=self.group)
             self.b.apply_parents(local_parent)
             slots = np.concatenate(recv_slots) if sum(recv_counts) else np.zeros(0, np.int32)
             self.b.import_particles(slots, in_buf)
@@ -119,6 +143,20 @@ class GpuShard:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._all = None
 
+    # The filter enqueues on its own HIP stream unless it was created on torch's current stream
+    # (bench.py does that: RCCL collectives and kernels are then ordered by the stream itself).
+    # With different streams the hand-offs are ordered by host synchronisation.
+    def _same_stream(self):
+        return int(self.f.stream or 0) == int(torch.cuda.current_stream().cuda_stream)
+
+    def _torch_to_filter(self):
+        if not self._same_stream():
+            torch.cuda.current_stream().synchronize()
+
+    def _filter_to_torch(self):
+        if not self._same_stream():
+            self.f.sync()
+
     def _wrap(self, ptr_value, n, dtype=torch.float32):
         class _Holder:
             pass
@@ -129,6 +167,7 @@ class GpuShard:
     def raw_logweights(self):
         p = self._C.c_void_p()
         self._check(self._lib().phd_raw_logweights_dev(self.f._h, self._C.byref(p)), "phd_raw_logweights_dev")
+        self._filter_to_torch()
         return self._wrap(p.value, self.f.n)
 
     def update_local_dev(self, d_z, n_meas):
@@ -136,6 +175,7 @@ class GpuShard:
 
     def global_normalize(self, all_logw):
         self._all = all_logw
+        self._torch_to_filter()
         ne = self._C.c_float(0)
         self._check(self._lib().phd_global_normalize(self.f._h, self._ptr(all_logw.data_ptr()), self.n_global,
                                                      self._C.byref(ne)), "phd_global_normalize")
@@ -156,6 +196,7 @@ class GpuShard:
         buf = torch.empty((len(which), self.pack_bytes()), dtype=torch.uint8, device=self.device)
         self._check(self._lib().phd_export_particles_dev(self.f._h, self._ptr(which), len(which),
                                                          self._ptr(buf.data_ptr())), "phd_export_particles_dev")
+        self._filter_to_torch()
         return buf
 
     def apply_parents(self, local_parent):
@@ -164,6 +205,7 @@ class GpuShard:
 
     def import_particles(self, slots, buf):
         slots = np.ascontiguousarray(slots, np.int32)
+        self._torch_to_filter()
         self._check(self._lib().phd_import_particles_dev(self.f._h, self._ptr(slots), len(slots),
                                                          self._ptr(buf.data_ptr())), "phd_import_particles_dev")
 

@@ -1,0 +1,87 @@
+"""The multi-rank path on real hardware: two ranks share cuda:0 (gloo transport staged through host
+memory stands in for RCCL, which needs one GPU per rank) and must reproduce, bit for bit, what one
+filter holding all particles computes — update, global normalise, global systematic resample,
+particle migration (export / all-to-all / import)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir, N, G, M, seed, u):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    D = importlib.import_module("cuda-phdslam_amd.dist")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    w = S.make_workload(N, G, M, seed=seed)
+    n = N // world
+    sl = slice(rank * n, (rank + 1) * n)
+    cfg = P.default_config(n_particles=N)
+    f = P.PhdFilter(cfg, n_particles=n, map_capacity=4 * G, max_measurements=M, global_particles=N, global_offset=rank * n)
+    f.set_particles(w["poses"][sl], w["logw"][sl])
+    f.set_maps(w["maps"][sl], w["sizes"][sl])
+    d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    d_noise = torch.from_numpy(w["noise"][0][sl].copy()).to(dev)
+    torch.cuda.synchronize()
+    shard = D.GpuShard(f, N)
+    sf = D.ShardedFilter(shard, N, rank, world)
+    f.predict_dev((2.0, 0.05), d_noise.data_ptr())
+    shard.update_local_dev(d_z.data_ptr(), M)
+    allw = sf.gather_logweights()
+    neff = sf.normalize(allw)
+    _, lw_norm = f.get_particles()
+    idx = sf.resample(u)
+    poses, lw = f.get_particles()
+    maps = f.get_maps()
+    f.status()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, neff=neff, lw_norm=lw_norm, lw=lw, poses=poses,
+             sizes=np.array([len(m) for m in maps]), flat=np.concatenate(maps))
+    f.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_filter(tmp_path):
+    import torch.multiprocessing as mp
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    N, G, M, seed, u, world = 64, 24, 10, 77, 0.61, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), N, G, M, seed, u), nprocs=world, join=True)
+    # the same filter on one rank
+    w = S.make_workload(N, G, M, seed=seed)
+    with P.PhdFilter(P.default_config(n_particles=N), n_particles=N, map_capacity=4 * G, max_measurements=M) as f:
+        f.set_particles(w["poses"], w["logw"])
+        f.set_maps(w["maps"], w["sizes"])
+        f.predict((2.0, 0.05), w["noise"][0])
+        f.update(w["z"][0])
+        _, lw_norm = f.get_particles()
+        neff = f.neff()
+        idx = f.resample(u)
+        poses, lw = f.get_particles()
+        maps = f.get_maps()
+    n = N // world
+    moved = 0
+    for r in range(world):
+        d = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(d["idx"], idx)
+        assert float(d["neff"]) == neff
+        assert np.array_equal(d["lw_norm"], lw_norm[r * n:(r + 1) * n])
+        assert np.array_equal(d["lw"], lw[r * n:(r + 1) * n])
+        assert np.array_equal(d["poses"], poses[r * n:(r + 1) * n])
+        off = np.concatenate([[0], np.cumsum(d["sizes"])])
+        for j in range(n):
+            got = d["flat"][off[j]:off[j + 1]]
+            assert np.array_equal(got, maps[r * n + j]), (r, j)
+        moved += int(np.sum(idx[r * n:(r + 1) * n] // n != r))
+    assert moved > 0
