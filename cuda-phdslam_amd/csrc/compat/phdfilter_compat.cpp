@@ -1,0 +1,212 @@
+// phdfilter_compat.cpp — src/phdfilter.h's entry points implemented over the C-ABI.
+//
+// Semantics follow the reference: the caller owns the SynthSLAM, every call uploads the state it
+// needs, runs the gfx950 kernels and writes the results back into the SynthSLAM (the reference
+// round-trips the whole state per call as well, src/phdfilter.cu:2952-3002,3293-3318).  For
+// throughput, drive the C-ABI directly and keep the state on the device (see phdslam_main.cpp).
+#include "phdfilter_compat.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+static_assert(sizeof(ConstantVelocityState) == 24 && sizeof(Gaussian2D) == 28 && sizeof(RangeBearingMeasurement) == 12 &&
+                  sizeof(SlamConfig) == 324 && sizeof(AckermanControl) == 8,
+              "reference layouts");
+
+SlamConfig config;
+
+namespace {
+phd_filter* g_filter = nullptr;
+int g_n = 0, g_cap = 0;
+
+[[noreturn]] void die(const char* where)
+{
+    // the reference's error convention: checkCudaErrors -> print + exit(EXIT_FAILURE)
+    fprintf(stderr, "%s failed: %s\n", where, phd_last_error());
+    exit(EXIT_FAILURE);
+}
+#define CHK(call) do { if ((call) != PHD_OK) die(#call); } while (0)
+
+int needed_capacity(const SynthSLAM& p, int n_meas)
+{
+    size_t mx = 0;
+    for (const auto& m : p.maps_static) mx = std::max(mx, m.size());
+    // births can add one component per measurement and step; leave head room
+    int want = (int)mx + 2 * std::max(n_meas, 32) + 64;
+    int cap = 256;
+    while (cap < want) cap *= 2;
+    return cap;
+}
+
+void ensure_filter(const SynthSLAM& p, int n_meas)
+{
+    const int cap = needed_capacity(p, n_meas);
+    if (g_filter && g_n == p.n_particles && cap <= g_cap) return;
+    if (g_filter) phd_destroy(g_filter);
+    g_filter = nullptr;
+    phd_options o = {};
+    o.n_particles = p.n_particles;
+    o.map_capacity = std::max(cap, g_cap);
+    CHK(phd_create(&config, &o, &g_filter));
+    g_n = p.n_particles;
+    g_cap = o.map_capacity;
+}
+
+void upload(const SynthSLAM& p)
+{
+    CHK(phd_set_particles(g_filter, p.states.data(), p.weights.data(), p.n_particles));
+    std::vector<Gaussian2D> concat;
+    std::vector<int32_t> sizes(p.n_particles);
+    for (int i = 0; i < p.n_particles; ++i) {
+        sizes[i] = (int32_t)p.maps_static[i].size();
+        concat.insert(concat.end(), p.maps_static[i].begin(), p.maps_static[i].end());
+    }
+    CHK(phd_set_maps(g_filter, concat.data(), sizes.data()));
+}
+
+void download(SynthSLAM& p, bool maps)
+{
+    CHK(phd_get_particles(g_filter, p.states.data(), p.weights.data()));
+    if (!maps) return;
+    std::vector<int32_t> sizes(p.n_particles);
+    CHK(phd_get_map_sizes(g_filter, sizes.data()));
+    size_t total = 0;
+    for (int s : sizes) total += s;
+    std::vector<Gaussian2D> concat(total ? total : 1);
+    CHK(phd_get_maps(g_filter, concat.data(), concat.size(), sizes.data()));
+    size_t off = 0;
+    for (int i = 0; i < p.n_particles; ++i) {
+        p.maps_static[i].assign(concat.begin() + off, concat.begin() + off + sizes[i]);
+        off += sizes[i];
+    }
+}
+} // namespace
+
+void initRandomNumberGenerators() {} // the variance diagnostic's cuRAND states: out of scope
+
+void setDeviceConfig(const SlamConfig& c)
+{
+    config = c;
+    if (g_filter) CHK(phd_set_config(g_filter, &config));
+}
+
+void phdPredict(SynthSLAM& particles, ...)
+{
+    if (config.motionType != ACKERMAN_MOTION) {
+        fprintf(stderr, "phdPredict: only the Ackerman motion model is supported\n");
+        exit(EXIT_FAILURE);
+    }
+    va_list ap;
+    va_start(ap, particles);
+    AckermanControl control = va_arg(ap, AckermanControl); // src/phdfilter.cu:1140-1144
+    va_end(ap);
+    ensure_filter(particles, 0);
+    CHK(phd_set_particles(g_filter, particles.states.data(), particles.weights.data(), particles.n_particles));
+    // host-drawn noise in the reference's order (n_alpha, n_encoder) per particle (src/phdfilter.cu:1147-1152)
+    std::vector<AckermanNoise> noise(particles.n_particles);
+    for (auto& nz : noise) {
+        nz.n_alpha = (REAL)(config.stdAlpha * randn());
+        nz.n_encoder = (REAL)(config.stdEncoder * randn());
+    }
+    CHK(phd_predict_ackerman(g_filter, control, noise.data()));
+    CHK(phd_get_particles(g_filter, particles.states.data(), nullptr));
+}
+
+SynthSLAM phdUpdateSynth(SynthSLAM& particles, measurementSet measurements)
+{
+    SynthSLAM particlesPreMerge(particles); // the reference returns a pre-update copy (src/phdfilter.cu:3351,3760)
+    if (measurements.empty()) return particlesPreMerge;
+    ensure_filter(particles, (int)measurements.size());
+    upload(particles);
+    CHK(phd_update(g_filter, measurements.data(), (int)measurements.size()));
+    uint32_t st = 0;
+    if (phd_device_status(g_filter, &st, nullptr, nullptr) != PHD_OK) die("phd_update (capacity)");
+    download(particles, true);
+    return particlesPreMerge;
+}
+
+REAL computeNeff(SynthSLAM& particles)
+{
+    ensure_filter(particles, 0);
+    CHK(phd_set_particles(g_filter, nullptr, particles.weights.data(), particles.n_particles));
+    REAL ne = 0;
+    CHK(phd_neff(g_filter, &ne));
+    return ne;
+}
+
+SynthSLAM resampleParticles(SynthSLAM oldParticles, int n_new_particles)
+{
+    if (n_new_particles >= 0 && n_new_particles != oldParticles.n_particles) {
+        fprintf(stderr, "resampleParticles: changing the particle count is not supported\n");
+        exit(EXIT_FAILURE);
+    }
+    ensure_filter(oldParticles, 0);
+    CHK(phd_set_particles(g_filter, nullptr, oldParticles.weights.data(), oldParticles.n_particles));
+    const double u = randu01();
+    std::vector<int32_t> idx(oldParticles.n_particles);
+    CHK(phd_resample(g_filter, &u, 1, idx.data()));
+    return oldParticles.copy_particles(std::vector<int>(idx.begin(), idx.end()));
+}
+
+void recoverSlamState(SynthSLAM& particles, ConstantVelocityState& expectedPose, std::vector<REAL>& cn_estimate)
+{
+    ensure_filter(particles, 0);
+    CHK(phd_set_particles(g_filter, particles.states.data(), particles.weights.data(), particles.n_particles));
+    CHK(phd_expected_pose(g_filter, &expectedPose));
+    // MAP map: the map of the arg-max-weight particle (src/main.cpp:344-361; map_estimate = 0 yields no
+    // map for N > 1 in the reference — treated as MAP here)
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int i = 0; i < particles.n_particles; ++i)
+        if (particles.weights[i] > best) { best = particles.weights[i]; bi = i; }
+    particles.max_map_static = particles.maps_static[bi];
+    cn_estimate = particles.cardinalities[bi];
+}
+
+// ---------------------------------------------------------------------------------------------
+// rng.h: seedable portable generator (xoshiro256** seeded by splitmix64; Box-Muller normals)
+// ---------------------------------------------------------------------------------------------
+namespace {
+uint64_t rs[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0x2545F4914F6CDD1Dull};
+bool have_spare = false;
+double spare = 0;
+inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+uint64_t next_u64()
+{
+    const uint64_t result = rotl(rs[1] * 5, 7) * 9;
+    const uint64_t t = rs[1] << 17;
+    rs[2] ^= rs[0]; rs[3] ^= rs[1]; rs[1] ^= rs[2]; rs[0] ^= rs[3];
+    rs[2] ^= t;
+    rs[3] = rotl(rs[3], 45);
+    return result;
+}
+} // namespace
+
+extern "C" void phd_compat_seed_rng(uint64_t seed)
+{
+    for (int i = 0; i < 4; ++i) {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        rs[i] = z ^ (z >> 31);
+    }
+    have_spare = false;
+}
+
+extern "C" double randu01() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+
+extern "C" double randn()
+{
+    if (have_spare) { have_spare = false; return spare; }
+    double u1;
+    do { u1 = randu01(); } while (u1 <= 0.0);
+    const double u2 = randu01();
+    const double r = std::sqrt(-2.0 * std::log(u1));
+    spare = r * std::sin(6.283185307179586 * u2);
+    have_spare = true;
+    return r * std::cos(6.283185307179586 * u2);
+}

@@ -1,0 +1,183 @@
+"""The C++ host side on hardware: the run_synth-style driver (cuda-phdslam_amd/bin/phdslam, C-ABI with
+device-resident state) and the phdfilter.h-compatible adapter (libphdfilter_compat.so) must produce
+what the same sequence of C-ABI calls produces from Python, on a small synthetic data directory in the
+reference's file formats (config.cfg / measurements.txt / controls.txt -> state_estimate%05d.log)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cuda-phdslam_amd")
+
+
+def write_dataset(d, n_steps=6, n_particles=48, seed=5):
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    w = S.make_workload(1, 20, 12, seed=seed, n_meas_sets=n_steps)
+    with open(os.path.join(d, "measurements.txt"), "w") as f:
+        f.write("% range bearing pairs, one step per line\n")
+        for k in range(n_steps):
+            z = w["z"][k]
+            f.write(" ".join("%.6f %.6f" % (z["range"][i], z["bearing"][i]) for i in range(len(z))) + " \n")
+    with open(os.path.join(d, "controls.txt"), "w") as f:
+        f.write("% velocity\tsteering angle\n")
+        for k in range(n_steps):
+            f.write("%.5f %.6f\n" % (2.0 + 0.1 * k, 0.05 - 0.01 * k))
+    cfg = open(os.path.join(ROOT, "tests", "golden", "config_sample.cfg")).read()
+    cfg = cfg.replace("n_particles = 200", "n_particles = %d" % n_particles)
+    cfg = cfg.replace("resample_threshold = 0.5", "resample_threshold = 0.97")  # make the nEff trigger fire in a short run
+    cfg = cfg.replace("data_directory = /data/synth_bowtie/", "data_directory = %s/" % d)
+    with open(os.path.join(d, "config.cfg"), "w") as f:
+        f.write(cfg)
+    return os.path.join(d, "config.cfg")
+
+
+def parse_log(path):
+    lines = open(path).read().split("\n")
+    pose = np.array(lines[0].split(), float)
+    gmap = np.array(lines[1].split(), float).reshape(-1, 7)
+    lw = np.array(lines[2].split(), float)
+    poses = np.array(lines[3].split(), float).reshape(-1, 6)
+    return pose, gmap, lw, poses
+
+
+def test_driver_matches_python_host(tmp_path):
+    P = importlib.import_module("cuda-phdslam_amd")
+    d = str(tmp_path)
+    cfg_path = write_dataset(d)
+    out_c = os.path.join(d, "out_c"); os.makedirs(out_c)
+    r = subprocess.run([os.path.join(PKG, "bin", "phdslam"), cfg_path, "synth", "--out", out_c, "--seed", "9",
+                        "--capacity", "256"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the same run from Python: same RNG (the adapter's randn/randu01), same C-ABI calls
+    rng = C.CDLL(os.path.join(PKG, "libphdfilter_compat.so"))
+    rng.randn.restype = C.c_double
+    rng.randu01.restype = C.c_double
+    rng.phd_compat_seed_rng(C.c_uint64(9))
+    cfg, ddir, _ = P.load_config(cfg_path)
+    Z = P.load_measurements(os.path.join(ddir, "measurements.txt"))
+    U = P.load_controls(os.path.join(ddir, "controls.txt"))
+    N = cfg.n_particles
+    resampled = 0
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=256, max_measurements=max(len(z) for z in Z)) as f:
+        for n in range(len(Z)):
+            if n > 0:
+                noise = np.zeros((N, 2), np.float32)
+                for i in range(N):
+                    noise[i, 0] = cfg.stdAlpha * rng.randn()
+                    noise[i, 1] = cfg.stdEncoder * rng.randn()
+                f.predict((U["v_encoder"][n - 1], U["alpha"][n - 1]), noise)
+            f.update(Z[n])
+            e = f.expected_pose()
+            m, who = f.map_estimate()
+            poses, lw = f.get_particles()
+            pose_c, map_c, lw_c, poses_c = parse_log(os.path.join(out_c, "state_estimate%05d.log" % n))
+            # the log has 6 significant digits (default operator<< formatting)
+            assert np.allclose(pose_c[:3], [e["px"], e["py"], e["ptheta"]], rtol=2e-5, atol=1e-6), n
+            assert len(map_c) == len(m), n
+            assert np.allclose(map_c[:, 0], m["weight"], rtol=2e-5) and np.allclose(map_c[:, 1:3], m["mean"], rtol=2e-5, atol=1e-6)
+            assert np.allclose(map_c[:, 3:], m["cov"], rtol=2e-5, atol=1e-9)
+            assert np.allclose(lw_c, lw, rtol=2e-5) and np.allclose(poses_c[:, :3], np.stack([poses["px"], poses["py"], poses["ptheta"]], 1), rtol=2e-5, atol=1e-6)
+            did, _ = f.resample_if_needed(rng.randu01(), had_measurements=len(Z[n]) > 0)
+            resampled += int(did)
+    assert os.path.exists(os.path.join(out_c, "loopTime.log"))
+    assert resampled >= 1  # the trigger fired at least once, so the resampled state was compared too
+
+
+def test_phdfilter_h_adapter(tmp_path):
+    """phdPredict / phdUpdateSynth / resampleParticles / recoverSlamState of the adapter, called from a
+    small C++ program written against the reference-style header, equal the Python host's results."""
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    src = tmp_path / "adapter_test.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "phdfilter_compat.h"
+int main(int argc, char** argv) {
+    char ddir[1024]; int32_t ns;
+    if (phd_config_load(argv[1], &config, ddir, sizeof(ddir), &ns)) { printf("cfg: %s\n", phd_last_error()); return 1; }
+    phd_compat_seed_rng(3);
+    setDeviceConfig(config);
+    initRandomNumberGenerators();
+    const int N = config.n_particles;
+    SynthSLAM particles(N);
+    for (int i = 0; i < N; ++i) {
+        particles.states[i] = ConstantVelocityState{0.01f * i, -0.02f * i, 0.001f * i, 0, 0, 0};
+        particles.weights[i] = -2.7725887f; // -log(16)
+        for (int g = 0; g < 5; ++g) {
+            Gaussian2D f; f.cov[0] = 0.04f; f.cov[1] = f.cov[2] = 0.001f * g; f.cov[3] = 0.09f;
+            f.mean[0] = 2.0f + 1.5f * g; f.mean[1] = -3.0f + 1.1f * g; f.weight = 0.5f + 0.1f * g;
+            particles.maps_static[i].push_back(f);
+        }
+    }
+    AckermanControl u; u.alpha = 0.05f; u.v_encoder = 2.0f;
+    phdPredict(particles, u);
+    measurementSet Z;
+    for (int m = 0; m < 6; ++m) { RangeBearingMeasurement z; z.range = 3.0f + m; z.bearing = -1.0f + 0.4f * m; z.label = 0; Z.push_back(z); }
+    SynthSLAM pre = phdUpdateSynth(particles, Z);
+    ConstantVelocityState e; std::vector<REAL> cn;
+    recoverSlamState(particles, e, cn);
+    printf("pre %zu %.9g\n", pre.maps_static[0].size(), pre.weights[0]);
+    printf("pose %.9g %.9g %.9g\n", e.px, e.py, e.ptheta);
+    printf("neff %.9g\n", computeNeff(particles));
+    for (int i = 0; i < N; ++i) printf("p %d %.9g %zu %.9g\n", i, particles.weights[i], particles.maps_static[i].size(), particles.maps_static[i].size() ? particles.maps_static[i][0].weight : 0.f);
+    SynthSLAM rs = resampleParticles(particles, N);
+    for (int i = 0; i < N; ++i) printf("r %d %d\n", i, rs.resample_idx[i]);
+    return 0;
+}
+''')
+    exe = tmp_path / "adapter_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "csrc", "compat"), "-Wno-varargs", str(src), "-o", str(exe),
+                           "-L" + PKG, "-lphdfilter_compat", "-lphdslam", "-Wl,-rpath," + PKG])
+    d = str(tmp_path)
+    cfg_path = write_dataset(d, n_particles=16)
+    r = subprocess.run([str(exe), cfg_path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.split("\n")
+    # the same sequence from Python
+    rng = C.CDLL(os.path.join(PKG, "libphdfilter_compat.so"))
+    rng.randn.restype = C.c_double
+    rng.randu01.restype = C.c_double
+    rng.phd_compat_seed_rng(C.c_uint64(3))
+    cfg, _, _ = P.load_config(cfg_path)
+    N = 16
+    poses = np.zeros(N, P.POSE)
+    poses["px"] = np.float32(0.01) * np.arange(N, dtype=np.float32)
+    poses["py"] = np.float32(-0.02) * np.arange(N, dtype=np.float32)
+    poses["ptheta"] = np.float32(0.001) * np.arange(N, dtype=np.float32)
+    g = np.zeros(5, P.GAUSSIAN)
+    for k in range(5):
+        g[k]["cov"] = [0.04, np.float32(0.001) * np.float32(k), np.float32(0.001) * np.float32(k), 0.09]
+        g[k]["mean"] = [2.0 + np.float32(1.5) * k, -3.0 + np.float32(1.1) * k]
+        g[k]["weight"] = np.float32(0.5) + np.float32(0.1) * np.float32(k)
+    z = np.zeros(6, P.MEAS)
+    z["range"] = 3.0 + np.arange(6)
+    z["bearing"] = np.float32(-1.0) + np.float32(0.4) * np.arange(6, dtype=np.float32)
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=256) as f:
+        f.set_particles(poses, np.full(N, -2.7725887, np.float32))
+        f.set_maps([g] * N)
+        noise = np.zeros((N, 2), np.float32)
+        for i in range(N):
+            noise[i, 0] = cfg.stdAlpha * rng.randn()
+            noise[i, 1] = cfg.stdEncoder * rng.randn()
+        f.predict((2.0, 0.05), noise)
+        f.update(z)
+        e = f.expected_pose()
+        _, lw = f.get_particles()
+        maps = f.get_maps()
+        ne = f.neff()
+        idx = f.resample(rng.randu01())
+    assert out[0].split()[1] == "5"
+    assert np.allclose([float(v) for v in out[1].split()[1:]], [e["px"], e["py"], e["ptheta"]], rtol=1e-6, atol=1e-7)
+    assert abs(float(out[2].split()[1]) - ne) < 1e-6
+    for i in range(N):
+        t = out[3 + i].split()
+        assert abs(float(t[2]) - lw[i]) <= 1e-6 * abs(lw[i]) and int(t[3]) == len(maps[i])
+        assert abs(float(t[4]) - maps[i]["weight"][0]) <= 1e-6 * maps[i]["weight"][0]
+        assert int(out[3 + N + i].split()[2]) == idx[i]
