@@ -84,6 +84,7 @@ struct WeightArgs {
     const int* parent_in;
     int* parent_out;
     int n_weight_norm;
+    unsigned long long* wstamps; // [8] phase stamps (diagnostics) or NULL
 };
 
 size_t update_lds_bytes(int S, int C, int MM);

@@ -44,6 +44,9 @@ namespace phd {
                             // when a CU holds a single particle; throughput-neutral at 4096 particles)
 #endif
 #define PHD_T (64 * PHD_NW)
+#ifndef PHD_MIN_WAVES
+#define PHD_MIN_WAVES 4      // launch bound: waves per SIMD the register allocation must allow
+#endif
 #define PHD_COLS (64 / PHD_NW) // window columns (= candidate seeds) owned by one wave
 #define NEAR_U_BASE 0x40000000
 // phase stamps of the diagnostic instantiation (100 MHz s_memrealtime), thread 0 of each workgroup
@@ -230,7 +233,7 @@ typedef LDS_T(unsigned char)* lds_u8;
 struct LdsOffsets {
     u32 w, mx, my, xx, xy, yy, tr, u;
     u32 alias;      // start of the aliased region
-    u32 out_idx, z_r, z_b, logZ, zpart, zok, part, win, red, ctr;
+    u32 out_idx, z_r, z_b, logZ, zpart, zok, bgeo, part, win, red, ctr;
     u32 total;
 };
 
@@ -256,6 +259,7 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.logZ = p; p += align16u(4u * (u32)MM);
     o.zpart = p; p += align16u(4u * PHD_NW * (u32)MM);
     o.zok = p; p += align16u(4u * (u32)MM);
+    o.bgeo = p; p += align16u(20u * (u32)MM);
     o.part = p; p += 4u * PHD_NW * 64u;
     o.win = p; p += 4u * 7u * 64u;
     o.red = p; p += align16u(4u * (PHD_NW + 4));
@@ -280,6 +284,7 @@ struct Lds {
     lds_u16 out_idx;                  // C
     lds_f32 z_r, z_b, logZ, zpart;    // MM, MM, MM, 4*MM
     lds_u32 zok;                      // MM
+    lds_f32 bgeo;                     // 5*MM: birth mean and covariance per measurement
     lds_u32 part;                     // 4*64 row parts of the window closeness matrix
     lds_f32 win;                      // 7*64: the window's candidates (pos, mx, my, tr, xx, xy, yy)
     lds_f32 red;                      // PHD_NW + 4
@@ -306,6 +311,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.out_idx = (lds_u16)(base + o.out_idx);
     L.z_r = (lds_f32)(base + o.z_r); L.z_b = (lds_f32)(base + o.z_b); L.logZ = (lds_f32)(base + o.logZ);
     L.zpart = (lds_f32)(base + o.zpart); L.zok = (lds_u32)(base + o.zok);
+    L.bgeo = (lds_f32)(base + o.bgeo);
     L.part = (lds_u32)(base + o.part);
     L.win = (lds_f32)(base + o.win);
     L.red = (lds_f32)(base + o.red);
@@ -440,7 +446,7 @@ __device__ __forceinline__ void reg_sort_asc32(u32 (&key)[E], int n, int tid, ld
                     const int i = tid * E + e;
                     const u32 oth = __shfl_xor(key[e], lm);
                     const bool want_min = (((i & k) == 0) == ((i & j) == 0));
-                    if (want_min ? (oth < key[e]) : (oth > key[e])) key[e] = oth;
+                    key[e] = want_min ? min(key[e], oth) : max(key[e], oth);
                 }
             } else {
 #pragma unroll
@@ -462,19 +468,94 @@ __device__ __forceinline__ void reg_sort_asc32(u32 (&key)[E], int n, int tid, ld
     }
 }
 
-// sort 1 of the merge: survivors by (weight desc, slab index asc), then permute the SoA arrays into
-// that order (in place, staged through registers) and clear the assignment array.
+// keys-only variant of reg_sort_desc64 (the payload rides in the low 16 bits of the key)
 template <int E>
-__device__ __forceinline__ void sort_survivors(const Lds& L, int S, int n_pad, int tid)
+__device__ __forceinline__ void reg_sort_desc64k(u32 (&khi)[E], u32 (&klo)[E], int n, int tid, lds_u32 xhi, lds_u32 xlo)
+{
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E * 64) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    if (i < n) { xhi[i] = khi[e]; xlo[i] = klo[e]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    if (i < n) {
+                        const int l = i ^ j;
+                        const u64 mine = ((u64)khi[e] << 32) | klo[e];
+                        const u64 oth = ((u64)xhi[l] << 32) | xlo[l];
+                        const bool want_max = (((i & k) == 0) == ((i & j) == 0));
+                        const u64 r = want_max ? (oth > mine ? oth : mine) : (oth < mine ? oth : mine);
+                        khi[e] = (u32)(r >> 32); klo[e] = (u32)r;
+                    }
+                }
+                __syncthreads();
+            } else if (j >= E) {
+                const int lm = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const u32 ohi = __shfl_xor(khi[e], lm), olo = __shfl_xor(klo[e], lm);
+                    const u64 mine = ((u64)khi[e] << 32) | klo[e];
+                    const u64 oth = ((u64)ohi << 32) | olo;
+                    const bool want_max = (((i & k) == 0) == ((i & j) == 0));
+                    const u64 r = want_max ? (oth > mine ? oth : mine) : (oth < mine ? oth : mine);
+                    khi[e] = (u32)(r >> 32); klo[e] = (u32)r;
+                }
+            } else {
+#pragma unroll
+                for (int jj = E / 2; jj > 0; jj >>= 1) {
+                    if (j == jj) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            if ((e & jj) == 0) {
+                                const int i = tid * E + e;
+                                const u64 a = ((u64)khi[e] << 32) | klo[e];
+                                const u64 b = ((u64)khi[e | jj] << 32) | klo[e | jj];
+                                const bool desc = ((i & k) == 0);
+                                const u64 hi = a > b ? a : b, lo = a > b ? b : a;
+                                const u64 first = desc ? hi : lo, second = desc ? lo : hi;
+                                khi[e] = (u32)(first >> 32); klo[e] = (u32)first;
+                                khi[e | jj] = (u32)(second >> 32); klo[e | jj] = (u32)second;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// sort 1 of the merge: survivors by (weight desc, slab index asc), then permute the SoA arrays into
+// that order (in place, staged through registers) and clear the assignment array.  The slab index of a
+// nearly-in-range feature is n_update + its map index.  When every slab index fits 16 bits the key is
+// (weight | ~slab index | slot) in 64 bits and nothing but the key is sorted.
+template <int E>
+__device__ __forceinline__ void sort_survivors(const Lds& L, int S, int n_pad, int tid, int n_update, bool packed)
 {
     u32 khi[E], klo[E], pay[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = tid * E + e;
-        if (i < S) { khi[e] = orderable(L.w[i]); klo[e] = 0xFFFFFFFFu - (u32)L.u[i]; pay[e] = (u32)i; }
-        else { khi[e] = 0; klo[e] = 0; pay[e] = 0; }
+        if (i < S) {
+            const int u0 = L.u[i];
+            const u32 u = (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
+            khi[e] = orderable(L.w[i]);
+            klo[e] = packed ? (((0xFFFFu - u) << 16) | (u32)i) : (0xFFFFFFFFu - u);
+            pay[e] = (u32)i;
+        } else { khi[e] = 0; klo[e] = 0; pay[e] = 0; }
     }
-    reg_sort_desc64<E>(khi, klo, pay, n_pad, tid, L.khi, L.klo, L.pay);
+    if (packed) {
+        reg_sort_desc64k<E>(khi, klo, n_pad, tid, L.khi, L.klo);
+#pragma unroll
+        for (int e = 0; e < E; ++e) pay[e] = klo[e] & 0xFFFFu;
+    } else {
+        reg_sort_desc64<E>(khi, klo, pay, n_pad, tid, L.khi, L.klo, L.pay);
+    }
     float rw[E], rmx[E], rmy[E], rxx[E], rxy[E], ryy[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -500,14 +581,20 @@ __device__ __forceinline__ void sort_survivors(const Lds& L, int S, int n_pad, i
     __syncthreads();
 }
 
-// small mixtures (S <= 256): rank by counting instead of a sorting network — every thread reads all
-// keys (LDS broadcast reads, independent, no barriers), rank = number of keys that sort before its own
-__device__ __forceinline__ void rank_sort_survivors(const Lds& L, int S, int tid)
+// small mixtures (S <= workgroup size): rank by counting instead of a sorting network — every thread
+// reads all keys (LDS broadcast reads, independent, no barriers inside); a survivor's rank is the
+// number of keys that sort before its own
+__device__ __forceinline__ void rank_sort_survivors(const Lds& L, int S, int tid, int n_update)
 {
     u32 mh = 0, ml = 0;
-    if (tid < S) { mh = orderable(L.w[tid]); ml = 0xFFFFFFFFu - (u32)L.u[tid]; L.khi[tid] = mh; L.klo[tid] = ml; }
     float rw = 0, rmx = 0, rmy = 0, rxx = 0, rxy = 0, ryy = 0;
-    if (tid < S) { rw = L.w[tid]; rmx = L.mx[tid]; rmy = L.my[tid]; rxx = L.xx[tid]; rxy = L.xy[tid]; ryy = L.yy[tid]; }
+    if (tid < S) {
+        const int u0 = L.u[tid];
+        mh = orderable(L.w[tid]);
+        ml = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
+        L.khi[tid] = mh; L.klo[tid] = ml;
+        rw = L.w[tid]; rmx = L.mx[tid]; rmy = L.my[tid]; rxx = L.xx[tid]; rxy = L.xy[tid]; ryy = L.yy[tid];
+    }
     __syncthreads();
     if (tid < S) {
         const u64 mine = ((u64)mh << 32) | ml;
@@ -552,7 +639,7 @@ __device__ __forceinline__ void sort_assignments(const Lds& L, int S, int n_pad,
         key[e] = (i < S) ? (((u32)L.u[i] << 16) | (u32)i) : 0xFFFFFFFFu;
     }
     reg_sort_asc32<E>(key, n_pad, tid, L.key2);
-    __syncthreads(); // L.key2 aliases nothing that is still read, but waves may lag in the last exchange
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = tid * E + e;
@@ -601,7 +688,7 @@ __device__ __forceinline__ bool is_close(float smx, float smy, float sxx, float 
 // ------------------------------------------------------------------------------------------
 template <bool HELLINGER, bool STAMPS>
 __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv, const DevConfig& cfg, float* __restrict__ out_slab,
-                             int cap, int tid, u64* st)
+                             int cap, int tid, u64* st, int n_update, bool packed)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const float T = cfg.minSeparation;
@@ -614,10 +701,10 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
     int n_pad = 2;
     while (n_pad < S) n_pad <<= 1;
-    if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid);
-    else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid);
-    else if (n_pad <= 4 * PHD_T) sort_survivors<4>(L, S, n_pad, tid);
-    else sort_survivors<8>(L, S, n_pad, tid);
+    if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid, n_update);
+    else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid, n_update, packed);
+    else if (n_pad <= 4 * PHD_T) sort_survivors<4>(L, S, n_pad, tid, n_update, packed);
+    else sort_survivors<8>(L, S, n_pad, tid, n_update, packed);
     STAMP(6);
 
     // ---- rounds: 64 live candidates at a time ---------------------------------------------------
@@ -934,7 +1021,7 @@ __device__ __forceinline__ phd_pose predict_pose(const phd_pose& o, phd_ackerman
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
 template <bool STAMPS>
-__global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
+__global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const Lds L = lds_carve((lds_u8)lds_raw, A.S_cap, A.cap, A.MM);
@@ -970,6 +1057,25 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         L.zok[m] = (z.label == 0 || !cfg.labeledMeasurements) ? 1u : 0u; // :1913
     }
     __syncthreads();
+
+    // ---- birth geometry (host loop src/phdfilter.cu:3470-3506): depends only on the pose and the
+    //      measurement, so the top lanes of the workgroup — idle while the low lanes classify the map —
+    //      compute it now; the birth weights follow once the normalisers are known
+    for (int m = PHD_T - 1 - tid; m < M; m += PHD_T) {
+        const float zr = L.z_r[m];
+        const float theta = pose.ptheta + L.z_b[m];
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        const float dx = zr * cs, dy = zr * sn;
+        const float J0 = dx / zr, J1 = dy / zr, J2 = -dy, J3 = dx;
+        const float sr = cfg.stdRange * cfg.birthNoiseFactor, sb = cfg.stdBearing * cfg.birthNoiseFactor;
+        const float vr = sr * sr, vb = sb * sb;
+        L.bgeo[0 * A.MM + m] = pose.px + dx;
+        L.bgeo[1 * A.MM + m] = pose.py + dy;
+        L.bgeo[2 * A.MM + m] = J0 * J0 * vr + J2 * J2 * vb;
+        L.bgeo[3 * A.MM + m] = J0 * J1 * vr + J2 * J3 * vb;
+        L.bgeo[4 * A.MM + m] = J1 * J1 * vr + J3 * J3 * vb;
+    }
 
     // ---- classification + per-feature EKF terms -----------------------------------------------
     float pdw_local = 0.f; // sum_j pd_j w_j (cardinality_predict, :2160)
@@ -1073,6 +1179,12 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
         const float lz = safe_log(sum);                                                               // :2217
         L.logZ[m] = lz;
         lz_local += lz;                                                                               // :2251
+        // the birth term of this measurement (weight :2239-2243, prune :2314) while lz is in a register
+        const float wb = L.zok[m] ? expf(safe_log(cfg.birthWeight) - lz) : 0.f;
+        const bool keep = !(wb < cfg.minFeatureWeight);
+        const int slot = alloc_slots(keep, L.ctr);
+        if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
+                                 L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m);
     }
     {
         const float lz_sum = block_sum(lz_local, L.red, tid);
@@ -1137,33 +1249,6 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
             L.xx[s] = oxx; L.xy[s] = oxy; L.yy[s] = oyy;
         }
     }
-    // births (host loop src/phdfilter.cu:3470-3506; weight :2239-2243)
-    for (int m0 = 0; m0 < M; m0 += PHD_T) {
-        const int m = m0 + tid;
-        bool keep = false;
-        float w = 0, bmx = 0, bmy = 0, bxx = 0, bxy = 0, byy = 0;
-        if (m < M) {
-            w = L.zok[m] ? expf(safe_log(cfg.birthWeight) - L.logZ[m]) : 0.f;
-            keep = !(w < cfg.minFeatureWeight);
-            if (keep) {
-                const float zr = L.z_r[m];
-                const float theta = pose.ptheta + L.z_b[m];
-                float sn, cs;
-                sincosf(theta, &sn, &cs);
-                const float dx = zr * cs, dy = zr * sn;
-                bmx = pose.px + dx;
-                bmy = pose.py + dy;
-                const float J0 = dx / zr, J1 = dy / zr, J2 = -dy, J3 = dx;
-                const float sr = cfg.stdRange * cfg.birthNoiseFactor, sb = cfg.stdBearing * cfg.birthNoiseFactor;
-                const float vr = sr * sr, vb = sb * sb;
-                bxx = J0 * J0 * vr + J2 * J2 * vb;
-                bxy = J0 * J1 * vr + J2 * J3 * vb;
-                byy = J1 * J1 * vr + J3 * J3 * vb;
-            }
-        }
-        const int slot = alloc_slots(keep, L.ctr);
-        if (keep) store_survivor(L, slot, S_cap, w, bmx, bmy, bxx, bxy, byy, n_in + M * n_in + m);
-    }
     __syncthreads();
     STAMP(5);
     int n_surv = L.ctr[CTR_NSURV];
@@ -1185,8 +1270,10 @@ __global__ __launch_bounds__(PHD_T) void phd_update_merge_kernel(UpdateArgs A)
     __syncthreads();
 
     // ---- merge ----------------------------------------------------------------------------------------
-    if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st);
-    else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st);
+    const int n_update = n_in * (M + 1) + M;
+    const bool packed = (n_update + n_map <= 0xFFFF) && (S_cap <= 0x10000);
+    if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed);
+    else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed);
     int k_out = L.ctr[CTR_KOUT];
     if (k_out > cap) { k_out = cap; status |= PHD_STATUS_MAP_OVERFLOW; }
     // append the untouched out-of-range features (src/phdfilter.cu:3311-3318)
@@ -1252,6 +1339,52 @@ __device__ __forceinline__ double det_exp(float xf)
     return ldexp(p, (int)kd);
 }
 
+// ------------------------------------------------------------------------------------------
+// Fixed-point resampling CDF (definition and rationale: oracle/scphd_cpu.c, o_resample):
+//   sb = 62 - ceil(log2 N);  q_i = floor(min(det_exp(w_i), 1) * 2^sb);  Q_i = q_0 + ... + q_i (exact)
+//   the reference's "r_j > c_i"  <=>  Q_i < T_j = ceil(r_j * 2^sb)
+// Integer sums are associative: the parallel scan below, the oracle's sequential loop and every rank
+// of a multi-GPU run produce the same Q, hence the same indices.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cdf_scale_bits(int n)
+{
+    int b = 0;
+    while ((1ll << b) < n) ++b;
+    return 62 - b;
+}
+__device__ __forceinline__ u64 cdf_quantise(double p, double scale) { return (u64)floor((p > 1.0 ? 1.0 : p) * scale); }
+
+// in-place inclusive scan of q[0..m) (u64, LDS) by a workgroup of BT threads, plus `carry`; returns
+// the total (carry included).  Thread t owns the contiguous entries [t*per, (t+1)*per).
+template <int BT>
+__device__ __forceinline__ u64 block_scan_u64(u64* q, int m, u64 carry, u64* s_wtot, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (m + BT - 1) / BT;
+    const int lo = tid * per, hi = (lo + per < m) ? lo + per : m;
+    u64 local = 0;
+    for (int e = lo; e < hi; ++e) local += q[e];
+    u64 incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    u64 woff = carry, total = carry;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) {
+        const u64 c = s_wtot[w];
+        if (w < wave) woff += c;
+        total += c;
+    }
+    u64 run = woff + incl - local;
+    for (int e = lo; e < hi; ++e) { run += q[e]; q[e] = run; }
+    __syncthreads();
+    return total;
+}
+
 #define PHD_CDF_CHUNK 2048
 
 template <int PHD_WT>
@@ -1280,7 +1413,7 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     __shared__ int s_flag;
     __shared__ int s_argmax;
     __shared__ double s_chunk[PHD_CDF_CHUNK];
-    __shared__ double s_carry;
+    __shared__ u64 s_wtot[PHD_WT / 64];
     __shared__ double s_bestv[PHD_WT / 64];
     __shared__ int s_besti[PHD_WT / 64];
     const int tid = threadIdx.x;
@@ -1335,43 +1468,26 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     }
     // 4. resample (src/main.cpp:453-501).  Thresholds: HEAD's expression r_j = j*interval + u_j*interval
     //    (:468); with a single uniform (systematic, as src/phdfilter.cu.bak:3279-3327) u_j = u_0.
-    //    CDF: p_i = det_exp(w_i), accumulated SEQUENTIALLY in double in index order (:463,495) by one
-    //    lane — parallel scans round differently and would break bit-exactness across ranks/CPU.
-    double* cdf = A.cdf;   // [n] global scratch
+    //    CDF in fixed point (see cdf_quantise): chunks of 2048 scanned in LDS, spilled to A.cdf (as u64).
+    u64* cdf = (u64*)A.cdf;   // [n] global scratch
+    u64* qch = (u64*)s_chunk;
     const double interval = 1.0 / n_new;
+    const int sb = cdf_scale_bits(n);
+    const double scale = ldexp(1.0, sb);
     double best = -1.0;
     int besti = 0x7FFFFFFF;
+    u64 carry = 0;
     for (int c0 = 0; c0 < n; c0 += PHD_CDF_CHUNK) {
         const int m = (n - c0 < PHD_CDF_CHUNK) ? (n - c0) : PHD_CDF_CHUNK;
         for (int i = tid; i < m; i += PHD_WT) {
             const double e = det_exp(logw[c0 + i]);
-            s_chunk[i] = e;
+            qch[i] = cdf_quantise(e, scale);
             if (e > best) { best = e; besti = c0 + i; } // strided ascending: keeps the lowest index per lane
         }
         __syncthreads();
-        if (tid == 0) {
-            double c = (c0 == 0) ? 0.0 : s_carry;
-            int i = 0;
-            for (; i + 8 <= m; i += 8) {
-                const double e0 = s_chunk[i], e1 = s_chunk[i + 1], e2 = s_chunk[i + 2], e3 = s_chunk[i + 3];
-                const double e4 = s_chunk[i + 4], e5 = s_chunk[i + 5], e6 = s_chunk[i + 6], e7 = s_chunk[i + 7];
-                c += e0; s_chunk[i] = c;
-                c += e1; s_chunk[i + 1] = c;
-                c += e2; s_chunk[i + 2] = c;
-                c += e3; s_chunk[i + 3] = c;
-                c += e4; s_chunk[i + 4] = c;
-                c += e5; s_chunk[i + 5] = c;
-                c += e6; s_chunk[i + 6] = c;
-                c += e7; s_chunk[i + 7] = c;
-            }
-            for (; i < m; ++i) { c += s_chunk[i]; s_chunk[i] = c; }
-            s_carry = c;
-        }
+        carry = block_scan_u64<PHD_WT>(qch, m, carry, s_wtot, tid);
+        for (int i = tid; i < m; i += PHD_WT) cdf[c0 + i] = qch[i];
         __syncthreads();
-        if (n > PHD_CDF_CHUNK) {
-            for (int i = tid; i < m; i += PHD_WT) cdf[c0 + i] = s_chunk[i];
-            __syncthreads();
-        }
     }
     // arg-max of p (first maximum, strict '>'), used by the overflow guard (:475-494)
     {
@@ -1390,21 +1506,20 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
         }
         __syncthreads();
     }
-    const bool in_lds = (n <= PHD_CDF_CHUNK);
-    const double ctot = s_carry;
+    const u64 ctot = carry;
     for (int j = tid; j < n_new; j += PHD_WT) {
         const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
         const double r = j * interval + u * interval;                                                  // :468
+        const u64 T = (u64)ceil(r * scale);
         int idx;
-        if (r > ctot) {
+        if (T > ctot) {
             idx = s_argmax;                                                                            // :475-494
         } else {
-            // smallest i with !(r > cdf[i])  ==  where the reference's "while (r > c) i++" stops
+            // smallest i with Q_i >= T  ==  where the reference's "while (r > c) i++" stops
             int lo = 0, hi = n - 1;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                const double cm = in_lds ? s_chunk[mid] : cdf[mid];
-                if (r > cm) lo = mid + 1; else hi = mid;
+                if (cdf[mid] < T) lo = mid + 1; else hi = mid;
             }
             idx = lo;
         }
@@ -1436,11 +1551,13 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
     __shared__ float sc[BT / 64];
     __shared__ int s_flag;
     __shared__ int s_argmax;
-    __shared__ double s_chunk[PHD_CDF_CHUNK];
+    __shared__ u64 s_wtot[BT / 64];
     __shared__ double s_bestv[BT / 64];
     __shared__ int s_besti[BT / 64];
     const int tid = threadIdx.x;
     const int n = A.n;
+#define WSTAMP(k) do { if (A.wstamps && tid == 0) A.wstamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    WSTAMP(0);
     float w[R];
     // 1. load + accumulate (src/phdfilter.cu:3741-3744)
 #pragma unroll
@@ -1467,6 +1584,7 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
 #pragma unroll
         for (int r = 0; r < R; ++r) w[r] -= lse;
     }
+    WSTAMP(1);
     // 3. nEff (src/main.cpp:1281-1284)
     float s2 = 0.f;
 #pragma unroll
@@ -1490,7 +1608,13 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         }
         return;
     }
-    // 4. resample: p_i = det_exp(w_i); sequential double CDF by one lane (src/main.cpp:463,495)
+    // 4. resample: p_i = det_exp(w_i) -> fixed-point CDF (see cdf_quantise) scanned in LDS by the
+    //    whole workgroup; thresholds r_j = j*interval + u*interval (src/main.cpp:468)
+    WSTAMP(2);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    u64* Q = (u64*)s_dyn; // [n]
+    const int sb = cdf_scale_bits(n);
+    const double scale = ldexp(1.0, sb);
     double best = -1.0;
     int besti = 0x7FFFFFFF;
 #pragma unroll
@@ -1498,37 +1622,21 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         const int i = tid + r * BT;
         if (i < n) {
             const double e = det_exp(w[r]);
-            s_chunk[i] = e;
+            Q[i] = cdf_quantise(e, scale);
             if (e > best) { best = e; besti = i; }
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        double c = 0.0;
-        int i = 0;
-        for (; i + 8 <= n; i += 8) {
-            const double e0 = s_chunk[i], e1 = s_chunk[i + 1], e2 = s_chunk[i + 2], e3 = s_chunk[i + 3];
-            const double e4 = s_chunk[i + 4], e5 = s_chunk[i + 5], e6 = s_chunk[i + 6], e7 = s_chunk[i + 7];
-            c += e0; s_chunk[i] = c;
-            c += e1; s_chunk[i + 1] = c;
-            c += e2; s_chunk[i + 2] = c;
-            c += e3; s_chunk[i + 3] = c;
-            c += e4; s_chunk[i + 4] = c;
-            c += e5; s_chunk[i + 5] = c;
-            c += e6; s_chunk[i + 6] = c;
-            c += e7; s_chunk[i + 7] = c;
-        }
-        for (; i < n; ++i) { c += s_chunk[i]; s_chunk[i] = c; }
-    }
-    __syncthreads();
-    const double ctot = s_chunk[n - 1];
+    WSTAMP(3);
+    const u64 ctot = block_scan_u64<BT>(Q, n, 0ull, s_wtot, tid);
+    WSTAMP(4);
     const double interval = 1.0 / n_new;
     // the overflow guard (src/main.cpp:475-494) needs the arg-max of p only if the last threshold
     // exceeds the total mass (weights that do not sum to one): thresholds increase with j
     {
         const int jl = n_new - 1;
         const double ul = (A.n_uniforms == 1) ? A.u0 : A.uniforms[jl];
-        const bool overflow = (jl * interval + ul * interval) > ctot;
+        const bool overflow = (u64)ceil((jl * interval + ul * interval) * scale) > ctot;
         if (overflow) { // uniform
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1546,18 +1654,20 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
             __syncthreads();
         }
     }
+    WSTAMP(5);
     const float nlw = (float)(-log((double)A.n_weight_norm));
     for (int j = tid; j < n_new; j += BT) {
         const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
         const double r = j * interval + u * interval;                                                  // :468
+        const u64 T = (u64)ceil(r * scale);
         int idx;
-        if (r > ctot) {
+        if (T > ctot) {
             idx = s_argmax;
         } else {
             int lo = 0, hi = n - 1;
-            while (lo < hi) {
+            while (lo < hi) { // smallest i with Q_i >= T
                 const int mid = (lo + hi) >> 1;
-                if (r > s_chunk[mid]) lo = mid + 1; else hi = mid;
+                if (Q[mid] < T) lo = mid + 1; else hi = mid;
             }
             idx = lo;
         }
@@ -1573,6 +1683,7 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         const int i = tid + r * BT;
         if (i < n) A.logw[i] = (A.mode & W_COMMIT) ? nlw : w[r];
     }
+    WSTAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1753,8 +1864,17 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
     // one workgroup; small particle sets use a small one (cheaper barriers, same results: the
     // reductions are fixed trees per block size)
     // (the commit of the small kernel writes logw[j] for j < n: it needs n_new <= n, true for every caller)
-    if (a.n <= 512 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), 0, st, a);
-    else if (a.n <= 2048 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 8>), dim3(1), dim3(256), 0, st, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t dyn = (size_t)a.n * 8; // the fixed-point CDF, one u64 per particle
+    if (a.n <= 512 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, a);
+    else if (a.n <= 2048 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 8>), dim3(1), dim3(256), dyn, st, a);
+    else if (a.n <= 16384 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, a);
     else if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(phd_weights_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();

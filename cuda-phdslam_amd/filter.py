@@ -195,9 +195,10 @@ class PhdFilter:
 
     def stamps(self):
         """phase stamps of the last update (after debug(2)): [n, 16] ticks of 10 ns"""
-        out = np.zeros((self.n, 16), np.uint64)
+        out = np.zeros(self.n * 16 + 8, np.uint64)
         check(lib().phd_debug_get_stamps(self._h, ptr(out)), "phd_debug_get_stamps")
-        return out
+        self.weight_stamps = out[self.n * 16:]     # phases of the weights/resample kernel
+        return out[:self.n * 16].reshape(self.n, 16)
 
     def survivors(self, particle):
         """pruned update components (+ nearly-in-range features) of one particle in slab order"""

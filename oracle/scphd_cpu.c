@@ -560,18 +560,38 @@ float o_neff(const float* logw, int n)
     return nEff;
 }
 
+/*
+ * Resampling (src/main.cpp:453-501; systematic: src/phdfilter.cu.bak:3279-3327).
+ *
+ * The reference walks a CDF accumulated in double, "c += exp(w_i)" (:463,495), against thresholds
+ * r_j = j*interval + u_j*interval (:468).  A floating-point running sum depends on the order of
+ * the additions, so no parallel implementation can reproduce it bit for bit, and its libm exp()
+ * is platform specific.  The CDF here is the same quantity in FIXED POINT:
+ *     sb  = 62 - ceil(log2 N)                       (so that the total fits 63 bits)
+ *     q_i = floor(min(det_exp(w_i), 1) * 2^sb)      (exact: power-of-two scaling, then floor)
+ *     Q_i = q_0 + ... + q_i                         (exact integer sum: associative)
+ *     "r_j > c_i"  <=>  Q_i < T_j,  T_j = ceil(r_j * 2^sb)
+ * Resolution N*2^-62 of the total mass, a few hundred times finer than the rounding noise of the
+ * reference's own double sum (N*2^-53).  Every implementation — sequential, parallel scan, any
+ * rank — gets the same indices.  Weights above exp(0) are clamped (normalised weights never are).
+ */
+static int o_ceil_log2(int n) { int b = 0; while ((1LL << b) < n) b++; return b; }
+
 void o_resample(const float* logw, int n, const double* uniforms, int n_uniforms, int n_new, int32_t* idx)
 {
+    const int sb = 62 - o_ceil_log2(n);
+    const double scale = ldexp(1.0, sb);
     double interval = 1.0 / n_new;                                       /* src/main.cpp:461 */
-    double r = uniforms[0] * interval;                                   /* :462 */
-    double c = o_det_exp(logw[0]);                                       /* :463 */
+    double p0 = o_det_exp(logw[0]);
+    uint64_t c = (uint64_t)floor((p0 > 1.0 ? 1.0 : p0) * scale);          /* :463 */
     int i = 0;
+    int overflowed = 0;
     for (int j = 0; j < n_new; j++) {
-        /* :468 "r = j*interval + randu01()*interval".  The RNG draw is an input here: one uniform
-         * per stratum (stratified, HEAD) or the same uniform for every j (n_uniforms == 1:
-         * systematic, the scheme of src/phdfilter.cu.bak:3279-3327 written in HEAD's expression) */
-        r = j * interval + uniforms[n_uniforms == 1 ? 0 : j] * interval;
-        while (r > c) {                                                  /* :469 */
+        /* :468 "r = j*interval + randu01()*interval": one uniform per stratum (stratified, HEAD) or the
+         * same uniform for every j (n_uniforms == 1: systematic) */
+        double r = j * interval + uniforms[n_uniforms == 1 ? 0 : j] * interval;
+        uint64_t T = (uint64_t)ceil(r * scale);
+        while (!overflowed && c < T) {                                   /* :469  r > c */
             i++;
             if (i >= n || i < 0) {                                       /* :475-490 */
                 double max_weight = -1;
@@ -581,13 +601,13 @@ void o_resample(const float* logw, int n, const double* uniforms, int n_uniforms
                     if (e > max_weight) { max_weight = e; max_idx = k; }
                 }
                 i = max_idx;
-                c = 2;
+                overflowed = 1;                                          /* ":492 c = 2": never enter again */
                 break;
             }
-            c += o_det_exp(logw[i]);                                     /* :495 */
+            double p = o_det_exp(logw[i]);
+            c += (uint64_t)floor((p > 1.0 ? 1.0 : p) * scale);            /* :495 */
         }
         idx[j] = i;
-        r += interval;                                                   /* :497 (dead store, as in HEAD) */
     }
 }
 

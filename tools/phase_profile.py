@@ -16,8 +16,15 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
         f.debug(2)
         for _ in range(3):
             f.update(w["z"][0])
+        import torch
+        dz = torch.from_numpy(w["z"][0].view(np.uint8).copy()).cuda(); dn = torch.from_numpy(w["noise"][0].copy()).cuda()
+        torch.cuda.synchronize()
+        f.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, 0.37, True)
         f.sync()
         st = f.stamps().astype(np.int64)
+        ws = f.weight_stamps.astype(np.int64)
+        print("   weights kernel phases (us): load+normalise %.2f, neff %.2f, det_exp %.2f, scan %.2f, guard %.2f, search+commit %.2f"
+              % tuple(np.diff(ws[:7]) * 0.01))
         d = np.diff(st[:, :12], axis=1) * 0.01  # us
         tot = (st[:, 11] - st[:, 0]) * 0.01
         span = (st[:, 11].max() - st[:, 0].min()) * 0.01
