@@ -138,7 +138,7 @@ def main():
             f.predict_dev(control, d_noise.data_ptr())
             shard.update_local_dev(d_z.data_ptr(), M)
             allw = sf.gather_logweights()
-            sf.normalize(allw)
+            sf.normalize(allw, want_neff=False)     # the bench forces the resample: no host round trip for nEff
             sf.resample(u)
 
     def sync():

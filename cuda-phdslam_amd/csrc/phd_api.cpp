@@ -94,6 +94,8 @@ struct phd_filter {
     int* max_surv = nullptr;
     int* max_map = nullptr;
     int* d_tmp_int = nullptr; // n entries (selection / slot lists)
+    unsigned* ticket = nullptr; // arrival counter of the fused step (zero between launches)
+    bool fuse_enabled = true;
     // staging for AoS <-> SoA
     phd_gaussian2d* d_concat = nullptr;
     size_t concat_cap = 0;
@@ -217,6 +219,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
     A(dalloc(&f->status, 1)); A(dalloc(&f->max_surv, 1)); A(dalloc(&f->max_map, 1));
     A(dalloc(&f->d_tmp_int, f->n));
+    A(dalloc(&f->ticket, 1));
     A(dalloc(&f->d_offsets, f->n + 1)); A(dalloc(&f->d_sizes, std::max(f->n, f->n_global)));
     if (e != hipSuccess) {
         phd_destroy(f);
@@ -227,6 +230,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     hipMemsetAsync(f->counts[0], 0, f->n * sizeof(int), f->stream);
     hipMemsetAsync(f->counts[1], 0, f->n * sizeof(int), f->stream);
     hipMemsetAsync(f->status, 0, 4, f->stream);
+    hipMemsetAsync(f->ticket, 0, 4, f->stream);
     hipMemsetAsync(f->max_surv, 0, 4, f->stream);
     hipMemsetAsync(f->max_map, 0, 4, f->stream);
     for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n, f->stream);
@@ -255,7 +259,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->logw); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
     hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
-    hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int);
+    hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
@@ -556,7 +560,16 @@ struct FusedPredict {
     const phd_ackerman_noise* d_noise;
 };
 
-static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, const FusedPredict* fp = nullptr)
+struct FusedWeights {
+    int mode;
+    double u0;
+};
+static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0,
+                              WeightArgs& w, int& free_pose);
+static void commit_weights(phd_filter* f, int mode, int free_pose);
+
+static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, const FusedPredict* fp = nullptr,
+                           const FusedWeights* fw = nullptr)
 {
     UpdateArgs a;
     memset(&a, 0, sizeof(a));
@@ -600,6 +613,12 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     a.max_surv = f->max_surv;
     a.max_map = f->max_map;
     a.cfg = f->dcfg;
+    int free_pose = 0;
+    if (fw) {
+        build_weight_args(f, fw->mode, nullptr, 1, fw->u0, a.wa, free_pose);
+        a.fuse_weights = 1;
+        a.ticket = f->ticket;
+    }
     t_begin(f, PHD_K_UPDATE_MERGE);
     HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream));
     t_end(f);
@@ -608,13 +627,16 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         f->cur ^= 1;
         f->parent_dirty = false;
     }
+    if (fw) commit_weights(f, fw->mode, free_pose);
     return PHD_OK;
 }
 
 // weights kernel on the local shard
-static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0 = 0.0)
+// arguments of the weights / nEff / resample routine on the local shard; free_pose = the pose
+// buffer the commit gathers into
+static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0,
+                              WeightArgs& w, int& free_pose)
 {
-    WeightArgs w;
     memset(&w, 0, sizeof(w));
     w.logw_in = f->logw;
     w.logw = f->frozen ? f->logw_scratch : f->logw;
@@ -632,7 +654,7 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
     w.neff_out = f->neff;
     w.did_resample = f->did;
     const phd_pose* pin = f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur];
-    int free_pose = 0;
+    free_pose = 0;
     while (f->pose[free_pose] == pin || free_pose == f->pose_cur) free_pose++;
     w.pose_in = pin;
     w.pose_out = f->pose[free_pose];
@@ -640,16 +662,36 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
     w.parent_out = f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1];
     w.n_weight_norm = f->n_global;
     if (f->want_stamps && f->stamps) w.wstamps = f->stamps + (size_t)f->n * 16;
-    t_begin(f, PHD_K_WEIGHTS);
-    HIPCHK(launch_weights(w, f->stream));
-    t_end(f);
+}
+
+static void commit_weights(phd_filter* f, int mode, int free_pose)
+{
     if ((mode & WM_COMMIT) && !f->frozen) {
         f->pose_cur = free_pose;
         f->pcur ^= 1;
         f->parent_dirty = true; // conservatively: parents may be non-identity now
     }
     f->pose_for_update = nullptr;
+}
+
+static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0 = 0.0)
+{
+    WeightArgs w;
+    int free_pose = 0;
+    build_weight_args(f, mode, d_uniforms, n_uniforms, u0, w, free_pose);
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights(w, f->stream));
+    t_end(f);
+    commit_weights(f, mode, free_pose);
     return PHD_OK;
+}
+
+// update + prune + merge with the weights routine fused into the kernel's tail (the last workgroup
+// to finish runs it): one launch per step.  Used for small particle counts, where the second
+// launch's fixed cost is a measurable share of the step.
+static bool can_fuse(const phd_filter* f)
+{
+    return f->fuse_enabled && !f->want_stamps && f->n <= update_fuse_max_particles() && (size_t)f->n * 8 <= f->lds_bytes;
 }
 
 extern "C" int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_meas)
@@ -657,6 +699,10 @@ extern "C" int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_m
     CHECK_F(f);
     if (n_meas <= 0) return PHD_OK; // the reference skips the update when Z is empty (src/main.cpp:1260)
     int M = std::min(n_meas, f->MM); // reference clamps to 256 (src/phdfilter.cu:3390-3394)
+    if (can_fuse(f)) {
+        FusedWeights fw = {WM_ACCUMULATE | WM_NORMALIZE, 0.0};
+        return do_update_merge(f, d_z, M, nullptr, &fw);
+    }
     int rc = do_update_merge(f, d_z, M);
     if (rc) return rc;
     return do_weights(f, WM_ACCUMULATE | WM_NORMALIZE, nullptr, 1);
@@ -727,6 +773,11 @@ extern "C" int phd_step_dev(phd_filter* f, phd_ackerman_control u, const phd_ack
         if (rc) return rc;
     } else {
         FusedPredict fp = {u, d_noise};
+        mode |= WM_ACCUMULATE | WM_NORMALIZE | WM_HAD_MEAS;
+        if (can_fuse(f)) {
+            FusedWeights fw = {mode, uniform};
+            return do_update_merge(f, d_z, M, &fp, &fw);
+        }
         rc = do_update_merge(f, d_z, M, &fp);
         if (rc) return rc;
         mode |= WM_ACCUMULATE | WM_NORMALIZE | WM_HAD_MEAS;
@@ -888,18 +939,13 @@ extern "C" int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int
 extern "C" int phd_finish_resample(phd_filter* f)
 {
     CHECK_F(f);
-    if (f->frozen) { // bench protocol: the exchange ran, the snapshot stays
-        HIPCHK(hipStreamSynchronize(f->stream));
-        return PHD_OK;
-    }
+    if (f->frozen) return PHD_OK; // bench protocol: the exchange ran, the snapshot stays
     f->cur ^= 1;
     f->pose_cur = (f->pose_cur + 1) % 3;
     HIPCHK(launch_iota(f->parent[f->pcur], f->n, f->stream));
     f->parent_dirty = false;
-    std::vector<float> w(f->n, (float)(-log((double)f->n_global))); // src/slamtypes.h:327
-    HIPCHK(hipMemcpyAsync(f->logw, w.data(), f->n * sizeof(float), hipMemcpyHostToDevice, f->stream));
-    HIPCHK(hipStreamSynchronize(f->stream));
-    return PHD_OK;
+    HIPCHK(launch_fill(f->logw, (float)(-log((double)f->n_global)), f->n, f->stream)); // src/slamtypes.h:327
+    return PHD_OK; // stream-ordered: no host synchronisation
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,6 +30,31 @@ enum { PHD_STATUS_MAP_OVERFLOW = 1u, PHD_STATUS_SURVIVOR_OVERFLOW = 2u };
 
 // Map slab layout in HBM: particle-major, then 6 SoA planes of `cap` floats:
 //   slab(p) = base + p*6*cap ; planes: 0 weight, 1 mean x, 2 mean y, 3 cov xx, 4 cov xy, 5 cov yy
+struct WeightArgs {
+    const float* logw_in;       // [n]
+    float* logw;                // [n] working/out vector (== logw_in unless frozen)
+    const float* dlogw;         // [n]
+    float* raw_out;             // [n] optional: un-normalised accumulated weights
+    int n;
+    int n_new;
+    int mode;
+    float resample_thresh;
+    const double* uniforms;     // device, n_uniforms entries (stratified); unused when n_uniforms == 1
+    double u0;                  // the single uniform of systematic resampling (n_uniforms == 1)
+    int n_uniforms;
+    double* cdf;                // [n] scratch (used when n > 2048)
+    int* idx_out;               // [n_new]
+    float* neff_out;            // [1]
+    int* did_resample;          // [1]
+    // commit (copy_particles)
+    const phd_pose* pose_in;
+    phd_pose* pose_out;
+    const int* parent_in;
+    int* parent_out;
+    int n_weight_norm;
+    unsigned long long* wstamps; // [8] phase stamps (diagnostics) or NULL
+};
+
 struct UpdateArgs {
     const float* map_in;
     const int* count_in;
@@ -56,38 +81,18 @@ struct UpdateArgs {
     const phd_ackerman_noise* noise; // NULL: draw from (seed, counter)
     phd_pose* pose_out;
     unsigned long long seed, counter;
+    // fused weights / resample tail (small particle counts): run by the last workgroup to finish
+    int fuse_weights;
+    unsigned* ticket;
+    WeightArgs wa;
     unsigned* status;
     int* max_surv;
     int* max_map;
     DevConfig cfg;
 };
 
-struct WeightArgs {
-    const float* logw_in;       // [n]
-    float* logw;                // [n] working/out vector (== logw_in unless frozen)
-    const float* dlogw;         // [n]
-    float* raw_out;             // [n] optional: un-normalised accumulated weights
-    int n;
-    int n_new;
-    int mode;
-    float resample_thresh;
-    const double* uniforms;     // device, n_uniforms entries (stratified); unused when n_uniforms == 1
-    double u0;                  // the single uniform of systematic resampling (n_uniforms == 1)
-    int n_uniforms;
-    double* cdf;                // [n] scratch (used when n > 2048)
-    int* idx_out;               // [n_new]
-    float* neff_out;            // [1]
-    int* did_resample;          // [1]
-    // commit (copy_particles)
-    const phd_pose* pose_in;
-    phd_pose* pose_out;
-    const int* parent_in;
-    int* parent_out;
-    int n_weight_norm;
-    unsigned long long* wstamps; // [8] phase stamps (diagnostics) or NULL
-};
-
 size_t update_lds_bytes(int S, int C, int MM);
+int update_fuse_max_particles();
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
 hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman_control u,
@@ -108,6 +113,7 @@ hipError_t launch_gather_maps(const float* src, const int* counts_src, const int
                               int* counts_dst, const phd_pose* pose_src, phd_pose* pose_dst, int cap, int n,
                               hipStream_t st);
 hipError_t launch_iota(int* a, int n, hipStream_t st);
+hipError_t launch_fill(float* a, float v, int n, hipStream_t st);
 
 // weight-kernel mode bits (mirrors the enum in phd_kernels.hip)
 enum { WM_ACCUMULATE = 1, WM_NORMALIZE = 2, WM_RESAMPLE_FORCE = 4, WM_RESAMPLE_AUTO = 8, WM_HAD_MEAS = 16, WM_COMMIT = 32 };

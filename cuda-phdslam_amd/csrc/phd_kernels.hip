@@ -320,6 +320,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
 }
 
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total; }
+int update_fuse_max_particles() { return PHD_T * 2; } // weights_body<PHD_T, 2> of the fused step
 
 enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */ };
 
@@ -1017,10 +1018,14 @@ __device__ __forceinline__ phd_pose predict_pose(const phd_pose& o, phd_ackerman
     return nw;
 }
 
+// (defined further down) the weights / nEff / resample routine, run by the last workgroup of a fused step
+template <int BT, int R, bool HANDOFF>
+__device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn);
+
 // ------------------------------------------------------------------------------------------
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
-template <bool STAMPS>
+template <bool STAMPS, bool FUSEW>
 __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1042,7 +1047,19 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         if (A.noise) { n_alpha = A.noise[p].n_alpha; n_encoder = A.noise[p].n_encoder; }
         else draw_noise(A.seed, A.counter, p, cfg, n_alpha, n_encoder);
         pose = predict_pose(pose, A.control, n_alpha, n_encoder, cfg);
-        if (tid == 0) A.pose_out[p] = pose;
+        if (tid == 0) {
+            if (FUSEW) { // handed to the last workgroup: agent-scope (sc1) stores
+                float* po = (float*)&A.pose_out[p];
+                __hip_atomic_store(po + 0, pose.px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 1, pose.py, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 2, pose.ptheta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 3, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 4, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 5, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                A.pose_out[p] = pose;
+            }
+        }
     }
     u64* st = STAMPS ? (A.stamps + (size_t)p * 16) : nullptr;
     if (STAMPS && tid == 0) { st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0; }
@@ -1190,7 +1207,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const float lz_sum = block_sum(lz_local, L.red, tid);
         const float pdw = block_sum(pdw_local, L.red, tid);
         // particle_weighting == 0 (:2260-2263): sum_m log Z_m - (sum_j pd_j w_j + M * birthWeight)
-        if (tid == 0) A.dlogw[p] = lz_sum - (pdw + (float)M * cfg.birthWeight);
+        if (tid == 0) {
+            const float dl = lz_sum - (pdw + (float)M * cfg.birthWeight);
+            if (FUSEW) __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else A.dlogw[p] = dl;
+        }
     }
     __syncthreads();
 
@@ -1285,13 +1306,32 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         for (int pl = 0; pl < 6; ++pl) out[pl * cap + k_out + i] = in[pl * cap + s];
     }
     if (tid == 0) {
-        if (A.parent_reset) A.parent_reset[p] = p; // the output slab of particle p is its own again
+        if (A.parent_reset) { // the output slab of particle p is its own again
+            if (FUSEW) __hip_atomic_store(&A.parent_reset[p], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else A.parent_reset[p] = p;
+        }
         A.count_out[p] = k_out + n_app;
         if (status) atomicOr(A.status, status);
         atomicMax(A.max_surv, L.ctr[CTR_NSURV]);
         atomicMax(A.max_map, k_out + n_out0);
     }
     STAMP(11);
+    if (FUSEW) {
+        // ---- fused tail: the workgroup that finishes last runs the weights / nEff / resample routine.
+        // Hand-off (cdna guide, Guideline 16): lane 0 of every workgroup made its hand-off stores
+        // (dlogw, predicted pose, parent reset) agent-scope, drains them, then takes a ticket with an
+        // agent-scope atomic; the workgroup whose ticket is the last one reads them with sc1 loads.
+        lds_i32 flag = L.ctr + CTR_TMP;
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == gridDim.x - 1);
+            *flag = last;
+            if (last) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+        }
+        __syncthreads();
+        if (*flag) weights_body<PHD_T, 2, true>(A.wa, lds_raw);
+    }
 }
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
@@ -1545,8 +1585,31 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
 // write.  n <= PHD_CDF_CHUNK.  Results are a pure function of (inputs, BT): every rank of a
 // multi-GPU run launches the same instantiation on the same gathered vector.
 // ------------------------------------------------------------------------------------------
-template <int BT, int R>
-__global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
+// hand-off loads (fused step): data written by OTHER workgroups of the same launch is read with
+// agent-scope (sc1) loads, which bypass this CU's L1 (cdna guide, Guideline 16)
+template <bool HANDOFF>
+__device__ __forceinline__ float ld_f32(const float* p)
+{
+    return HANDOFF ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool HANDOFF>
+__device__ __forceinline__ int ld_i32(const int* p)
+{
+    return HANDOFF ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool HANDOFF>
+__device__ __forceinline__ phd_pose ld_pose(const phd_pose* p)
+{
+    if (!HANDOFF) return *p;
+    const float* f = (const float*)p;
+    phd_pose o;
+    o.px = ld_f32<true>(f + 0); o.py = ld_f32<true>(f + 1); o.ptheta = ld_f32<true>(f + 2);
+    o.vx = ld_f32<true>(f + 3); o.vy = ld_f32<true>(f + 4); o.vtheta = ld_f32<true>(f + 5);
+    return o;
+}
+
+template <int BT, int R, bool HANDOFF>
+__device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn)
 {
     __shared__ float sc[BT / 64];
     __shared__ int s_flag;
@@ -1566,7 +1629,7 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         w[r] = -FLT_MAX;
         if (i < n) {
             w[r] = A.logw_in[i];
-            if (A.mode & W_ACCUMULATE) w[r] += A.dlogw[i];
+            if (A.mode & W_ACCUMULATE) w[r] += ld_f32<HANDOFF>(&A.dlogw[i]);
             if (A.raw_out) A.raw_out[i] = w[r];
         }
     }
@@ -1604,14 +1667,13 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         }
         for (int j = tid; j < n_new; j += BT) {
             A.idx_out[j] = j;                                                                          // :1292-1296
-            if (A.mode & W_COMMIT) { A.pose_out[j] = A.pose_in[j]; A.parent_out[j] = A.parent_in[j]; }
+            if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
         }
         return;
     }
     // 4. resample: p_i = det_exp(w_i) -> fixed-point CDF (see cdf_quantise) scanned in LDS by the
     //    whole workgroup; thresholds r_j = j*interval + u*interval (src/main.cpp:468)
     WSTAMP(2);
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     u64* Q = (u64*)s_dyn; // [n]
     const int sb = cdf_scale_bits(n);
     const double scale = ldexp(1.0, sb);
@@ -1673,8 +1735,8 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         }
         A.idx_out[j] = idx;
         if (A.mode & W_COMMIT) { // copy_particles (src/slamtypes.h:313-333)
-            A.pose_out[j] = A.pose_in[idx];
-            A.parent_out[j] = A.parent_in[idx];
+            A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[idx]);
+            A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[idx]);
         }
     }
     // weights: -log(N) after a committed resample (slamtypes.h:327), else the normalised values
@@ -1684,6 +1746,13 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
         if (i < n) A.logw[i] = (A.mode & W_COMMIT) ? nlw : w[r];
     }
     WSTAMP(6);
+}
+
+template <int BT, int R>
+__global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_wdyn[];
+    weights_body<BT, R, false>(A, s_wdyn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1824,6 +1893,12 @@ __global__ void phd_gather_maps_kernel(const float* __restrict__ src, const int*
     if (pose_dst && threadIdx.x < 6) ((float*)&pose_dst[p])[threadIdx.x] = ((const float*)&pose_src[q])[threadIdx.x];
 }
 
+__global__ void phd_fill_kernel(float* a, float v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
 __global__ void phd_iota_kernel(int* a, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1837,16 +1912,21 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)phd_update_merge_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)phd_update_merge_kernel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
+        const void* fns[3] = {(const void*)phd_update_merge_kernel<false, false>, (const void*)phd_update_merge_kernel<true, false>,
+                              (const void*)phd_update_merge_kernel<false, true>};
+        for (int k = 0; k < 3; ++k) {
+            hipFuncAttributes fa;
+            hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
-    if (a.stamps) hipLaunchKernelGGL(phd_update_merge_kernel<true>, dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else hipLaunchKernelGGL(phd_update_merge_kernel<false>, dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else hipLaunchKernelGGL((phd_update_merge_kernel<false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     return hipGetLastError();
 }
 
@@ -1925,6 +2005,12 @@ hipError_t launch_gather_maps(const float* src, const int* counts_src, const int
 {
     hipLaunchKernelGGL(phd_gather_maps_kernel, dim3(n), dim3(256), 0, st, src, counts_src, parent, sel, dst, counts_dst,
                        pose_src, pose_dst, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float* a, float v, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(phd_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, v, n);
     return hipGetLastError();
 }
 

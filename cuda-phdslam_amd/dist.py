@@ -86,9 +86,10 @@ class ShardedFilter:
         dist.all_gather_into_tensor(allw, raw.contiguous(), group=self.group)
         return allw
 
-    def normalize(self, all_logw):
-        """-> nEff of the global particle set; the shard's normalised weights are adopted"""
-        return self.b.global_normalize(all_logw)
+    def normalize(self, all_logw, want_neff=True):
+        """-> nEff of the global particle set (None if not wanted: saves a host synchronisation);
+        the shard's normalised weights are adopted"""
+        return self.b.global_normalize(all_logw, want_neff)
 
     def resample(self, uniform):
         """global systematic resample + migration.  Returns the global parent indices."""
@@ -173,13 +174,13 @@ class GpuShard:
     def update_local_dev(self, d_z, n_meas):
         self._check(self._lib().phd_update_local_dev(self.f._h, self._ptr(d_z), int(n_meas)), "phd_update_local_dev")
 
-    def global_normalize(self, all_logw):
+    def global_normalize(self, all_logw, want_neff=True):
         self._all = all_logw
         self._torch_to_filter()
         ne = self._C.c_float(0)
         self._check(self._lib().phd_global_normalize(self.f._h, self._ptr(all_logw.data_ptr()), self.n_global,
-                                                     self._C.byref(ne)), "phd_global_normalize")
-        return ne.value
+                                                     self._C.byref(ne) if want_neff else None), "phd_global_normalize")
+        return ne.value if want_neff else None
 
     def global_resample_indices(self, uniform):
         u = np.ascontiguousarray(np.atleast_1d(uniform), np.float64)

@@ -32,7 +32,7 @@ class NumpyShard:
     def raw_logweights(self):
         return torch.from_numpy(self.raw.copy())
 
-    def global_normalize(self, all_logw):
+    def global_normalize(self, all_logw, want_neff=True):
         a = O.normalize_weights(all_logw.numpy())
         self._all = a
         return O.neff(a)
