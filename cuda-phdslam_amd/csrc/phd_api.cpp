@@ -63,7 +63,10 @@ struct TimedEvent {
 struct phd_filter {
     phd_slam_config cfg;
     DevConfig dcfg;
-    int n = 0, cap = 0, MM = 0, S_cap = 0, device = 0;
+    int n = 0; // CURRENT particle count (n_base normally; grows by n_predict_particles per predict)
+    int n_base = 0, n_max = 0;
+    float* logw_alt = nullptr; // second log-weight buffer (shotgun predict writes out of place)
+    int cap = 0, MM = 0, S_cap = 0, device = 0;
     int n_global = 0, global_offset = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -144,7 +147,7 @@ static int check_supported(const phd_slam_config& c)
     if (c.motionType != 1) return fail(PHD_ERR_UNSUPPORTED, "motion_type != 1 (Ackerman) is not supported");
     if (c.filterType != 0) return fail(PHD_ERR_UNSUPPORTED, "filter_type != 0 (CPHD) is not supported in this build");
     if (c.distanceMetric != 0 && c.distanceMetric != 1) return fail(PHD_ERR_INVALID_ARG, "distance_metric must be 0 or 1");
-    if (c.nPredictParticles > 1) return fail(PHD_ERR_UNSUPPORTED, "n_predict_particles > 1 is not supported in this build");
+    if (c.nPredictParticles < 1) return fail(PHD_ERR_INVALID_ARG, "n_predict_particles must be >= 1");
     return PHD_OK;
 }
 
@@ -180,6 +183,10 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     fill_devcfg(*cfg, f->dcfg);
     f->device = o.device;
     f->n = o.n_particles > 0 ? o.n_particles : cfg->n_particles;
+    f->n_base = f->n;
+    // particle "shotgun" (n_predict_particles = k > 1, src/phdfilter.cu:1185-1238): every predict multiplies
+    // the count by k until it exceeds 5*n_particles and the resample trigger of src/main.cpp:1286 fires
+    f->n_max = cfg->nPredictParticles > 1 ? 5 * f->n * cfg->nPredictParticles : f->n;
     f->cap = o.map_capacity > 0 ? o.map_capacity : 256;
     f->MM = o.max_measurements > 0 ? std::min(o.max_measurements, PHD_MAX_MEASUREMENTS) : PHD_MAX_MEASUREMENTS;
     f->n_global = o.global_particles > 0 ? o.global_particles : f->n;
@@ -204,36 +211,36 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         }
         f->own_stream = true;
     }
-    const size_t slab = (size_t)f->n * 6 * f->cap;
+    const size_t slab = (size_t)f->n_max * 6 * f->cap;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
-    for (int k = 0; k < 2; ++k) { A(dalloc(&f->maps[k], slab)); A(dalloc(&f->counts[k], f->n)); }
-    for (int k = 0; k < 3; ++k) { A(dalloc(&f->parent[k], f->n)); A(dalloc(&f->pose[k], f->n)); }
-    A(dalloc(&f->logw, f->n)); A(dalloc(&f->logw_scratch, std::max(f->n, f->n_global)));
-    A(dalloc(&f->logw_raw, f->n)); A(dalloc(&f->dlogw, f->n));
-    A(dalloc(&f->d_z, f->MM)); A(dalloc(&f->d_noise, f->n));
-    A(dalloc(&f->d_uniforms, std::max(f->n, f->n_global)));
-    A(dalloc(&f->cdf, std::max(f->n, f->n_global)));
-    A(dalloc(&f->idx, std::max(f->n, f->n_global)));
+    for (int k = 0; k < 2; ++k) { A(dalloc(&f->maps[k], slab)); A(dalloc(&f->counts[k], f->n_max)); }
+    for (int k = 0; k < 3; ++k) { A(dalloc(&f->parent[k], f->n_max)); A(dalloc(&f->pose[k], f->n_max)); }
+    A(dalloc(&f->logw, f->n_max)); A(dalloc(&f->logw_alt, f->n_max)); A(dalloc(&f->logw_scratch, std::max(f->n_max, f->n_global)));
+    A(dalloc(&f->logw_raw, f->n_max)); A(dalloc(&f->dlogw, f->n_max));
+    A(dalloc(&f->d_z, f->MM)); A(dalloc(&f->d_noise, f->n_max));
+    A(dalloc(&f->d_uniforms, std::max(f->n_max, f->n_global)));
+    A(dalloc(&f->cdf, std::max(f->n_max, f->n_global)));
+    A(dalloc(&f->idx, std::max(f->n_max, f->n_global)));
     A(dalloc(&f->neff, 1)); A(dalloc(&f->did, 1));
     A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
     A(dalloc(&f->status, 1)); A(dalloc(&f->max_surv, 1)); A(dalloc(&f->max_map, 1));
-    A(dalloc(&f->d_tmp_int, f->n));
+    A(dalloc(&f->d_tmp_int, f->n_max));
     A(dalloc(&f->ticket, 1));
-    A(dalloc(&f->d_offsets, f->n + 1)); A(dalloc(&f->d_sizes, std::max(f->n, f->n_global)));
+    A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
     if (e != hipSuccess) {
         phd_destroy(f);
         return fail(PHD_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(e));
     }
     hipMemsetAsync(f->maps[0], 0, slab * sizeof(float), f->stream);
     hipMemsetAsync(f->maps[1], 0, slab * sizeof(float), f->stream);
-    hipMemsetAsync(f->counts[0], 0, f->n * sizeof(int), f->stream);
-    hipMemsetAsync(f->counts[1], 0, f->n * sizeof(int), f->stream);
+    hipMemsetAsync(f->counts[0], 0, f->n_max * sizeof(int), f->stream);
+    hipMemsetAsync(f->counts[1], 0, f->n_max * sizeof(int), f->stream);
     hipMemsetAsync(f->status, 0, 4, f->stream);
     hipMemsetAsync(f->ticket, 0, 4, f->stream);
     hipMemsetAsync(f->max_surv, 0, 4, f->stream);
     hipMemsetAsync(f->max_map, 0, 4, f->stream);
-    for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n, f->stream);
+    for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n_max, f->stream);
     // initial particles: cfg pose, weights -log N (src/main.cpp:1130-1145)
     std::vector<phd_pose> p0(f->n);
     std::vector<float> w0(f->n, -logf((float)f->n_global));
@@ -256,7 +263,7 @@ extern "C" int phd_destroy(phd_filter* f)
     for (auto& ev : f->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (int k = 0; k < 2; ++k) { hipFree(f->maps[k]); hipFree(f->counts[k]); }
     for (int k = 0; k < 3; ++k) { hipFree(f->parent[k]); hipFree(f->pose[k]); }
-    hipFree(f->logw); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
+    hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
     hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
     hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
@@ -433,8 +440,9 @@ extern "C" int phd_get_map_sizes(phd_filter* f, int32_t* sizes_out)
 {
     CHECK_F(f);
     if (!sizes_out) return fail(PHD_ERR_INVALID_ARG, "null output");
-    std::vector<int> cnt(f->n), par(f->n);
-    HIPCHK(hipMemcpyAsync(cnt.data(), f->counts[f->cur], f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    // a parent may be any slab written while the particle set was larger (shotgun): all n_max counts
+    std::vector<int> cnt(f->n_max), par(f->n);
+    HIPCHK(hipMemcpyAsync(cnt.data(), f->counts[f->cur], f->n_max * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(par.data(), f->parent[f->pcur], f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
     for (int p = 0; p < f->n; ++p) sizes_out[p] = cnt[par[p]];
@@ -519,6 +527,27 @@ extern "C" int phd_get_map(phd_filter* f, int particle, phd_gaussian2d* out, int
 // ---------------------------------------------------------------------------------------------
 static int do_predict(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise)
 {
+    const int k = f->cfg.nPredictParticles;
+    if (k > 1) {
+        // shotgun: k predicted particles per prior particle (prior index = idx / k, src/phdfilter.cu:797);
+        // maps are shared through the parent indirection, weights lose log k (:1213)
+        if (f->frozen) return fail(PHD_ERR_UNSUPPORTED, "n_predict_particles > 1 is not supported while frozen");
+        if ((long long)f->n * k > f->n_max)
+            return fail(PHD_ERR_CAPACITY, "particle count would exceed 5*n_particles*n_predict_particles: resample first (src/main.cpp:1286)");
+        const int pnext = (f->pose_cur + 1) % 3;
+        t_begin(f, PHD_K_PREDICT);
+        HIPCHK(launch_predict_shotgun(f->pose[f->pose_cur], f->pose[pnext], f->n * k, k, u, d_noise, f->seed, f->counter,
+                                      f->dcfg, f->parent[f->pcur], f->parent[f->pcur ^ 1], f->logw, f->logw_alt, f->stream));
+        t_end(f);
+        f->counter++;
+        f->pose_cur = pnext;
+        f->pcur ^= 1;
+        std::swap(f->logw, f->logw_alt);
+        f->n *= k;
+        f->parent_dirty = true;
+        f->pose_for_update = nullptr;
+        return PHD_OK;
+    }
     const phd_pose* in = f->pose[f->pose_cur];
     phd_pose* out = f->frozen ? f->pose[(f->pose_cur + 1) % 3] : f->pose[f->pose_cur];
     t_begin(f, PHD_K_PREDICT);
@@ -539,7 +568,9 @@ extern "C" int phd_predict_ackerman(phd_filter* f, phd_ackerman_control u, const
 {
     CHECK_F(f);
     if (noise) {
-        HIPCHK(hipMemcpyAsync(f->d_noise, noise, f->n * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, f->stream));
+        const int k = f->cfg.nPredictParticles > 1 ? f->cfg.nPredictParticles : 1;
+        if ((long long)f->n * k > f->n_max) return fail(PHD_ERR_CAPACITY, "particle count would exceed its maximum: resample first");
+        HIPCHK(hipMemcpyAsync(f->d_noise, noise, (size_t)f->n * k * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, f->stream));
         return do_predict(f, u, f->d_noise);
     }
     return do_predict(f, u, nullptr);
@@ -548,10 +579,10 @@ extern "C" int phd_predict_ackerman(phd_filter* f, phd_ackerman_control u, const
 static int ensure_debug(phd_filter* f)
 {
     if (f->dbg_surv) return PHD_OK;
-    HIPCHK(dalloc(&f->dbg_surv, (size_t)f->n * 6 * f->S_cap));
-    HIPCHK(dalloc(&f->dbg_u, (size_t)f->n * f->S_cap));
-    HIPCHK(dalloc(&f->dbg_n, f->n));
-    HIPCHK(dalloc(&f->dbg_nin, f->n));
+    HIPCHK(dalloc(&f->dbg_surv, (size_t)f->n_max * 6 * f->S_cap));
+    HIPCHK(dalloc(&f->dbg_u, (size_t)f->n_max * f->S_cap));
+    HIPCHK(dalloc(&f->dbg_n, f->n_max));
+    HIPCHK(dalloc(&f->dbg_nin, f->n_max));
     return PHD_OK;
 }
 
@@ -604,8 +635,8 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     }
     if (f->want_stamps) {
         if (!f->stamps) {
-            HIPCHK(dalloc(&f->stamps, (size_t)f->n * 16 + 8));
-            HIPCHK(hipMemsetAsync(f->stamps, 0, ((size_t)f->n * 16 + 8) * 8, f->stream));
+            HIPCHK(dalloc(&f->stamps, (size_t)f->n_max * 16 + 8));
+            HIPCHK(hipMemsetAsync(f->stamps, 0, ((size_t)f->n_max * 16 + 8) * 8, f->stream));
         }
         a.stamps = f->stamps;
     }
@@ -643,7 +674,7 @@ static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms,
     w.dlogw = f->dlogw;
     w.raw_out = (mode & WM_NORMALIZE) ? nullptr : ((mode & WM_ACCUMULATE) ? f->logw_raw : nullptr);
     w.n = f->n;
-    w.n_new = f->n;
+    w.n_new = (f->n == f->n_base || f->n_global != f->n_base) ? f->n : f->n_base; // resample back to n_particles (src/main.cpp:1289)
     w.mode = mode;
     w.resample_thresh = f->cfg.resampleThresh;
     w.uniforms = d_uniforms ? d_uniforms : f->d_uniforms;
@@ -691,7 +722,8 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
 // launch's fixed cost is a measurable share of the step.
 static bool can_fuse(const phd_filter* f)
 {
-    return f->fuse_enabled && !f->want_stamps && f->n <= update_fuse_max_particles() && (size_t)f->n * 8 <= f->lds_bytes;
+    return f->fuse_enabled && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
+           (size_t)f->n * 8 <= f->lds_bytes;
 }
 
 extern "C" int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_meas)
@@ -736,14 +768,17 @@ extern "C" int phd_neff(phd_filter* f, float* neff_out)
 extern "C" int phd_resample(phd_filter* f, const double* uniforms, int n_uniforms, int32_t* idx_out)
 {
     CHECK_F(f);
-    if (!uniforms || (n_uniforms != 1 && n_uniforms != f->n))
+    // resampleParticles(particles, config.n_particles) (src/main.cpp:1289): back to the configured count
+    const int n_new = (f->n == f->n_base || f->n_global != f->n_base) ? f->n : f->n_base;
+    if (!uniforms || (n_uniforms != 1 && n_uniforms != n_new))
         return fail(PHD_ERR_INVALID_ARG, "phd_resample: n_uniforms must be 1 (systematic) or n_particles (stratified)");
     if (n_uniforms != 1)
         HIPCHK(hipMemcpyAsync(f->d_uniforms, uniforms, n_uniforms * sizeof(double), hipMemcpyHostToDevice, f->stream));
     int rc = do_weights(f, WM_RESAMPLE_FORCE | WM_COMMIT, f->d_uniforms, n_uniforms, uniforms[0]);
     if (rc) return rc;
+    if (!f->frozen) f->n = n_new;
     if (idx_out) {
-        HIPCHK(hipMemcpyAsync(idx_out, f->idx, f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipMemcpyAsync(idx_out, f->idx, n_new * sizeof(int), hipMemcpyDeviceToHost, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
     }
     return PHD_OK;
@@ -753,11 +788,25 @@ extern "C" int phd_resample_if_needed(phd_filter* f, double uniform, int had_mea
                                       int32_t* idx_out)
 {
     CHECK_F(f);
-    int rc = do_weights(f, WM_RESAMPLE_AUTO | WM_COMMIT | (had_measurements ? WM_HAD_MEAS : 0), nullptr, 1, uniform);
+    // trigger of src/main.cpp:1286: (nEff <= resample_threshold and the step had measurements), decided
+    // on the device, OR more than 5*n_particles particles (shotgun growth), decided here
+    const bool grown = f->n != f->n_base && f->n_global == f->n_base;
+    const bool force = grown && f->n > 5 * f->n_base;
+    const int n_before = f->n, n_new = grown ? f->n_base : f->n;
+    int rc = do_weights(f, (force ? WM_RESAMPLE_FORCE : WM_RESAMPLE_AUTO) | WM_COMMIT | (had_measurements ? WM_HAD_MEAS : 0),
+                        nullptr, 1, uniform);
     if (rc) return rc;
-    if (did_resample_out) HIPCHK(hipMemcpyAsync(did_resample_out, f->did, sizeof(int), hipMemcpyDeviceToHost, f->stream));
-    if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, f->idx, f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
-    if (did_resample_out || idx_out) HIPCHK(hipStreamSynchronize(f->stream));
+    int did = force ? 1 : 0;
+    if (did_resample_out || (grown && !force)) { // with a grown particle set the count depends on the decision
+        HIPCHK(hipMemcpyAsync(&did, f->did, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
+    if (did_resample_out) *did_resample_out = did;
+    if (grown && did && !f->frozen) f->n = n_new;
+    if (idx_out) {
+        HIPCHK(hipMemcpyAsync(idx_out, f->idx, (did ? n_new : n_before) * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
     return PHD_OK;
 }
 

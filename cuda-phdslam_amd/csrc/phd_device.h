@@ -98,6 +98,10 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
 hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman_control u,
                           const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,
                           hipStream_t st);
+hipError_t launch_predict_shotgun(const phd_pose* in, phd_pose* out, int n_pred, int k, phd_ackerman_control u,
+                                  const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,
+                                  const int* parent_in, int* parent_out, const float* logw_in, float* logw_out,
+                                  hipStream_t st);
 hipError_t launch_weights(const WeightArgs& a, hipStream_t st);
 hipError_t launch_pack_maps(const phd_gaussian2d* concat, const int* offsets, const int* sizes, float* slabs, int cap,
                             int n, hipStream_t st);

@@ -316,6 +316,54 @@ extern "C" int phd_load_controls(const char* path, int has_header, phd_ackerman_
     return PHD_OK;
 }
 
+// loadTimestamps (src/main.cpp:147-166): one value per line, NO header line, trailing blank dropped
+extern "C" int phd_load_timestamps(const char* path, float* out, size_t capacity, size_t* n_out)
+{
+    if (!path) return host_fail(PHD_ERR_INVALID_ARG, "null path");
+    std::ifstream f(path);
+    size_t n = 0;
+    if (f) { // a missing file means "no timestamps" (lock-step mode), like the reference
+        std::string line;
+        std::vector<double> nums;
+        while (std::getline(f, line)) {
+            if (trim(line).empty()) continue;
+            if (!numbers_of(line, nums) || nums.empty())
+                return host_fail(PHD_ERR_PARSE, std::string(path) + ": line " + std::to_string(n + 1) + ": expected a time stamp");
+            if (out && n < capacity) out[n] = (float)nums[0];
+            n++;
+        }
+    }
+    if (n_out) *n_out = n;
+    if (out && n > capacity) return host_fail(PHD_ERR_CAPACITY, "timestamp buffer too small");
+    return PHD_OK;
+}
+
+// loadTrajectory (src/main.cpp:242-260): "px py ptheta vx vy vtheta" per line, '%' lines skipped
+extern "C" int phd_load_trajectory(const char* path, phd_pose* out, size_t capacity, size_t* n_out)
+{
+    if (!path) return host_fail(PHD_ERR_INVALID_ARG, "null path");
+    std::ifstream f(path);
+    if (!f) return host_fail(PHD_ERR_IO, std::string("could not open trajectory file: ") + path);
+    std::string line;
+    std::vector<double> nums;
+    size_t n = 0;
+    while (std::getline(f, line)) {
+        std::string t = trim(line);
+        if (t.empty() || t[0] == '%') continue;
+        if (!numbers_of(line, nums) || nums.size() < 3)
+            return host_fail(PHD_ERR_PARSE, std::string(path) + ": pose " + std::to_string(n) + ": expected 'px py ptheta [vx vy vtheta]'");
+        if (out && n < capacity) {
+            phd_pose q = {(float)nums[0], (float)nums[1], (float)nums[2], 0, 0, 0};
+            if (nums.size() >= 6) { q.vx = (float)nums[3]; q.vy = (float)nums[4]; q.vtheta = (float)nums[5]; }
+            out[n] = q;
+        }
+        n++;
+    }
+    if (n_out) *n_out = n;
+    if (out && n > capacity) return host_fail(PHD_ERR_CAPACITY, "trajectory buffer too small");
+    return PHD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // state_estimate%05d.log — the 5-line consumer contract (README:31-39; python/batch_analyze.py:16-24;
 // python/plot_phdslam.py:205-226): default operator<< float formatting, space separated, trailing space
@@ -346,6 +394,46 @@ extern "C" int phd_write_state_log(const char* dir, int step, const phd_pose* e,
           << poses[n].vtheta << " ";
     s << std::endl;
     for (int n = 0; n < max_cardinality + 1; ++n) s << "0 "; // PHD: zeros (:942-949)
+    s << std::endl;
+    return s.good() ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name.str());
+}
+
+// HEAD's writeLog (src/main.cpp:848-954): 7 lines — pose / static map / dynamic map (empty: static
+// model) / log-weights / poses / resample indices / cardinality — opened in APPEND mode; at t = 0 the
+// weights and poses are repeated nPredictParticles times (:901-934).
+extern "C" int phd_write_state_log7(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                                    const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
+                                    int n_particles, int max_cardinality, int n_predict_particles)
+{
+    if (!e) return host_fail(PHD_ERR_INVALID_ARG, "null pose");
+    std::ostringstream name;
+    if (dir && dir[0]) {
+        name << dir;
+        if (name.str().back() != '/') name << '/';
+    }
+    name << "state_estimate" << std::setfill('0') << std::setw(5) << step << ".log";
+    std::ofstream s(name.str().c_str(), std::ios::out | std::ios::app);
+    if (!s) return host_fail(PHD_ERR_IO, "cannot write " + name.str());
+    s << e->px << " " << e->py << " " << e->ptheta << " " << e->vx << " " << e->vy << " " << e->vtheta << " " << std::endl;
+    for (int n = 0; n < n_map; ++n) {
+        s << map[n].weight << " ";
+        for (int i = 0; i < 2; ++i) s << map[n].mean[i] << " ";
+        for (int i = 0; i < 4; ++i) s << map[n].cov[i] << " ";
+    }
+    s << std::endl;
+    s << std::endl; // dynamic map: none in the static feature model
+    const int times = (step == 0 && n_predict_particles > 1) ? n_predict_particles : 1;
+    for (int k = 0; k < times; ++k)
+        for (int n = 0; n < n_particles; ++n) s << log_weights[n] << " ";
+    s << std::endl;
+    for (int k = 0; k < times; ++k)
+        for (int n = 0; n < n_particles; ++n)
+            s << poses[n].px << " " << poses[n].py << " " << poses[n].ptheta << " " << poses[n].vx << " " << poses[n].vy << " "
+              << poses[n].vtheta << " ";
+    s << std::endl;
+    for (int n = 0; n < n_particles; ++n) s << (resample_idx ? resample_idx[n] : n) << " ";
+    s << std::endl;
+    for (int n = 0; n < max_cardinality + 1; ++n) s << "0 ";
     s << std::endl;
     return s.good() ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name.str());
 }

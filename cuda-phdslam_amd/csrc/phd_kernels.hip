@@ -1379,6 +1379,27 @@ __device__ __forceinline__ double det_exp(float xf)
     return ldexp(p, (int)kd);
 }
 
+// particle "shotgun" (n_predict_particles = k > 1; src/phdfilter.cu:797-823,1185-1238): predicted
+// particle idx descends from prior particle idx / k, draws its own control noise, shares the prior's map
+// through the parent indirection (the reference deep-copies the maps k times) and carries the prior's
+// log-weight minus log k
+__global__ void phd_predict_shotgun_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n_pred, int k,
+                                           phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
+                                           u64 seed, u64 counter, DevConfig cfg, const int* __restrict__ parent_in,
+                                           int* __restrict__ parent_out, const float* __restrict__ logw_in,
+                                           float* __restrict__ logw_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pred) return;
+    const int prior = i / k;                                                    // :797
+    float n_alpha, n_encoder;
+    if (noise) { n_alpha = noise[i].n_alpha; n_encoder = noise[i].n_encoder; }
+    else draw_noise(seed, counter, i, cfg, n_alpha, n_encoder);
+    out[i] = predict_pose(in[prior], u, n_alpha, n_encoder, cfg);
+    parent_out[i] = parent_in[prior];
+    logw_out[i] = logw_in[prior] - safe_log((float)k);                           // :1213
+}
+
 // ------------------------------------------------------------------------------------------
 // Fixed-point resampling CDF (definition and rationale: oracle/scphd_cpu.c, o_resample):
 //   sb = 62 - ceil(log2 N);  q_i = floor(min(det_exp(w_i), 1) * 2^sb);  Q_i = q_0 + ... + q_i (exact)
@@ -1497,7 +1518,7 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     __syncthreads();
     const int n_new = A.n_new;
     if (!s_flag) {
-        for (int j = tid; j < n_new; j += PHD_WT) {
+        for (int j = tid; j < ((A.mode & W_COMMIT) ? n : n_new); j += PHD_WT) {
             A.idx_out[j] = j;                                                                          // :1292-1296
             if (A.mode & W_COMMIT) {
                 A.pose_out[j] = A.pose_in[j];
@@ -1665,7 +1686,7 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
             const int i = tid + r * BT;
             if (i < n) A.logw[i] = w[r];
         }
-        for (int j = tid; j < n_new; j += BT) {
+        for (int j = tid; j < ((A.mode & W_COMMIT) ? n : n_new); j += BT) {
             A.idx_out[j] = j;                                                                          // :1292-1296
             if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
         }
@@ -1936,6 +1957,16 @@ hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman
 {
     hipLaunchKernelGGL(phd_predict_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n, u, noise, seed,
                        counter, cfg);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict_shotgun(const phd_pose* in, phd_pose* out, int n_pred, int k, phd_ackerman_control u,
+                                  const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,
+                                  const int* parent_in, int* parent_out, const float* logw_in, float* logw_out,
+                                  hipStream_t st)
+{
+    hipLaunchKernelGGL(phd_predict_shotgun_kernel, dim3((n_pred + 255) / 256), dim3(256), 0, st, in, out, n_pred, k, u, noise,
+                       seed, counter, cfg, parent_in, parent_out, logw_in, logw_out);
     return hipGetLastError();
 }
 

@@ -39,8 +39,12 @@ class PhdFilter:
         h = C.c_void_p()
         check(lib().phd_create(C.byref(self.cfg), C.byref(opt), C.byref(h)), "phd_create")
         self._h = h
-        self.n = lib().phd_n_particles(h)
         self.cap = lib().phd_map_capacity(h)
+
+    @property
+    def n(self):
+        """current particle count (n_particles; grows by n_predict_particles per predict until a resample)"""
+        return lib().phd_n_particles(self._h)
 
     # -- lifetime ------------------------------------------------------------------------------
     def close(self):
@@ -124,8 +128,9 @@ class PhdFilter:
     def predict(self, control, noise=None):
         """phdPredict(particles, control); noise[N] = (n_alpha, n_encoder) or None (device RNG)"""
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32).view(NOISE).reshape(-1)
-        if nz is not None and len(nz) != self.n:
-            raise ValueError("noise must have n_particles entries")
+        k = max(1, int(self.cfg.nPredictParticles))
+        if nz is not None and len(nz) != self.n * k:
+            raise ValueError("noise must have n_particles * n_predict_particles entries")
         check(lib().phd_predict_ackerman(self._h, _ctrl(control), ptr(nz)), "phd_predict_ackerman")
 
     def update(self, z):
@@ -142,14 +147,14 @@ class PhdFilter:
         u = np.ascontiguousarray(np.atleast_1d(uniforms), np.float64)
         idx = np.zeros(self.n, np.int32)
         check(lib().phd_resample(self._h, ptr(u), len(u), ptr(idx)), "phd_resample")
-        return idx
+        return idx[:self.n]  # a grown (shotgun) particle set shrinks back to n_particles
 
     def resample_if_needed(self, uniform, had_measurements=True):
         did = C.c_int32(0)
         idx = np.zeros(self.n, np.int32)
         check(lib().phd_resample_if_needed(self._h, float(uniform), int(had_measurements), C.byref(did), ptr(idx)),
               "phd_resample_if_needed")
-        return bool(did.value), idx
+        return bool(did.value), idx[:self.n]
 
     def expected_pose(self):
         p = np.zeros(1, POSE)

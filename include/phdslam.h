@@ -301,6 +301,19 @@ int phd_load_measurements(const char* path, int triples, phd_measurement* out, s
  * ',' tolerated as separator */
 int phd_load_controls(const char* path, int has_header, phd_ackerman_control* out, size_t capacity, size_t* n_out);
 
+/* replaces: loadTimestamps (src/main.cpp:147-166): one value per line, no header; a missing file
+ * yields zero timestamps (= lock-step mode) */
+int phd_load_timestamps(const char* path, float* out, size_t capacity, size_t* n_out);
+/* replaces: loadTrajectory (src/main.cpp:242-260): "px py ptheta vx vy vtheta" per line, '%' lines skipped */
+int phd_load_trajectory(const char* path, phd_pose* out, size_t capacity, size_t* n_out);
+
+/* replaces: HEAD's 7-line writeLog (src/main.cpp:848-954): pose / static map / dynamic map / weights /
+ * poses / resample indices / cardinality, append mode, weights and poses repeated
+ * n_predict_particles times at step 0 */
+int phd_write_state_log7(const char* dir, int step, const phd_pose* expected_pose, const phd_gaussian2d* map,
+                         int n_map, const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
+                         int n_particles, int max_cardinality, int n_predict_particles);
+
 /* replaces: the state_estimate%05d.log contract (README:31-39; writer src/main.cpp:848-954):
  * 5 lines: pose / map (weight mx my c0 c1 c2 c3) / log-weights / poses / cardinality zeros */
 int phd_write_state_log(const char* dir, int step, const phd_pose* expected_pose,

@@ -52,8 +52,7 @@ def test_compute_fails_loudly_without_a_gpu():
 
 def test_out_of_scope_configs_are_rejected():
     P = pkg()
-    for over in (dict(featureModel=2), dict(particleWeighting=1), dict(filterType=1), dict(motionType=0),
-                 dict(nPredictParticles=4)):
+    for over in (dict(featureModel=2), dict(particleWeighting=1), dict(filterType=1), dict(motionType=0)):
         with pytest.raises(P.PhdError) as e:
             P.PhdFilter(P.default_config(**over), n_particles=4)
         assert e.value.code == -4, over
@@ -146,3 +145,45 @@ def test_state_log_format(tmp_path):
     assert np.allclose(np.array(lines[2].split(), float), lw, rtol=1e-5)
     assert len(lines[3].split()) == 18 and lines[4].split() == ["0"] * 5
     assert all(l.endswith(" ") for l in lines[:5])
+
+
+def test_timestamp_and_trajectory_loaders(tmp_path):
+    P = pkg()
+    L = P._lib.lib()
+    t = tmp_path / "measurement_times.txt"
+    t.write_text("0.0\n0.1\n0.25\n\n")                 # no header, trailing blank dropped (src/main.cpp:147-166)
+    n = C.c_size_t(0)
+    assert L.phd_load_timestamps(str(t).encode(), None, 0, C.byref(n)) == 0 and n.value == 3
+    out = np.zeros(3, np.float32)
+    assert L.phd_load_timestamps(str(t).encode(), out.ctypes.data_as(C.c_void_p), 3, C.byref(n)) == 0
+    assert np.array_equal(out, np.array([0.0, 0.1, 0.25], np.float32))
+    # a missing file means lock-step mode: zero time stamps, no error
+    assert L.phd_load_timestamps(str(tmp_path / "nope.txt").encode(), None, 0, C.byref(n)) == 0 and n.value == 0
+    tr = tmp_path / "traj.txt"
+    tr.write_text("% px py ptheta vx vy vtheta\n1 2 0.5 0 0 0\n1.5 2.5 0.6 0.1 0.2 0.3\n")
+    assert L.phd_load_trajectory(str(tr).encode(), None, 0, C.byref(n)) == 0 and n.value == 2
+    poses = np.zeros(2, P.POSE)
+    assert L.phd_load_trajectory(str(tr).encode(), poses.ctypes.data_as(C.c_void_p), 2, C.byref(n)) == 0
+    assert poses["px"][1] == np.float32(1.5) and poses["vtheta"][1] == np.float32(0.3) and poses["ptheta"][0] == np.float32(0.5)
+
+
+def test_state_log7_format(tmp_path):
+    """HEAD's writeLog (src/main.cpp:848-954): 7 lines, append mode, weights/poses repeated at t = 0"""
+    P = pkg()
+    L = P._lib.lib()
+    e = np.zeros(1, P.POSE); e["px"] = 1.5
+    g = np.zeros(1, P.GAUSSIAN); g["weight"] = 0.7; g["mean"] = [[1, 2]]; g["cov"] = [[0.1, 0.0, 0.0, 0.2]]
+    poses = np.zeros(2, P.POSE); poses["py"] = [3, 4]
+    lw = np.log(np.array([0.25, 0.75], np.float32))
+    ridx = np.array([1, 1], np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for step, times in ((0, 2), (3, 1)):
+        assert L.phd_write_state_log7(str(tmp_path).encode(), step, p(e), p(g), 1, p(lw), p(poses), p(ridx), 2, 3, 2) == 0
+        lines = open(tmp_path / ("state_estimate%05d.log" % step)).read().split("\n")
+        assert len(lines) == 8 and lines[7] == ""
+        assert float(lines[0].split()[0]) == 1.5 and len(lines[1].split()) == 7 and lines[2].strip() == ""
+        assert len(lines[3].split()) == 2 * times and len(lines[4].split()) == 12 * times   # nPredictParticles copies at t = 0
+        assert lines[5].split() == ["1", "1"] and lines[6].split() == ["0"] * 4
+    # append mode (fstream::app, :860)
+    assert L.phd_write_state_log7(str(tmp_path).encode(), 3, p(e), p(g), 1, p(lw), p(poses), p(ridx), 2, 3, 2) == 0
+    assert len(open(tmp_path / "state_estimate00003.log").read().split("\n")) == 15

@@ -405,3 +405,62 @@ def test_full_size_properties(cfg_id, sample):
             n_ok += 1
             assert_maps_close(maps[p], ref["map"], what="cfg %d particle %d" % (cfg_id, p))
     assert n_ok >= 1
+
+
+# ----------------------------------------------------------------------------------------------
+# particle "shotgun": n_predict_particles > 1 (src/phdfilter.cu:797,1185-1238; trigger src/main.cpp:1286)
+# ----------------------------------------------------------------------------------------------
+def test_shotgun_predict_and_resample_back():
+    P, S = pkg(), synthetic()
+    n, k = 32, 2
+    w = S.make_workload(n, 12, 8, seed=61)
+    cfg = P.default_config(nPredictParticles=k, n_particles=n)
+    ocfg = oracle_config_from(cfg)
+    rng = np.random.default_rng(3)
+    noise = np.stack([rng.normal(0, 0.03, n * k), rng.normal(0, 1.0, n * k)], 1).astype(np.float32)
+    with make_filter(cfg, w, cap=96) as f:
+        assert f.n == n
+        f.predict((2.0, 0.05), noise)
+        assert f.n == n * k
+        poses, lw = f.get_particles()
+        # predicted particle i descends from prior i // k, with its own noise (:797-803)
+        ref = O.predict_ackerman(np.repeat(w["poses"], k), 0.05, 2.0, noise, ocfg)
+        for fld in ("px", "py", "ptheta"):
+            assert np.abs(poses[fld] - ref[fld]).max() < 2e-6
+        logk = O.lib().o_safe_log(float(k))
+        assert np.abs(lw - (np.repeat(w["logw"], k) - np.float32(logk))).max() < 1e-6       # :1213
+        maps = f.get_maps()
+        for i in range(n * k):
+            assert np.array_equal(maps[i], w["maps"][i // k])                               # maps duplicated k times
+        # update on the grown set, then resample back to n_particles (src/main.cpp:1289)
+        f.update(w["z"][0])
+        poses2, lw2 = f.get_particles()
+        maps2 = f.get_maps()
+        idx = f.resample(0.42)
+        assert f.n == n and len(idx) == n
+        assert np.array_equal(idx, O.resample(lw2, 0.42, n_new=n))
+        p3, lw3 = f.get_particles()
+        assert np.array_equal(p3, poses2[idx]) and np.all(lw3 == np.float32(-np.log(float(n))))
+        maps3 = f.get_maps()
+        for j in range(n):
+            assert np.array_equal(maps3[j], maps2[idx[j]])
+        f.status()
+
+
+def test_shotgun_growth_forces_resample():
+    """more than 5*n_particles particles forces the resample (src/main.cpp:1286)"""
+    P, S = pkg(), synthetic()
+    n, k = 16, 2
+    w = S.make_workload(n, 6, 4, seed=62)
+    cfg = P.default_config(nPredictParticles=k, n_particles=n, resampleThresh=0.0)   # nEff never triggers
+    with make_filter(cfg, w, cap=64) as f:
+        counts = []
+        for step in range(4):
+            f.predict((2.0, 0.05), None)
+            did, idx = f.resample_if_needed(0.3)
+            counts.append((f.n, did))
+        # 16 -> 32 -> 64 -> 128 (> 80: forced back to 16) -> 32
+        assert counts == [(32, False), (64, False), (16, True), (32, False)], counts
+        with pytest.raises(P.PhdError):
+            for _ in range(8):
+                f.predict((2.0, 0.05), None)      # exceeding 5*n*k without resampling is refused
