@@ -123,6 +123,8 @@ SYMBOLS = {
     "phd_load_measurements": (_i, [C.c_char_p, _i, _vp, _sz, _vp, _sz, _vp, _vp]),
     "phd_load_controls": (_i, [C.c_char_p, _i, _vp, _sz, _vp]),
     "phd_write_state_log": (_i, [C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _i, _i]),
+    "phd_ospa": (_i, [_vp, _i, _vp, _i, _d, _d, _vp]),
+    "phd_evaluate_state_log": (_i, [C.c_char_p, _vp, _vp, _i, _d, _d, _vp]),
     "phd_load_timestamps": (_i, [C.c_char_p, _vp, _sz, _vp]),
     "phd_load_trajectory": (_i, [C.c_char_p, _vp, _sz, _vp]),
     "phd_write_state_log7": (_i, [C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i]),

@@ -320,6 +320,18 @@ int phd_write_state_log(const char* dir, int step, const phd_pose* expected_pose
                         const phd_gaussian2d* map, int n_map, const float* log_weights,
                         const phd_pose* poses, int n_particles, int max_cardinality);
 
+/* ------------------------------------------------------------------------------------
+ * Estimation-quality metrics of the reference's offline tooling (host side, no device)
+ * ---------------------------------------------------------------------------------- */
+/* replaces: ospa_distance(X, Y, p, c) (python/ospa.py:220-274; its Munkres cannot be built here):
+ * X[m][2], Y[n][2]; out[3] = (OSPA, localisation part, cardinality part) */
+int phd_ospa(const float* X, int m, const float* Y, int n, double p, double c, double* out);
+/* replaces: compute_error_k (python/batch_analyze.py:16-37) on one state_estimate log:
+ * out[5] = (pose error, OSPA, OSPA localisation, OSPA cardinality, nEff); the map estimate is the
+ * round(sum of weights) highest-weighted features; the reference uses p = 1, c = 5 */
+int phd_evaluate_state_log(const char* path, const float* true_pose_xy, const float* true_map, int n_true,
+                           double p, double c, double* out);
+
 #ifdef __cplusplus
 }
 #endif
