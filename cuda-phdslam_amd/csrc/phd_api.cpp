@@ -114,6 +114,9 @@ struct phd_filter {
     bool want_stamps = false;
     int last_M = 0;
 
+    GmWorkspace* gm = nullptr; // expected-map / gm_reduce workspace, created on first use
+    int gm_rounds = 0;
+
     bool frozen = false;
     uint64_t seed = 0x5EED, counter = 0;
     const phd_pose* pose_for_update = nullptr; // set by a frozen predict
@@ -269,6 +272,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
+    gm_workspace_destroy(f->gm);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     delete f;
     return PHD_OK;
@@ -855,6 +859,102 @@ extern "C" int phd_map_estimate(phd_filter* f, phd_gaussian2d* out, int capacity
     if (particle_out) *particle_out = am;
     return phd_get_map(f, am, out, capacity, n_out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// expected-a-posteriori map (config.mapEstimate & 2): computeExpectedMap, src/main.cpp:290-316,
+// with reduceGaussianMixture (src/gm_reduce.cpp:57-134) run on the device (phd_eap.hip)
+// ---------------------------------------------------------------------------------------------
+static int gm_fetch(phd_filter* f, const phd_gaussian2d* d_res, int K, phd_gaussian2d* out, int capacity, int32_t* n_out)
+{
+    if (n_out) *n_out = K;
+    if (K > capacity) return fail(PHD_ERR_CAPACITY, "expected map: output buffer too small (n_out holds the size needed)");
+    if (K > 0 && out) {
+        HIPCHK(hipMemcpyAsync(out, d_res, (size_t)K * sizeof(phd_gaussian2d), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_expected_map_concat_dev(phd_filter* f, float** d_planes, int64_t* total_out)
+{
+    CHECK_F(f);
+    if (!d_planes || !total_out) return fail(PHD_ERR_INVALID_ARG, "phd_expected_map_concat_dev: null output");
+    if (!f->gm) f->gm = gm_workspace_create();
+    std::vector<int32_t> sizes(f->n);
+    int rc = phd_get_map_sizes(f, sizes.data());
+    if (rc) return rc;
+    std::vector<int> off(f->n + 1, 0);
+    for (int p = 0; p < f->n; ++p) off[p + 1] = off[p] + sizes[p];
+    const size_t T = (size_t)off[f->n];
+    *total_out = (int64_t)T;
+    *d_planes = nullptr;
+    if (T == 0) return PHD_OK;
+    float* buf = gm_concat_buffer(f->gm, T, f->stream);
+    int* d_off = gm_offsets_buffer(f->gm, (size_t)f->n_max + 1, f->stream);
+    if (!buf || !d_off) return fail(PHD_ERR_HIP, "expected map: device allocation failed");
+    HIPCHK(hipMemcpyAsync(d_off, off.data(), (f->n + 1) * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(launch_eap_concat(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->logw, d_off, f->cap, f->n, buf, T,
+                             f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream)); // `off` is pageable host memory
+    *d_planes = buf;
+    return PHD_OK;
+}
+
+extern "C" int phd_gm_reduce_dev(phd_filter* f, const float* d_planes, int64_t total, int n_planes, float min_distance,
+                                 phd_gaussian2d* out, int capacity, int32_t* n_out)
+{
+    CHECK_F(f);
+    if (total < 0 || (n_planes != 6 && n_planes != 7) || (total > 0 && !d_planes) || capacity < 0)
+        return fail(PHD_ERR_INVALID_ARG, "phd_gm_reduce_dev: bad argument");
+    if (!f->gm) f->gm = gm_workspace_create();
+    const size_t T = (size_t)total;
+    const float* in[7] = {d_planes, d_planes + T, d_planes + 2 * T, d_planes + 3 * T, d_planes + 4 * T,
+                          n_planes == 7 ? d_planes + 5 * T : d_planes + 4 * T, d_planes + (size_t)(n_planes - 1) * T};
+    int K = 0;
+    const phd_gaussian2d* d_res = nullptr;
+    HIPCHK(gm_reduce_device(f->gm, in, T, min_distance, f->stream, &K, &f->gm_rounds, &d_res));
+    return gm_fetch(f, d_res, K, out, capacity, n_out);
+}
+
+extern "C" int phd_gm_reduce(phd_filter* f, const phd_gaussian2d* in, int64_t n, float min_distance, phd_gaussian2d* out,
+                             int capacity, int32_t* n_out)
+{
+    CHECK_F(f);
+    if (n < 0 || (n > 0 && !in)) return fail(PHD_ERR_INVALID_ARG, "phd_gm_reduce: bad argument");
+    if (n == 0) { if (n_out) *n_out = 0; return PHD_OK; }
+    const size_t T = (size_t)n;
+    std::vector<float> planes(7 * T);
+    for (size_t i = 0; i < T; ++i) {
+        planes[i] = in[i].weight;
+        planes[T + i] = in[i].mean[0];
+        planes[2 * T + i] = in[i].mean[1];
+        planes[3 * T + i] = in[i].cov[0];
+        planes[4 * T + i] = in[i].cov[1];
+        planes[5 * T + i] = in[i].cov[2];
+        planes[6 * T + i] = in[i].cov[3];
+    }
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, planes.size() * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice, f->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
+    int rc = e == hipSuccess ? phd_gm_reduce_dev(f, d, n, 7, min_distance, out, capacity, n_out) : fail(PHD_ERR_HIP, hipGetErrorString(e));
+    (void)hipStreamSynchronize(f->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int phd_expected_map(phd_filter* f, phd_gaussian2d* out, int capacity, int32_t* n_out)
+{
+    CHECK_F(f);
+    float* d = nullptr;
+    int64_t T = 0;
+    int rc = phd_expected_map_concat_dev(f, &d, &T);
+    if (rc) return rc;
+    if (T == 0) { if (n_out) *n_out = 0; return PHD_OK; }                  // "no features", src/main.cpp:308-313
+    return phd_gm_reduce_dev(f, d, T, 6, f->cfg.minSeparation, out, capacity, n_out);
+}
+
+extern "C" int phd_debug_gm_rounds(phd_filter* f) { return f ? f->gm_rounds : 0; }
 
 extern "C" int phd_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw; return PHD_OK; }
 extern "C" int phd_raw_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw_raw; return PHD_OK; }

@@ -119,6 +119,18 @@ hipError_t launch_gather_maps(const float* src, const int* counts_src, const int
 hipError_t launch_iota(int* a, int n, hipStream_t st);
 hipError_t launch_fill(float* a, float v, int n, hipStream_t st);
 
+// expected-a-posteriori map / device-wide reduceGaussianMixture (phd_eap.hip)
+struct GmWorkspace;
+GmWorkspace* gm_workspace_create();
+void gm_workspace_destroy(GmWorkspace* w);
+float* gm_concat_buffer(GmWorkspace* w, size_t T, hipStream_t st);  // [6][T] planes, grown on demand
+int* gm_offsets_buffer(GmWorkspace* w, size_t n, hipStream_t st);
+hipError_t launch_eap_concat(const float* maps, const int* counts, const int* parent, const float* logw, const int* offsets,
+                             int cap, int n, float* out, size_t T, hipStream_t st);
+// planes in[0..6] = weight, mean x, mean y, cov(0,0), cov(1,0), cov(0,1), cov(1,1); in[5] == in[4] when symmetric
+hipError_t gm_reduce_device(GmWorkspace* w, const float* const in[7], size_t T, float min_distance, hipStream_t st,
+                            int* K_out, int* rounds_out, const phd_gaussian2d** d_result);
+
 // weight-kernel mode bits (mirrors the enum in phd_kernels.hip)
 enum { WM_ACCUMULATE = 1, WM_NORMALIZE = 2, WM_RESAMPLE_FORCE = 4, WM_RESAMPLE_AUTO = 8, WM_HAD_MEAS = 16, WM_COMMIT = 32 };
 

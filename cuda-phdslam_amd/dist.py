@@ -132,6 +132,34 @@ class ShardedFilter:
         return idx
 
 
+def _expected_map(self, min_distance):
+    """EAP map of the GLOBAL particle set (computeExpectedMap, src/main.cpp:290-316): every rank
+    concatenates its own weighted maps on its device, the shards' concatenations are all-gathered
+    (ragged: padded to the longest) in rank order = global particle order, and each rank reduces
+    the same global mixture — identical results everywhere, no rank is special."""
+    planes = self.b.expected_map_concat()                   # tensor [6, total_r]
+    if self.world > 1:
+        gloo = dist.get_backend(self.group) == "gloo"
+        dev = planes.device
+        t = torch.tensor([planes.shape[1]], dtype=torch.int64, device="cpu" if gloo else dev)
+        totals = torch.empty(self.world, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(totals, t, group=self.group)
+        totals = [int(x) for x in totals.cpu()]
+        width = max(totals)
+        if width == 0:
+            return self.b.gm_reduce_planes(planes, min_distance)
+        mine = torch.zeros((6, width), dtype=planes.dtype, device="cpu" if gloo else dev)
+        mine[:, :planes.shape[1]] = planes.cpu() if gloo else planes
+        allp = torch.empty(self.world * 6 * width, dtype=planes.dtype, device=mine.device)
+        dist.all_gather_into_tensor(allp, mine.contiguous().view(-1), group=self.group)
+        allp = allp.view(self.world, 6, width)
+        planes = torch.cat([allp[r, :, :totals[r]] for r in range(self.world)], dim=1).contiguous().to(dev)
+    return self.b.gm_reduce_planes(planes, min_distance)
+
+
+ShardedFilter.expected_map = _expected_map
+
+
 class GpuShard:
     """ShardedFilter backend over the gfx950 filter (C-ABI calls; torch only wraps device memory)."""
 
@@ -212,3 +240,14 @@ class GpuShard:
 
     def finish_resample(self):
         self._check(self._lib().phd_finish_resample(self.f._h), "phd_finish_resample")
+
+    def expected_map_concat(self):
+        d, total = self.f.expected_map_concat_dev()          # synchronises the filter's stream
+        if total == 0:
+            return torch.zeros((6, 0), dtype=torch.float32, device=self.device)
+        return self._wrap(d, 6 * total).view(6, total).clone()
+
+    def gm_reduce_planes(self, planes, min_distance):
+        total = planes.shape[1]
+        self._torch_to_filter()
+        return self.f.gm_reduce_dev(planes.data_ptr() if total else None, total, 6, min_distance)

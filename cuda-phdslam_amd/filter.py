@@ -168,6 +168,50 @@ class PhdFilter:
         check(lib().phd_map_estimate(self._h, ptr(out), self.cap, C.byref(n), C.byref(who)), "phd_map_estimate")
         return out[:n.value].copy(), who.value
 
+    def expected_map(self, capacity=None):
+        """EAP map (config map_estimate & 2): computeExpectedMap, src/main.cpp:290-316, on the device"""
+        capacity = int(capacity or 4 * self.cap)
+        while True:
+            out = np.zeros(max(capacity, 1), GAUSSIAN)
+            n = C.c_int32(0)
+            rc = lib().phd_expected_map(self._h, ptr(out), capacity, C.byref(n))
+            if rc == -5 and n.value > capacity:
+                capacity = n.value
+                continue
+            check(rc, "phd_expected_map")
+            return out[:n.value].copy()
+
+    def gm_reduce(self, comps, min_distance):
+        """reduceGaussianMixture (src/gm_reduce.cpp:57-134) of an arbitrary mixture on this filter's device"""
+        comps = np.ascontiguousarray(comps, dtype=GAUSSIAN)
+        out = np.zeros(max(len(comps), 1), GAUSSIAN)
+        n = C.c_int32(0)
+        check(lib().phd_gm_reduce(self._h, ptr(comps), len(comps), float(min_distance), ptr(out), len(out), C.byref(n)),
+              "phd_gm_reduce")
+        return out[:n.value].copy()
+
+    def expected_map_concat_dev(self):
+        """-> (device pointer of the [6][total] weighted concatenation, total)"""
+        d = C.c_void_p()
+        total = C.c_int64(0)
+        check(lib().phd_expected_map_concat_dev(self._h, C.byref(d), C.byref(total)), "phd_expected_map_concat_dev")
+        return d.value or 0, total.value
+
+    def gm_reduce_dev(self, d_planes, total, n_planes, min_distance, capacity=4096):
+        while True:
+            out = np.zeros(max(capacity, 1), GAUSSIAN)
+            n = C.c_int32(0)
+            rc = lib().phd_gm_reduce_dev(self._h, ptr(d_planes), int(total), int(n_planes), float(min_distance), ptr(out),
+                                         capacity, C.byref(n))
+            if rc == -5 and n.value > capacity:
+                capacity = n.value
+                continue
+            check(rc, "phd_gm_reduce_dev")
+            return out[:n.value].copy()
+
+    def gm_rounds(self):
+        return lib().phd_debug_gm_rounds(self._h)
+
     # -- device-resident variants (raw device pointers as ints) --------------------------------
     def predict_dev(self, control, d_noise):
         check(lib().phd_predict_ackerman_dev(self._h, _ctrl(control), ptr(d_noise)), "phd_predict_ackerman_dev")

@@ -213,6 +213,29 @@ int phd_resample_if_needed(phd_filter* f, double uniform, int had_measurements,
 int phd_expected_pose(phd_filter* f, phd_pose* out);
 int phd_map_estimate(phd_filter* f, phd_gaussian2d* out, int capacity, int32_t* n_out, int32_t* particle_out);
 
+/* replaces: computeExpectedMap (src/main.cpp:290-316), the expected-a-posteriori map selected by
+ * config.mapEstimate & 2 (src/main.cpp:363-379): every particle's map with feature weights scaled
+ * by exp(particle log-weight), concatenated in particle order and reduced with
+ * reduceGaussianMixture(concat, config.minSeparation) (src/gm_reduce.cpp:57-134) — on the device.
+ * PHD_ERR_CAPACITY (with *n_out = size needed) when `capacity` is too small. */
+int phd_expected_map(phd_filter* f, phd_gaussian2d* out, int capacity, int32_t* n_out);
+
+/* replaces: reduceGaussianMixture<Gaussian2D> (src/gm_reduce.cpp:57-134) for any mixture, run on
+ * the filter's device and stream.  Ties in weight are ordered by input index (the reference's
+ * std::sort leaves them unspecified). */
+int phd_gm_reduce(phd_filter* f, const phd_gaussian2d* in, int64_t n, float min_distance,
+                  phd_gaussian2d* out, int capacity, int32_t* n_out);
+
+/* The two halves of phd_expected_map for the multi-GPU host: the weighted concatenation of this
+ * rank's maps as SoA planes in device memory ([6][total]: weight, mean x, mean y, cov xx, xy, yy;
+ * valid until the next call), and the reduction of `total` Gaussians given as n_planes = 6
+ * (symmetric) or 7 (weight, mean x, mean y, cov[0], cov[1], cov[2], cov[3]) device planes. */
+int phd_expected_map_concat_dev(phd_filter* f, float** d_planes, int64_t* total_out);
+int phd_gm_reduce_dev(phd_filter* f, const float* d_planes, int64_t total, int n_planes, float min_distance,
+                      phd_gaussian2d* out, int capacity, int32_t* n_out);
+/* rounds (window/assign/compact passes) the last reduction took — diagnostics */
+int phd_debug_gm_rounds(phd_filter* f);
+
 /* ------------------------------------------------------------------------------------
  * Device-resident variants (inputs already in HBM; used by bench.py and the multi-GPU host)
  * ---------------------------------------------------------------------------------- */

@@ -85,6 +85,7 @@ def lib():
         L.o_neff.restype = f32; L.o_neff.argtypes = [vp, i32]
         L.o_resample.restype = None; L.o_resample.argtypes = [vp, i32, vp, i32, i32, vp]
         L.o_expected_pose.restype = None; L.o_expected_pose.argtypes = [vp, vp, i32, vp]
+        L.o_expected_map.restype = i32; L.o_expected_map.argtypes = [vp, vp, vp, i32, f32, vp]
         L.o_argmax_weight.restype = i32; L.o_argmax_weight.argtypes = [vp, i32]
         L.o_step.restype = i32
         L.o_step.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, cp, f64, i32, vp, vp, vp, vp, i32]
@@ -232,6 +233,14 @@ def expected_pose(poses, logw):
     out = np.zeros(1, POSE)
     lib().o_expected_pose(_p(poses), _p(logw), len(poses), _p(out))
     return out[0]
+
+
+def expected_map(maps_concat, sizes, logw, min_distance):
+    """computeExpectedMap (src/main.cpp:290-316): maps_concat = all particle maps back to back"""
+    maps_concat = _c(maps_concat, GAUSSIAN); sizes = _c(sizes, np.int32); logw = _c(logw, np.float32)
+    out = np.zeros(max(len(maps_concat), 1), GAUSSIAN)
+    n = lib().o_expected_map(_p(maps_concat), _p(sizes), _p(logw), len(sizes), float(min_distance), _p(out))
+    return out[:n]
 
 
 def argmax_weight(logw):

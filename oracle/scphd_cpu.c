@@ -636,6 +636,30 @@ int o_argmax_weight(const float* logw, int n)
     return max_idx;
 }
 
+/* computeExpectedMap, src/main.cpp:290-316: concatenate the particle maps (sizes[n] Gaussians each,
+ * back to back in `maps`) with weights scaled by exp(particle log-weight), then reduceGaussianMixture.
+ * exp is the portable o_det_exp rounded to float (the reference's libm expf is not reproducible
+ * across machines; the two agree to 1 ulp). */
+int o_expected_map(const o_gaussian* maps, const int32_t* sizes, const float* logw, int n_particles,
+                   float min_distance, o_gaussian* out)
+{
+    long total = 0;
+    for (int n = 0; n < n_particles; n++) total += sizes[n];
+    if (total == 0) return 0;                                             /* :308-313 */
+    o_gaussian* concat = (o_gaussian*)malloc(sizeof(o_gaussian) * (size_t)total);
+    long t = 0;
+    for (int n = 0; n < n_particles; n++) {
+        const float f = (float)o_det_exp(logw[n]);
+        for (int i = 0; i < sizes[n]; i++, t++) {
+            concat[t] = maps[t];
+            concat[t].weight = maps[t].weight * f;                        /* :303 */
+        }
+    }
+    int k = o_gm_reduce(concat, (int)total, min_distance, out);           /* :315 */
+    free(concat);
+    return k;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* whole step (run_synth loop body, src/main.cpp:1244-1297) on fixed-capacity slabs        */
 /* ------------------------------------------------------------------------------------ */

@@ -96,6 +96,10 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
 /* literal transcription of src/gm_reduce.cpp:57-134 (sort, deque, Cholesky distance :30-37) */
 int o_gm_reduce(const o_gaussian* in, int n, float min_distance, o_gaussian* out);
 
+/* computeExpectedMap (src/main.cpp:290-316): weighted concatenation of all particle maps -> o_gm_reduce */
+int o_expected_map(const o_gaussian* maps, const int32_t* sizes, const float* logw, int n_particles,
+                   float min_distance, o_gaussian* out);
+
 /* full per-particle measurement update: classify, births, pre-update, update, prune,
  * recombine with near-range, merge, append out-of-range (src/phdfilter.cu:3336-3761 for one
  * particle).  map_out must hold n_map*(M+1)+M+n_map entries.

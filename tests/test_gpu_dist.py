@@ -40,11 +40,12 @@ def _worker(rank, world, port, out_dir, N, G, M, seed, u):
     allw = sf.gather_logweights()
     neff = sf.normalize(allw)
     _, lw_norm = f.get_particles()
+    eap = sf.expected_map(cfg.minSeparation)                  # EAP map of the global set, before resampling
     idx = sf.resample(u)
     poses, lw = f.get_particles()
     maps = f.get_maps()
     f.status()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, neff=neff, lw_norm=lw_norm, lw=lw, poses=poses,
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, neff=neff, lw_norm=lw_norm, lw=lw, poses=poses, eap=eap,
              sizes=np.array([len(m) for m in maps]), flat=np.concatenate(maps))
     f.close()
     dist.barrier()
@@ -67,14 +68,17 @@ def test_two_ranks_equal_one_filter(tmp_path):
         f.update(w["z"][0])
         _, lw_norm = f.get_particles()
         neff = f.neff()
+        eap = f.expected_map()
         idx = f.resample(u)
         poses, lw = f.get_particles()
         maps = f.get_maps()
+    assert len(eap) > 0
     n = N // world
     moved = 0
     for r in range(world):
         d = np.load(tmp_path / ("rank%d.npz" % r))
         assert np.array_equal(d["idx"], idx)
+        assert d["eap"].tobytes() == eap.tobytes()                 # ragged all-gather + reduction == one filter's EAP map
         assert float(d["neff"]) == neff
         assert np.array_equal(d["lw_norm"], lw_norm[r * n:(r + 1) * n])
         assert np.array_equal(d["lw"], lw[r * n:(r + 1) * n])
