@@ -164,6 +164,21 @@ void recoverSlamState(SynthSLAM& particles, ConstantVelocityState& expectedPose,
         if (particles.weights[i] > best) { best = particles.weights[i]; bi = i; }
     particles.max_map_static = particles.maps_static[bi];
     cn_estimate = particles.cardinalities[bi];
+    if ((config.mapEstimate & 2) && particles.n_particles > 1) {
+        // expected a priori map estimate (src/main.cpp:363-379): computeExpectedMap on the device
+        ensure_filter(particles, 0);
+        upload(particles);
+        std::vector<Gaussian2D> out(1024);
+        int32_t n = 0;
+        int rc = phd_expected_map(g_filter, out.data(), (int)out.size(), &n);
+        if (rc == PHD_ERR_CAPACITY && n > (int)out.size()) {
+            out.resize((size_t)n);
+            rc = phd_expected_map(g_filter, out.data(), (int)out.size(), &n);
+        }
+        if (rc != PHD_OK) die("phd_expected_map");
+        out.resize((size_t)n);
+        particles.exp_map_static = out;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

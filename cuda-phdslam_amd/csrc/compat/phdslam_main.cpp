@@ -104,7 +104,7 @@ int main(int argc, char** argv)
     std::vector<phd_pose> poses(n_max);
     std::vector<float> logw(n_max);
     std::vector<int32_t> ridx(n_max);
-    std::vector<phd_gaussian2d> map(opt.map_capacity);
+    std::vector<phd_gaussian2d> map(opt.map_capacity), eap(4 * (size_t)opt.map_capacity);
     std::vector<phd_ackerman_noise> noise((size_t)n_max);
     std::string timefile = out_dir + "/loopTime.log";
     printf("STARTING SIMULATION\n");
@@ -165,6 +165,32 @@ int main(int argc, char** argv)
         int32_t n_map = 0, who = 0;
         CHK(phd_expected_pose(f, &expected));
         CHK(phd_map_estimate(f, map.data(), (int)map.size(), &n_map, &who));
+        if ((config.mapEstimate & 2) && n_cur > 1) {
+            // expected-a-posteriori map (recoverSlamState, :363-379).  map_estimate = 2: it is the map of the log;
+            // map_estimate = 3 (both): the MAP map stays in the log, the EAP map goes to expected_mapNNNNN.log
+            int32_t n_eap = 0;
+            int rc = phd_expected_map(f, eap.data(), (int)eap.size(), &n_eap);
+            if (rc == PHD_ERR_CAPACITY && n_eap > (int)eap.size()) {
+                eap.resize((size_t)n_eap);
+                rc = phd_expected_map(f, eap.data(), (int)eap.size(), &n_eap);
+            }
+            if (rc != PHD_OK) die("phd_expected_map");
+            if (config.mapEstimate & 1) {
+                char name[64];
+                snprintf(name, sizeof name, "/expected_map%05d.log", n);
+                if (FILE* ef = fopen((out_dir + name).c_str(), "w")) {
+                    for (int i = 0; i < n_eap; ++i)
+                        fprintf(ef, "%g %g %g %g %g %g %g ", eap[i].weight, eap[i].mean[0], eap[i].mean[1], eap[i].cov[0],
+                                eap[i].cov[1], eap[i].cov[2], eap[i].cov[3]);
+                    fprintf(ef, "\n");
+                    fclose(ef);
+                }
+            } else {
+                if ((size_t)n_eap > map.size()) map.resize((size_t)n_eap);
+                std::copy(eap.begin(), eap.begin() + n_eap, map.begin());
+                n_map = n_eap;
+            }
+        }
         CHK(phd_get_particles(f, poses.data(), logw.data()));
         // nEff test and resampling (:1281-1297)
         int32_t did = 0;

@@ -41,6 +41,7 @@ class SynthSLAM : public ParticleSLAM {
 public:
     std::vector<std::vector<Gaussian2D> > maps_static;
     std::vector<Gaussian2D> max_map_static;
+    std::vector<Gaussian2D> exp_map_static;
     std::vector<std::vector<REAL> > cardinalities;
     std::vector<REAL> variances;
     explicit SynthSLAM(unsigned int n) : ParticleSLAM(n), maps_static(n), cardinalities(n), variances(n) {}

@@ -108,9 +108,12 @@ def python_loop(cfg_path, seed, capacity=256):
                 f.update(zz)
             e = f.expected_pose()
             gm, _ = f.map_estimate()
+            eap = f.expected_map() if (cfg.mapEstimate & 2) and f.n > 1 else None
+            if eap is not None and not (cfg.mapEstimate & 1):
+                gm = eap
             poses, lw = f.get_particles()
             did, idx = f.resample_if_needed(rng.randu01(), had_measurements=len(zz) > 0)
-            recs.append(dict(pose=e, map=gm, lw=lw, poses=poses, did=did, idx=idx, n=len(lw), M=len(zz)))
+            recs.append(dict(pose=e, map=gm, lw=lw, poses=poses, did=did, idx=idx, n=len(lw), M=len(zz), eap=eap))
             f.status()
     return recs
 
@@ -175,3 +178,25 @@ def test_follow_trajectory(tmp_path):
     assert abs(recs[3]["pose"]["px"] - 0.6) < 1e-6
     run_driver(cfg_path, os.path.join(d, "o"), 6)
     compare(recs, os.path.join(d, "o"))
+
+
+def test_expected_map_in_the_log(tmp_path):
+    """map_estimate = 2: the log's map line is the EAP map (recoverSlamState, src/main.cpp:363-379);
+    map_estimate = 3: MAP map in the log, EAP map beside it"""
+    d = str(tmp_path)
+    cfg_path = write_data(d, 4, 4, dict(n_particles=24, map_estimate=2, resample_threshold=0.5))
+    recs = python_loop(cfg_path, 9)
+    assert all(r["eap"] is not None for r in recs) and len(recs[-1]["map"]) > 0
+    run_driver(cfg_path, os.path.join(d, "o2"), 9)
+    compare(recs, os.path.join(d, "o2"))
+    for n, rec in enumerate(recs):
+        _, gmap, _, _ = parse_log(os.path.join(d, "o2", "state_estimate%05d.log" % n))
+        assert np.allclose(gmap[:, 1:3], rec["map"]["mean"], rtol=2e-5, atol=1e-5)
+    cfg_path = write_data(d, 4, 4, dict(n_particles=24, map_estimate=3, resample_threshold=0.5))
+    recs3 = python_loop(cfg_path, 9)
+    run_driver(cfg_path, os.path.join(d, "o3"), 9)
+    compare(recs3, os.path.join(d, "o3"))
+    for n, rec in enumerate(recs3):
+        e = np.array(open(os.path.join(d, "o3", "expected_map%05d.log" % n)).read().split(), float).reshape(-1, 7)
+        assert len(e) == len(rec["eap"]) and np.allclose(e[:, 0], rec["eap"]["weight"], rtol=2e-5)
+        assert np.array_equal(rec["eap"], recs[n]["eap"])            # same filter run, same EAP map

@@ -131,11 +131,13 @@ def test_expected_map_empty_maps():
         assert len(f.expected_map()) == 0                                        # "no features" (src/main.cpp:308-313)
 
 
-def test_expected_map_config2_size():
-    """BASELINE configs[1] (256 particles x 64 features): parity + a timing line against the oracle"""
+@pytest.mark.parametrize("cfg_id", [2, 3])
+def test_expected_map_full_size(cfg_id):
+    """BASELINE configs[1] (256 particles x 64 features) and configs[2] (4096 x 256, ~10^6 Gaussians):
+    parity + a timing line against the oracle"""
     P, S = pkg(), synthetic()
     cfg = P.default_config()
-    w = S.config_workload(2)
+    w = S.config_workload(cfg_id)
     with P.PhdFilter(cfg, n_particles=w["N"], map_capacity=2 * w["G"], max_measurements=64) as f:
         f.set_particles(w["poses"], w["logw"])
         f.set_maps(w["maps"], w["sizes"])
@@ -151,6 +153,6 @@ def test_expected_map_config2_size():
         t0 = time.perf_counter()
         ref = O.expected_map(cat, sizes, logw, cfg.minSeparation)
         t_cpu = time.perf_counter() - t0
-        assert_bit_equal(got, ref, "config 2")
+        assert_bit_equal(got, ref, "config %d" % cfg_id)
         print("\nEAP map, %d Gaussians -> %d: device %.2f ms (%d rounds), oracle %.1f ms"
               % (len(cat), len(got), 1e3 * t_gpu, f.gm_rounds(), 1e3 * t_cpu))
