@@ -158,6 +158,23 @@ int main(int argc, char** argv)
                 CHK(phd_predict_ackerman(f, current_control, noise.data()));
             }
         }
+        if (config.savePrediction) {
+            // save_prediction (:1256-1257): the reference dumps the predicted particle set to a .mat file
+            // (libmatio); here the same state as text — log-weights, then poses (maps are untouched by predict)
+            n_cur = phd_n_particles(f);
+            CHK(phd_get_particles(f, poses.data(), logw.data()));
+            char name[64];
+            snprintf(name, sizeof name, "/particles_predict%05d.log", n);
+            if (FILE* pf = fopen((out_dir + name).c_str(), "w")) {
+                for (int i = 0; i < n_cur; ++i) fprintf(pf, "%g ", logw[i]);
+                fprintf(pf, "\n");
+                for (int i = 0; i < n_cur; ++i)
+                    fprintf(pf, "%g %g %g %g %g %g ", poses[i].px, poses[i].py, poses[i].ptheta, poses[i].vx, poses[i].vy,
+                            poses[i].vtheta);
+                fprintf(pf, "\n");
+                fclose(pf);
+            }
+        }
         if (M > 0) CHK(phd_update(f, Z, M));                                                 // :1260-1272
         // state extraction (:1274) and log
         n_cur = phd_n_particles(f);

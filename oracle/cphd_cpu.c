@@ -1,0 +1,256 @@
+/*
+ * cphd_cpu.c — CPU ORACLE of the CPHD variant (test infrastructure, not product code).
+ *
+ * PARITY UNPINNED.  The reference's HEAD has no runnable CPHD: the kernels are commented out in
+ * src/phdfilter.cu (:701-779 constants, :1360-1591 cardinality/ESF) and filter_type is never read
+ * by phdUpdateSynth.  The only complete statement is the older src/phdfilter.cu.bak
+ * (cphdConstantsKernel :369-415, cardinalityPredictKernel :518-545, birth cardinality :779-790,
+ * cphdPreUpdateKernel :1058-1176, computeEsfKernel :1191-1274, computePsiKernel :1282-1412,
+ * cphdUpdateKernel :1420-1462, host sequence :2388-2544,2661-2709).  That version has defects
+ * (leave-one-out ESFs subtract magnitudes :1259; the psi1d inner product mixes two maxima
+ * :1401-1404; the predicted cardinality is overwritten by a Poisson law :2470-2484, which makes
+ * the update algebraically the PHD update) and a different birth scheme from HEAD.  This file
+ * therefore states the algorithm those kernels implement — the Gaussian-mixture CPHD recursion of
+ * Vo, Vo & Cantoni (IEEE TSP 55(7), 2007, eqs. 31-35, 44-49) — in the .bak's decomposition and
+ * log-domain arithmetic, on HEAD's update structure:
+ *
+ *   scope           the particle's whole map + the M measurement-driven births of HEAD
+ *                   (src/phdfilter.cu:3465-3510); p_D = pd for in-range features, 0 for the rest,
+ *                   1 for a birth with respect to its own measurement
+ *   cardinality     log p(n), n = 0..maxCardinality, per particle (.bak:1142 uniform start);
+ *                   predicted = prior (*) Binomial(M, birthWeight)      (.bak:518-545, 779-790)
+ *   roots           Xi_m = (clutterRate/clutterDensity) (sum_j pd w_j g_jm + birthWeight)  (.bak:1205-1222)
+ *   ESFs            e_j(Xi), e_j(Xi \ m) by the log-domain recursion                       (.bak:1224-1272)
+ *   Upsilon^u(n)    sum_j (M-j)! p_K(M-j) P(n,j+u) <1-pD,v>^(n-j-u) / <1,v>^n e_j          (.bak:1342-1366)
+ *   weights         missed: w (1-pD) <Y1,p>/<Y0,p>;  detected: pd w g (lambda/kappa) <Y1[Z\m],p>/<Y0,p>
+ *                                                                                          (.bak:1420-1462)
+ *   cardinality     p(n) Y0(n) / <Y0,p>                                                     (.bak:1409-1411)
+ *   particle weight += log <Y0,p>                                                           (.bak:2661-2667)
+ * With a Poisson prior of mean <1,v> this reduces to HEAD's PHD update exactly (tested).
+ * Checked against an independent float64 brute-force evaluation (subset enumeration) in tests/.
+ */
+#define _GNU_SOURCE
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "scphd_cpu.h"
+
+#define LOG0 (-FLT_MAX)
+
+static float clampl(float x) { return x < -1e30f ? -1e30f : x; }
+
+static float lse2(float a, float b)
+{
+    const float mx = a > b ? a : b, mn = a > b ? b : a;
+    return mx + log1pf(expf(mn - mx));
+}
+
+/* log sum exp of t[0..n) (two passes: max, then the sum in index order) */
+static float lse_n(const float* t, int n)
+{
+    if (n <= 0) return LOG0;
+    float mx = t[0];
+    for (int i = 1; i < n; i++) if (t[i] > mx) mx = t[i];
+    float s = 0;
+    for (int i = 0; i < n; i++) s += expf(t[i] - mx);
+    return o_safe_log(s) + mx;
+}
+
+void o_cphd_log_factorials(float* lfact, int n)                      /* initCphdConstants, .bak:421-425 */
+{
+    lfact[0] = 0;
+    for (int k = 1; k < n; k++) lfact[k] = lfact[k - 1] + o_safe_log((float)k);
+}
+
+/* ESF of the roots lxi[0..M) without root `skip` (skip < 0: none), log domain: e[0..M] (.bak:1224-1272) */
+static void esf_log(const float* lxi, int M, int skip, float* e)
+{
+    e[0] = 0;
+    for (int j = 1; j <= M; j++) e[j] = LOG0;
+    int done = 0;
+    for (int m = 0; m < M; m++) {
+        if (m == skip) continue;
+        for (int j = done + 1; j >= 1; j--) e[j] = lse2(e[j], lxi[m] + e[j - 1]);
+        done++;
+    }
+}
+
+/*
+ * The cardinality-dependent terms of one particle's CPHD update.
+ *   cn_prior[cn_len]  log cardinality before the births of this step
+ *   S[M]              sum_j exp(lw_jm) (linear), the detection masses of each measurement
+ *   w_all, pdw        <1,map>, <pD,map>
+ * Outputs: lz[M] (detection weight = exp(lw_jm - lz[m])), r1 (missed-detection factor),
+ * cn_out[cn_len], lY0 (= particle log-weight increment).
+ */
+void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, float w_all, float pdw,
+                  float birth_weight, float clutter_rate, float clutter_density,
+                  float* lz, float* r1_out, float* cn_out, float* lY0_out)
+{
+    const int Nmax = cn_len - 1;
+    const int LF = (Nmax > M ? Nmax : M) + 2;
+    float* lfact = (float*)malloc(sizeof(float) * LF);
+    float* cnp = (float*)malloc(sizeof(float) * cn_len);
+    float* cnb = (float*)malloc(sizeof(float) * (M + 1));
+    float* lxi = (float*)malloc(sizeof(float) * (M + 1));
+    float* e = (float*)malloc(sizeof(float) * (M + 1));
+    float* em = (float*)malloc(sizeof(float) * (M + 1));
+    float* I0 = (float*)malloc(sizeof(float) * (M + 1));
+    float* I1 = (float*)malloc(sizeof(float) * (M + 1));
+    float* t = (float*)malloc(sizeof(float) * (cn_len + M + 2));
+    o_cphd_log_factorials(lfact, LF);
+    const float llam = o_safe_log(clutter_rate), lkap = o_safe_log(clutter_density);
+    const float lbw = o_safe_log(birth_weight), l1bw = o_safe_log(1 - birth_weight);
+    const float W1 = w_all + (float)M * birth_weight;               /* <1,v>: map + births */
+    const float Wq = w_all - pdw;                                   /* <1-pD,v>: births are always detected */
+    const float lW1 = clampl(o_safe_log(W1)), lWq = clampl(o_safe_log(Wq));
+
+    /* 1. predicted cardinality = prior (*) Binomial(M, birthWeight)  (.bak:518-545 with :779-790) */
+    const int Kb = M < Nmax ? M : Nmax;
+    for (int k = 0; k <= Kb; k++)
+        cnb[k] = lfact[M] - lfact[k] - lfact[M - k] + (float)k * lbw + (float)(M - k) * l1bw;
+    for (int n = 0; n <= Nmax; n++) {
+        const int kmax = n < Kb ? n : Kb;
+        for (int k = 0; k <= kmax; k++) t[k] = cnb[k] + cn_prior[n - k];
+        cnp[n] = lse_n(t, kmax + 1);
+    }
+    /* 2. roots (.bak:1205-1222) */
+    for (int m = 0; m < M; m++) lxi[m] = o_safe_log(S[m] + birth_weight) + llam - lkap;
+    /* 3. inner products over n that do not depend on the measurements:
+     *    I_u[j] = log sum_n p(n) P(n, j+u) Wq^(n-j-u) / W1^n */
+    for (int j = 0; j <= M; j++) {
+        int c = 0;
+        for (int n = j; n <= Nmax; n++)
+            t[c++] = cnp[n] + (lfact[n] - lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
+        I0[j] = lse_n(t, c);
+        c = 0;
+        for (int n = j + 1; n <= Nmax; n++)
+            t[c++] = cnp[n] + (lfact[n] - lfact[n - j - 1]) + (float)(n - j - 1) * lWq - (float)n * lW1;
+        I1[j] = lse_n(t, c);
+    }
+    /* 4. full ESF, <Y0,p>, <Y1,p>;  (M-j)! p_K(M-j) = lambda^(M-j) e^-lambda for Poisson clutter (.bak:398-400) */
+    esf_log(lxi, M, -1, e);
+    for (int j = 0; j <= M; j++) t[j] = e[j] + I0[j] + ((float)(M - j) * llam - clutter_rate);
+    const float lY0 = lse_n(t, M + 1);
+    for (int j = 0; j <= M; j++) t[j] = e[j] + I1[j] + ((float)(M - j) * llam - clutter_rate);
+    const float lY1 = lse_n(t, M + 1);
+    /* 5. leave-one-out ESFs and <Y1[Z\m],p> */
+    for (int m = 0; m < M; m++) {
+        esf_log(lxi, M, m, em);
+        for (int j = 0; j <= M - 1; j++) t[j] = em[j] + I1[j] + ((float)(M - 1 - j) * llam - clutter_rate);
+        const float lD = lse_n(t, M);
+        lz[m] = -((llam - lkap) + lD - lY0);
+    }
+    *r1_out = expf(lY1 - lY0);
+    /* 6. updated cardinality (.bak:1409-1411) */
+    for (int n = 0; n <= Nmax; n++) {
+        const int jmax = n < M ? n : M;
+        for (int j = 0; j <= jmax; j++)
+            t[j] = e[j] + ((float)(M - j) * llam - clutter_rate) + (lfact[n] - lfact[n - j]) + (float)(n - j) * lWq
+                   - (float)n * lW1;
+        cn_out[n] = cnp[n] + lse_n(t, jmax + 1) - lY0;
+    }
+    *lY0_out = lY0;
+    free(lfact); free(cnp); free(cnb); free(lxi); free(e); free(em); free(I0); free(I1); free(t);
+}
+
+/* o_update for the CPHD variant: same slab layout [non-detect | detect m-major | births] */
+void o_cphd_update(const o_gaussian* feat, const float* pd, const o_gaussian* preupdate, const o_gaussian* births,
+                   int n, int M, const o_config* cfg, float clutter_rate, float w_all,
+                   const float* cn_prior, int cn_len,
+                   o_gaussian* slab, uint8_t* prune_flag, float* dlogw, float* cn_out, float* r1_out)
+{
+    const int n_update = n * (M + 1) + M;
+    float* S = (float*)malloc(sizeof(float) * (M + 1));
+    float* lz = (float*)malloc(sizeof(float) * (M + 1));
+    float pdw = 0;
+    for (int j = 0; j < n; j++) pdw += pd[j] * feat[j].weight;
+    for (int m = 0; m < M; m++) {
+        float sum = 0;
+        for (int j = 0; j < n; j++) sum += expf(preupdate[(size_t)m * n + j].weight);
+        S[m] = sum;
+    }
+    float r1 = 1, lY0 = 0;
+    o_cphd_terms(cn_prior, cn_len, S, M, w_all, pdw, cfg->birthWeight, clutter_rate, cfg->clutterDensity,
+                 lz, &r1, cn_out, &lY0);
+    for (int j = 0; j < n; j++) {
+        slab[j] = feat[j];
+        slab[j].weight = feat[j].weight * (1 - pd[j]) * r1;
+        for (int m = 0; m < M; m++) {
+            o_gaussian g = preupdate[(size_t)m * n + j];
+            g.weight = expf(g.weight - lz[m]);
+            slab[n + (size_t)m * n + j] = g;
+        }
+    }
+    for (int m = 0; m < M; m++) {
+        o_gaussian b = births[m];
+        b.weight = expf(b.weight - lz[m]);
+        slab[n + (size_t)M * n + m] = b;
+    }
+    *dlogw = lY0;
+    if (r1_out) *r1_out = r1;
+    for (int i = 0; i < n_update; i++) prune_flag[i] = (slab[i].weight < cfg->minFeatureWeight) ? 1 : 0;
+    free(S); free(lz);
+}
+
+/* o_update_particle for the CPHD variant; features outside the field of view (pD = 0) take the
+ * missed-detection factor r1 like every undetected part of the intensity */
+int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                           const o_config* cfg, float clutter_rate, const float* cn_prior, int cn_len,
+                           o_gaussian* map_out, float* dlogw, float* cn_out,
+                           o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out)
+{
+    int8_t* cls = (int8_t*)malloc(n_map > 0 ? n_map : 1);
+    o_classify(map, n_map, pose, cfg, cls);
+    int n_in = 0, n_near = 0, n_out0 = 0;
+    float w_all = 0;
+    for (int i = 0; i < n_map; i++) {
+        n_in += cls[i] == 1; n_near += cls[i] == 2; n_out0 += cls[i] == 0;
+        w_all += map[i].weight;
+    }
+    o_gaussian* f_in = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_in + 1));
+    o_gaussian* f_near = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_near + 1));
+    o_gaussian* f_out = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_out0 + 1));
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < n_map; i++) {
+        if (cls[i] == 1) f_in[a++] = map[i];
+        else if (cls[i] == 2) f_near[b++] = map[i];
+        else f_out[c++] = map[i];
+    }
+    size_t n_update = (size_t)n_in * (M + 1) + M;
+    o_gaussian* births = (o_gaussian*)malloc(sizeof(o_gaussian) * (M + 1));
+    o_gaussian* pre = (o_gaussian*)malloc(sizeof(o_gaussian) * ((size_t)n_in * M + 1));
+    float* pd = (float*)malloc(sizeof(float) * (n_in + 1));
+    o_gaussian* slab = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_update + n_near + 1));
+    uint8_t* flag = (uint8_t*)malloc(n_update + 1);
+    float r1 = 1;
+    o_births(pose, z, M, cfg, births);
+    o_preupdate(pose, f_in, n_in, z, M, cfg, pd, pre);
+    o_cphd_update(f_in, pd, pre, births, n_in, M, cfg, clutter_rate, w_all, cn_prior, cn_len, slab, flag, dlogw, cn_out, &r1);
+    int ns = 0;
+    for (size_t i = 0; i < n_update; i++) {
+        if (!flag[i]) {
+            if (surv_slab_idx) surv_slab_idx[ns] = (int32_t)i;
+            slab[ns++] = slab[i];
+        }
+    }
+    for (int i = 0; i < n_near; i++) {
+        o_gaussian g = f_near[i];
+        g.weight = g.weight * r1;                                    /* joins the merge unpruned, like HEAD (:3242-3257) */
+        if (surv_slab_idx) surv_slab_idx[ns] = (int32_t)(n_update + i);
+        slab[ns++] = g;
+    }
+    if (survivors_out) memcpy(survivors_out, slab, sizeof(o_gaussian) * ns);
+    if (n_survivors_out) *n_survivors_out = ns;
+    int nm = o_merge(slab, ns, cfg, map_out, NULL);
+    for (int i = 0; i < n_out0; i++) {
+        map_out[nm] = f_out[i];
+        map_out[nm].weight = f_out[i].weight * r1;
+        nm++;
+    }
+    if (r1_out) *r1_out = r1;
+    free(cls); free(f_in); free(f_near); free(f_out); free(births); free(pre); free(pd); free(slab); free(flag);
+    return nm;
+}

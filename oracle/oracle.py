@@ -86,6 +86,10 @@ def lib():
         L.o_resample.restype = None; L.o_resample.argtypes = [vp, i32, vp, i32, i32, vp]
         L.o_expected_pose.restype = None; L.o_expected_pose.argtypes = [vp, vp, i32, vp]
         L.o_expected_map.restype = i32; L.o_expected_map.argtypes = [vp, vp, vp, i32, f32, vp]
+        L.o_cphd_terms.restype = None
+        L.o_cphd_terms.argtypes = [vp, i32, vp, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
+        L.o_cphd_update_particle.restype = i32
+        L.o_cphd_update_particle.argtypes = [vp, vp, i32, vp, i32, cp, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.o_argmax_weight.restype = i32; L.o_argmax_weight.argtypes = [vp, i32]
         L.o_step.restype = i32
         L.o_step.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, cp, f64, i32, vp, vp, vp, vp, i32]
@@ -241,6 +245,32 @@ def expected_map(maps_concat, sizes, logw, min_distance):
     out = np.zeros(max(len(maps_concat), 1), GAUSSIAN)
     n = lib().o_expected_map(_p(maps_concat), _p(sizes), _p(logw), len(sizes), float(min_distance), _p(out))
     return out[:n]
+
+
+def cphd_terms(cn_prior, S, w_all, pdw, birth_weight, clutter_rate, clutter_density):
+    """-> dict(lz[M], r1, cn[cn_len], lY0): the cardinality-dependent terms of one particle's CPHD update"""
+    cn_prior = _c(cn_prior, np.float32); S = _c(S, np.float32)
+    M = len(S)
+    lz = np.zeros(max(M, 1), np.float32); cn = np.zeros(len(cn_prior), np.float32)
+    r1 = np.zeros(1, np.float32); ly0 = np.zeros(1, np.float32)
+    lib().o_cphd_terms(_p(cn_prior), len(cn_prior), _p(S), M, float(w_all), float(pdw), float(birth_weight),
+                       float(clutter_rate), float(clutter_density), _p(lz), _p(r1), _p(cn), _p(ly0))
+    return dict(lz=lz[:M], r1=float(r1[0]), cn=cn, lY0=float(ly0[0]))
+
+
+def cphd_update_particle(pose, gmap, z, cfg, clutter_rate, cn_prior):
+    """-> dict(map, dlogw, cn, survivors, slab_idx, r1)"""
+    pose = _c(pose, POSE).reshape(1)
+    gmap = _c(gmap, GAUSSIAN); z = _c(z, MEAS); cn_prior = _c(cn_prior, np.float32)
+    n, M = len(gmap), len(z)
+    cap = n * (M + 1) + M + n + 1
+    out = np.zeros(cap, GAUSSIAN); surv = np.zeros(cap, GAUSSIAN); sidx = np.zeros(cap, np.int32)
+    ns = C.c_int(0)
+    dlw = np.zeros(1, np.float32); r1 = np.zeros(1, np.float32); cn = np.zeros(len(cn_prior), np.float32)
+    nm = lib().o_cphd_update_particle(_p(pose), _p(gmap), n, _p(z), M, C.byref(cfg), float(clutter_rate), _p(cn_prior),
+                                      len(cn_prior), _p(out), _p(dlw), _p(cn), _p(surv), _p(sidx), C.byref(ns), _p(r1))
+    return dict(map=out[:nm].copy(), dlogw=float(dlw[0]), cn=cn, survivors=surv[:ns.value].copy(),
+                slab_idx=sidx[:ns.value].copy(), r1=float(r1[0]))
 
 
 def argmax_weight(logw):

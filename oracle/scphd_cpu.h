@@ -110,6 +110,20 @@ int o_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, cons
                       o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
                       float* margin_out);
 
+/* ---- CPHD variant (cphd_cpu.c; parity unpinned, see its header) ---- */
+void o_cphd_log_factorials(float* lfact, int n);
+void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, float w_all, float pdw,
+                  float birth_weight, float clutter_rate, float clutter_density,
+                  float* lz, float* r1_out, float* cn_out, float* lY0_out);
+void o_cphd_update(const o_gaussian* feat, const float* pd, const o_gaussian* preupdate, const o_gaussian* births,
+                   int n, int M, const o_config* cfg, float clutter_rate, float w_all,
+                   const float* cn_prior, int cn_len,
+                   o_gaussian* slab, uint8_t* prune_flag, float* dlogw, float* cn_out, float* r1_out);
+int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                           const o_config* cfg, float clutter_rate, const float* cn_prior, int cn_len,
+                           o_gaussian* map_out, float* dlogw, float* cn_out,
+                           o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out);
+
 /* src/phdfilter.cu:3741-3755 + src/device_math.cuh:549-558 */
 void o_normalize_weights(float* logw, const float* dlogw, int n);
 /* src/main.cpp:1281-1284 */
