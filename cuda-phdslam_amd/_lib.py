@@ -95,6 +95,10 @@ SYMBOLS = {
     "phd_expected_pose": (_i, [_vp, _vp]),
     "phd_map_estimate": (_i, [_vp, _vp, _i, _vp, _vp]),
     "phd_expected_map": (_i, [_vp, _vp, _i, _vp]),
+    "phd_cardinality_length": (_i, [_vp]),
+    "phd_get_cardinalities": (_i, [_vp, _vp]),
+    "phd_set_cardinalities": (_i, [_vp, _vp]),
+    "phd_cardinality_estimate": (_i, [_vp, _vp, _vp]),
     "phd_gm_reduce": (_i, [_vp, _vp, C.c_int64, _f, _vp, _i, _vp]),
     "phd_expected_map_concat_dev": (_i, [_vp, _vp, _vp]),
     "phd_gm_reduce_dev": (_i, [_vp, _vp, C.c_int64, _i, _f, _vp, _i, _vp]),

@@ -114,6 +114,12 @@ struct phd_filter {
     bool want_stamps = false;
     int last_M = 0;
 
+    // CPHD variant (filter_type = 1): per-particle log cardinality rows, double-buffered and indexed like the slabs
+    bool cphd = false;
+    int cn_len = 0;
+    float* cn[2] = {nullptr, nullptr};
+    float* d_lfact = nullptr;
+    int lfact_len = 0;
     GmWorkspace* gm = nullptr; // expected-map / gm_reduce workspace, created on first use
     int gm_rounds = 0;
 
@@ -133,6 +139,7 @@ static void fill_devcfg(const phd_slam_config& c, DevConfig& d)
     d.minRange = c.minRange; d.maxRange = c.maxRange; d.maxBearing = c.maxBearing;
     d.stdRange = c.stdRange; d.stdBearing = c.stdBearing;
     d.clutterDensity = c.clutterDensity; d.pd = c.pd;
+    d.clutterRate = c.clutterRate;
     d.birthWeight = c.birthWeight; d.birthNoiseFactor = c.birthNoiseFactor;
     d.minFeatureWeight = c.minFeatureWeight; d.minSeparation = c.minSeparation;
     d.l = c.l; d.h = c.h; d.a = c.a; d.b = c.b;
@@ -148,7 +155,9 @@ static int check_supported(const phd_slam_config& c)
     if (c.featureModel != 0) return fail(PHD_ERR_UNSUPPORTED, "feature_model != 0 (dynamic/mixed features) is not supported");
     if (c.particleWeighting != 0) return fail(PHD_ERR_UNSUPPORTED, "particle_weighting != 0 is not supported");
     if (c.motionType != 1) return fail(PHD_ERR_UNSUPPORTED, "motion_type != 1 (Ackerman) is not supported");
-    if (c.filterType != 0) return fail(PHD_ERR_UNSUPPORTED, "filter_type != 0 (CPHD) is not supported in this build");
+    if (c.filterType != 0 && c.filterType != 1) return fail(PHD_ERR_INVALID_ARG, "filter_type must be 0 (PHD) or 1 (CPHD)");
+    if (c.filterType == 1 && (c.maxCardinality < 1 || c.maxCardinality > 1023))
+        return fail(PHD_ERR_INVALID_ARG, "CPHD: max_cardinality must be in 1..1023");
     if (c.distanceMetric != 0 && c.distanceMetric != 1) return fail(PHD_ERR_INVALID_ARG, "distance_metric must be 0 or 1");
     if (c.nPredictParticles < 1) return fail(PHD_ERR_INVALID_ARG, "n_predict_particles must be >= 1");
     return PHD_OK;
@@ -201,6 +210,12 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     if (S > 2048) S = 2048; // register-staged permutation in merge_in_lds handles <= 2048
     f->S_cap = S;
     f->lds_bytes = update_lds_bytes(f->S_cap, f->cap, f->MM);
+    if (cfg->filterType == 1) {
+        f->cphd = true;
+        f->cn_len = cfg->maxCardinality + 1;
+        f->lfact_len = std::max(f->cn_len, f->MM + 1) + 1;
+        f->lds_bytes += cphd_lds_bytes(f->cn_len, f->MM);
+    }
     if (f->lds_bytes > 160 * 1024) {
         delete f;
         return fail(PHD_ERR_CAPACITY, "phd_create: map_capacity/survivor_capacity need more than 160 KiB of LDS");
@@ -231,6 +246,10 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->d_tmp_int, f->n_max));
     A(dalloc(&f->ticket, 1));
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
+    if (f->cphd) {
+        A(dalloc(&f->cn[0], (size_t)f->n_max * f->cn_len)); A(dalloc(&f->cn[1], (size_t)f->n_max * f->cn_len));
+        A(dalloc(&f->d_lfact, f->lfact_len));
+    }
     if (e != hipSuccess) {
         phd_destroy(f);
         return fail(PHD_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(e));
@@ -244,6 +263,16 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     hipMemsetAsync(f->max_surv, 0, 4, f->stream);
     hipMemsetAsync(f->max_map, 0, 4, f->stream);
     for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n_max, f->stream);
+    if (f->cphd) {
+        // uniform cardinality -log(maxCardinality+1) (src/main.cpp:1142); log factorials by the reference's
+        // recurrence (initCphdConstants, src/phdfilter.cu.bak:421-425)
+        for (int k = 0; k < 2; ++k) launch_fill(f->cn[k], -logf((float)f->cn_len), f->n_max * f->cn_len, f->stream);
+        std::vector<float> lf(f->lfact_len);
+        lf[0] = 0.f;
+        for (int k = 1; k < f->lfact_len; ++k) lf[k] = lf[k - 1] + logf((float)k);
+        hipMemcpyAsync(f->d_lfact, lf.data(), lf.size() * sizeof(float), hipMemcpyHostToDevice, f->stream);
+        hipStreamSynchronize(f->stream);
+    }
     // initial particles: cfg pose, weights -log N (src/main.cpp:1130-1145)
     std::vector<phd_pose> p0(f->n);
     std::vector<float> w0(f->n, -logf((float)f->n_global));
@@ -271,6 +300,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
     hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
+    hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     gm_workspace_destroy(f->gm);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
@@ -378,6 +408,9 @@ static int materialize_parents(phd_filter* f)
     if (!f->parent_dirty) return PHD_OK;
     HIPCHK(launch_gather_maps(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], nullptr, f->maps[f->cur ^ 1],
                               f->counts[f->cur ^ 1], nullptr, nullptr, f->cap, f->n, f->stream));
+    if (f->cphd)
+        HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, nullptr, f->parent[f->pcur], f->cn[f->cur ^ 1], f->cn_len, nullptr,
+                                f->cn_len, f->n, f->stream));
     f->cur ^= 1;
     HIPCHK(launch_iota(f->parent[f->pcur], f->n, f->stream));
     f->parent_dirty = false;
@@ -420,6 +453,10 @@ extern "C" int phd_set_maps(phd_filter* f, const phd_gaussian2d* concat, const i
 {
     CHECK_F(f);
     if (!sizes) return fail(PHD_ERR_INVALID_ARG, "phd_set_maps: null sizes");
+    if (f->cphd) { // the cardinality rows share the map indirection this call resets
+        int rc = materialize_parents(f);
+        if (rc) return rc;
+    }
     std::vector<int> off(f->n + 1, 0);
     for (int p = 0; p < f->n; ++p) {
         if (sizes[p] < 0 || sizes[p] > f->cap)
@@ -647,6 +684,14 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     a.status = f->status;
     a.max_surv = f->max_surv;
     a.max_map = f->max_map;
+    if (f->cphd) {
+        a.cphd = 1;
+        a.cn_in = f->cn[f->cur];
+        a.cn_out = f->cn[f->cur ^ 1];
+        a.cn_len = f->cn_len;
+        a.lfact = f->d_lfact;
+        a.lfact_len = f->lfact_len;
+    }
     a.cfg = f->dcfg;
     int free_pose = 0;
     if (fw) {
@@ -726,7 +771,7 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
 // launch's fixed cost is a measurable share of the step.
 static bool can_fuse(const phd_filter* f)
 {
-    return f->fuse_enabled && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
+    return f->fuse_enabled && !f->cphd && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
            (size_t)f->n * 8 <= f->lds_bytes;
 }
 
@@ -956,6 +1001,54 @@ extern "C" int phd_expected_map(phd_filter* f, phd_gaussian2d* out, int capacity
 
 extern "C" int phd_debug_gm_rounds(phd_filter* f) { return f ? f->gm_rounds : 0; }
 
+// ---------------------------------------------------------------------------------------------
+// CPHD variant: the per-particle cardinality distributions (SynthSLAM::cardinalities, src/slamtypes.h:296)
+// ---------------------------------------------------------------------------------------------
+extern "C" int phd_cardinality_length(const phd_filter* f) { return f ? f->cn_len : 0; }
+
+extern "C" int phd_get_cardinalities(phd_filter* f, float* out)
+{
+    CHECK_F(f);
+    if (!f->cphd) return fail(PHD_ERR_UNSUPPORTED, "phd_get_cardinalities: filter_type is not CPHD");
+    if (!out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    int rc = materialize_parents(f);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, f->cn[f->cur], (size_t)f->n * f->cn_len * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+extern "C" int phd_set_cardinalities(phd_filter* f, const float* in)
+{
+    CHECK_F(f);
+    if (!f->cphd) return fail(PHD_ERR_UNSUPPORTED, "phd_set_cardinalities: filter_type is not CPHD");
+    if (!in) return fail(PHD_ERR_INVALID_ARG, "null input");
+    int rc = materialize_parents(f);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(f->cn[f->cur], in, (size_t)f->n * f->cn_len * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return PHD_OK;
+}
+
+// cn_estimate of recoverSlamState (src/main.cpp:360): the cardinality distribution of the arg-max-weight particle
+extern "C" int phd_cardinality_estimate(phd_filter* f, float* out, int32_t* particle_out)
+{
+    CHECK_F(f);
+    if (!f->cphd) return fail(PHD_ERR_UNSUPPORTED, "phd_cardinality_estimate: filter_type is not CPHD");
+    if (!out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    int am = -1, src = 0;
+    HIPCHK(launch_state(f->pose[f->pose_cur], f->logw, f->n, f->state_pose, f->state_argmax, f->stream));
+    HIPCHK(hipMemcpyAsync(&am, f->state_argmax, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (am < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
+    HIPCHK(hipMemcpyAsync(&src, f->parent[f->pcur] + am, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    HIPCHK(hipMemcpyAsync(out, f->cn[f->cur] + (size_t)src * f->cn_len, f->cn_len * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (particle_out) *particle_out = am;
+    return PHD_OK;
+}
+
 extern "C" int phd_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw; return PHD_OK; }
 extern "C" int phd_raw_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw_raw; return PHD_OK; }
 
@@ -1048,7 +1141,7 @@ extern "C" int phd_global_resample_indices(phd_filter* f, const float* d_all_log
     return PHD_OK;
 }
 
-extern "C" size_t phd_particle_pack_bytes(const phd_filter* f) { return f ? (size_t)(8 + 6 * f->cap) * 4 : 0; }
+extern "C" size_t phd_particle_pack_bytes(const phd_filter* f) { return f ? (size_t)(8 + 6 * f->cap + f->cn_len) * 4 : 0; }
 
 extern "C" int phd_export_particles_dev(phd_filter* f, const int32_t* particles, int n, void* d_buffer)
 {
@@ -1059,6 +1152,9 @@ extern "C" int phd_export_particles_dev(phd_filter* f, const int32_t* particles,
     HIPCHK(hipMemcpyAsync(f->d_sizes, particles, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
     HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->pose[f->pose_cur], f->d_sizes,
                          d_buffer, f->cap, phd_particle_pack_bytes(f), n, f->stream));
+    if (f->cphd) // the cardinality row travels behind the slab
+        HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, f->d_sizes, f->parent[f->pcur], (float*)d_buffer + 8 + 6 * f->cap,
+                                phd_particle_pack_bytes(f) / 4, nullptr, f->cn_len, n, f->stream));
     return PHD_OK;
 }
 
@@ -1070,6 +1166,9 @@ extern "C" int phd_apply_parents(phd_filter* f, const int32_t* local_parent)
     const int pnext = (f->pose_cur + 1) % 3;
     HIPCHK(launch_gather_maps(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->d_tmp_int, f->maps[f->cur ^ 1],
                               f->counts[f->cur ^ 1], f->pose[f->pose_cur], f->pose[pnext], f->cap, f->n, f->stream));
+    if (f->cphd)
+        HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, f->d_tmp_int, f->parent[f->pcur], f->cn[f->cur ^ 1], f->cn_len, nullptr,
+                                f->cn_len, f->n, f->stream));
     return PHD_OK;
 }
 
@@ -1082,6 +1181,9 @@ extern "C" int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int
     HIPCHK(hipMemcpyAsync(f->d_sizes, slots, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
     HIPCHK(launch_import(f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], f->d_sizes, d_buffer, f->cap,
                          phd_particle_pack_bytes(f), n, f->stream));
+    if (f->cphd)
+        HIPCHK(launch_copy_rows((const float*)d_buffer + 8 + 6 * f->cap, phd_particle_pack_bytes(f) / 4, nullptr, nullptr,
+                                f->cn[f->cur ^ 1], f->cn_len, f->d_sizes, f->cn_len, n, f->stream));
     return PHD_OK;
 }
 

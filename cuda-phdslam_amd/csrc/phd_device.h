@@ -17,6 +17,7 @@ struct DevConfig {
     float minRange, maxRange, maxBearing;
     float stdRange, stdBearing;
     float clutterDensity, pd;
+    float clutterRate;          // CPHD only: Poisson clutter cardinality
     float birthWeight, birthNoiseFactor;
     float minFeatureWeight, minSeparation;
     float l, h, a, b;
@@ -88,10 +89,21 @@ struct UpdateArgs {
     unsigned* status;
     int* max_surv;
     int* max_map;
+    // CPHD variant (filter_type = 1): per-particle log cardinality, rows of cn_len floats indexed like the slabs
+    int cphd;
+    const float* cn_in;
+    float* cn_out;
+    int cn_len;
+    const float* lfact;         // log factorials 0..lfact_len-1 (initCphdConstants, src/phdfilter.cu.bak:421-425)
+    int lfact_len;
     DevConfig cfg;
 };
 
 size_t update_lds_bytes(int S, int C, int MM);
+size_t cphd_lds_bytes(int cn_len, int MM);   // extra LDS of the CPHD instantiation, carved after update_lds_bytes()
+// rows of `len` floats: dst[(c ? c[k] : k)] = src[b ? b[a ? a[k] : k] : (a ? a[k] : k)], k < n; skipped when a[k] < 0
+hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, const int* b, float* dst, size_t dst_stride,
+                            const int* c, int len, int n, hipStream_t st);
 int update_fuse_max_particles();
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);

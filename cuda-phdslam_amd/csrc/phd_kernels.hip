@@ -323,7 +323,8 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total; }
 int update_fuse_max_particles() { return PHD_T * 2; } // weights_body<PHD_T, 2> of the fused step
 
-enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */ };
+enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */,
+       CTR_NNEAR = 30 };
 
 // append one survivor; slot allocation is wave-aggregated (one LDS atomic per wave per call site)
 __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
@@ -1019,6 +1020,225 @@ __device__ __forceinline__ phd_pose predict_pose(const phd_pose& o, phd_ackerman
     return nw;
 }
 
+// ------------------------------------------------------------------------------------------
+// CPHD variant (filter_type = 1): the cardinality-dependent terms of one particle's update.
+//
+// The reference's HEAD has no runnable CPHD (kernels commented out, src/phdfilter.cu:701-779,
+// 1360-1591); the complete statement is src/phdfilter.cu.bak — cardinalityPredictKernel :518-545,
+// birth cardinality :779-790, computeEsfKernel :1191-1274, computePsiKernel :1282-1412,
+// cphdUpdateKernel :1420-1462 — whose decomposition and log-domain arithmetic this follows, with
+// the recursion of Vo, Vo & Cantoni (IEEE TSP 2007) stated correctly where the .bak is defective
+// (see oracle/cphd_cpu.c, the CPU statement this block is tested against; parity unpinned).
+//
+//   predicted cardinality   prior (*) Binomial(M, birthWeight)                  thread per n
+//   I_u[j]                  log sum_n p(n) P(n,j+u) Wq^(n-j-u) / W1^n            wave per j, lanes over n
+//   ESF jobs                e_j(Xi) and the M leave-one-out e_j(Xi \ m): one job per wave at a time,
+//                           the M-step log-domain recursion held in registers (lane <-> j),
+//                           neighbours by wave shuffles; O(M^3 / 512) lse2 per thread
+//   <Y0,p>, <Y1,p>, <Y1[Z\m],p>   wave reductions at the end of each job
+//   updated cardinality     thread per n
+// Outputs: L.logZ[m] (detection / birth weight = exp(lw - logZ[m])), the missed-detection factor
+// r1 = <Y1,p>/<Y0,p>, log <Y0,p> (particle log-weight increment), cn_out[0..cn_len).
+// ------------------------------------------------------------------------------------------
+struct CphdLds {
+    lds_f32 cnq, cnp, lfact, lxi, I0, I1, lD, efull, cnb, scal;
+};
+enum { CQ_LY0 = 0, CQ_LY1 = 1, CQ_R1 = 2 };
+
+__host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 off[10])
+{
+    const u32 cn = align16u(4u * (u32)cn_len);
+    const u32 lf = align16u(4u * (u32)((cn_len > MM + 1 ? cn_len : MM + 1) + 1));
+    const u32 mm = align16u(4u * (u32)(MM + 1));
+    u32 p = 0;
+    off[0] = p; p += cn;  // cnq
+    off[1] = p; p += cn;  // cnp
+    off[2] = p; p += lf;  // lfact
+    off[3] = p; p += mm;  // lxi
+    off[4] = p; p += mm;  // I0
+    off[5] = p; p += mm;  // I1
+    off[6] = p; p += mm;  // lD
+    off[7] = p; p += mm;  // efull
+    off[8] = p; p += mm;  // cnb
+    off[9] = p; p += 64u; // scal
+    return p;
+}
+
+size_t cphd_lds_bytes(int cn_len, int MM)
+{
+    u32 off[10];
+    return cphd_lds_layout(cn_len, MM, off);
+}
+
+__device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
+{
+    u32 off[10];
+    cphd_lds_layout(cn_len, MM, off);
+    CphdLds Q;
+    Q.cnq = (lds_f32)(base + off[0]); Q.cnp = (lds_f32)(base + off[1]); Q.lfact = (lds_f32)(base + off[2]);
+    Q.lxi = (lds_f32)(base + off[3]); Q.I0 = (lds_f32)(base + off[4]); Q.I1 = (lds_f32)(base + off[5]);
+    Q.lD = (lds_f32)(base + off[6]); Q.efull = (lds_f32)(base + off[7]); Q.cnb = (lds_f32)(base + off[8]);
+    Q.scal = (lds_f32)(base + off[9]);
+    return Q;
+}
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ __forceinline__ float lse2f(float a, float b)
+{
+    const float mx = a > b ? a : b, mn = a > b ? b : a;
+    return mx + log1pf(expf(mn - mx));
+}
+
+__device__ __forceinline__ float clamp_log(float x) { return x < -1e30f ? -1e30f : x; }
+
+__device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const DevConfig& cfg, int M, int MM, int cn_len,
+                                        const float* __restrict__ lfact_g, int lfact_len, const float* __restrict__ cn_prior,
+                                        float* __restrict__ cn_out, float w_all, float pdw, int tid)
+{
+#pragma clang fp contract(off)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int Nmax = cn_len - 1;
+    const float lam = cfg.clutterRate;
+    const float llam = safe_log(lam), lkap = safe_log(cfg.clutterDensity);
+    const float lbw = safe_log(cfg.birthWeight), l1bw = safe_log(1 - cfg.birthWeight);
+    const float W1 = w_all + (float)M * cfg.birthWeight;   // <1,v>: map + births
+    const float Wq = w_all - pdw;                          // <1-pD,v>: a birth is always detected
+    const float lW1 = clamp_log(safe_log(W1)), lWq = clamp_log(safe_log(Wq));
+    const float LOG0F = -FLT_MAX;
+
+    for (int i = tid; i < cn_len; i += PHD_T) Q.cnq[i] = cn_prior[i];
+    for (int i = tid; i < lfact_len; i += PHD_T) Q.lfact[i] = lfact_g[i];
+    __syncthreads();
+    // birth cardinality: Binomial(k; M, birthWeight) (.bak:779-790)
+    const int Kb = M < Nmax ? M : Nmax;
+    for (int k = tid; k <= Kb; k += PHD_T)
+        Q.cnb[k] = Q.lfact[M] - Q.lfact[k] - Q.lfact[M - k] + (float)k * lbw + (float)(M - k) * l1bw;
+    __syncthreads();
+    // predicted cardinality (.bak:518-545)
+    for (int n = tid; n <= Nmax; n += PHD_T) {
+        const int kmax = n < Kb ? n : Kb;
+        float mx = Q.cnb[0] + Q.cnq[n];
+        for (int k = 1; k <= kmax; ++k) mx = fmaxf(mx, Q.cnb[k] + Q.cnq[n - k]);
+        float s = 0.f;
+        for (int k = 0; k <= kmax; ++k) s += expf(Q.cnb[k] + Q.cnq[n - k] - mx);
+        Q.cnp[n] = safe_log(s) + mx;
+    }
+    __syncthreads();
+    // I_u[j], u = 0, 1: wave per j, lanes over n
+    for (int j = wave; j <= M; j += PHD_NW) {
+        float mx0 = LOG0F, mx1 = LOG0F;
+        for (int n = j + lane; n <= Nmax; n += 64) {
+            const float t0 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
+            mx0 = fmaxf(mx0, t0);
+            if (n >= j + 1) {
+                const float t1 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j - 1]) + (float)(n - j - 1) * lWq - (float)n * lW1;
+                mx1 = fmaxf(mx1, t1);
+            }
+        }
+        mx0 = wave_max_f(mx0); mx1 = wave_max_f(mx1);
+        float s0 = 0.f, s1 = 0.f;
+        for (int n = j + lane; n <= Nmax; n += 64) {
+            const float t0 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
+            s0 += expf(t0 - mx0);
+            if (n >= j + 1) {
+                const float t1 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j - 1]) + (float)(n - j - 1) * lWq - (float)n * lW1;
+                s1 += expf(t1 - mx1);
+            }
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        if (lane == 0) {
+            Q.I0[j] = (j <= Nmax) ? safe_log(s0) + mx0 : LOG0F;
+            Q.I1[j] = (j + 1 <= Nmax) ? safe_log(s1) + mx1 : LOG0F;
+        }
+    }
+    __syncthreads();
+    // ESF jobs (.bak:1224-1272): q < M leaves measurement q out, q == M is the full set.
+    // e[j], j = 1..M, lives in registers: lane l holds j = l + 1 + 64 c, c < 4 (M <= 256)
+    const int tiles = (M + 63) >> 6;
+    for (int q = wave; q <= M; q += PHD_NW) {
+        float ev[4] = {LOG0F, LOG0F, LOG0F, LOG0F};
+        int done = 0;
+        for (int m = 0; m < M; ++m) {
+            if (m == q) continue;
+            const float x = Q.lxi[m];
+            float prev[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                prev[c] = 0.f;
+                if (c < tiles) {
+                    const float up = __shfl_up(ev[c], 1);
+                    const float carry = (c > 0) ? __shfl(ev[c > 0 ? c - 1 : 0], 63) : 0.f; // e[0] = log 1
+                    prev[c] = (lane == 0) ? carry : up;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < tiles && lane + 64 * c <= done) ev[c] = lse2f(ev[c], x + prev[c]);
+            ++done;
+        }
+        // inner products with the n-sums
+        const int Ms = (q == M) ? M : M - 1;                  // size of this job's measurement set
+        float t0[5], t1[5];
+        float mx0 = LOG0F, mx1 = LOG0F;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            // c == 4: the j = 0 term (e_0 = 1), carried by lane 0
+            const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
+            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= Ms);
+            const float e = (c == 4) ? 0.f : ev[c < 4 ? c : 0];
+            const float kterm = (float)(Ms - j) * llam - lam;  // (Ms-j)! p_K(Ms-j), Poisson clutter (.bak:398-400)
+            t0[c] = ok ? e + Q.I0[ok ? j : 0] + kterm : LOG0F;
+            t1[c] = ok ? e + Q.I1[ok ? j : 0] + kterm : LOG0F;
+            mx0 = fmaxf(mx0, t0[c]); mx1 = fmaxf(mx1, t1[c]);
+        }
+        mx0 = wave_max_f(mx0); mx1 = wave_max_f(mx1);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
+            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= Ms);
+            if (ok) { s0 += expf(t0[c] - mx0); s1 += expf(t1[c] - mx1); }
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        if (q == M) {
+            if (lane == 0) { Q.scal[CQ_LY0] = safe_log(s0) + mx0; Q.scal[CQ_LY1] = safe_log(s1) + mx1; Q.efull[0] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
+        } else if (lane == 0) {
+            Q.lD[q] = safe_log(s1) + mx1;                      // log <Y1[Z \ q], p>
+        }
+    }
+    __syncthreads();
+    const float lY0 = Q.scal[CQ_LY0];
+    for (int m = tid; m < M; m += PHD_T) L.logZ[m] = -((llam - lkap) + Q.lD[m] - lY0);      // .bak:1434-1437
+    if (tid == 0) Q.scal[CQ_R1] = expf(Q.scal[CQ_LY1] - lY0);                               // .bak:1452-1455
+    // updated cardinality (.bak:1409-1411)
+    for (int n = tid; n <= Nmax; n += PHD_T) {
+        const int jmax = n < M ? n : M;
+        float mx = LOG0F;
+        for (int j = 0; j <= jmax; ++j) {
+            const float t = Q.efull[j] + ((float)(M - j) * llam - lam) + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq
+                            - (float)n * lW1;
+            mx = fmaxf(mx, t);
+        }
+        float s = 0.f;
+        for (int j = 0; j <= jmax; ++j) {
+            const float t = Q.efull[j] + ((float)(M - j) * llam - lam) + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq
+                            - (float)n * lW1;
+            s += expf(t - mx);
+        }
+        cn_out[n] = Q.cnp[n] + (safe_log(s) + mx) - lY0;
+    }
+    __syncthreads();
+}
+
 // (defined further down) the weights / nEff / resample routine, run by the last workgroup of a fused step
 template <int BT, int R, bool HANDOFF>
 __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn);
@@ -1026,11 +1246,13 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
 // ------------------------------------------------------------------------------------------
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
-template <bool STAMPS, bool FUSEW>
+template <bool STAMPS, bool FUSEW, bool CPHD>
 __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const Lds L = lds_carve((lds_u8)lds_raw, A.S_cap, A.cap, A.MM);
+    // CPHD instantiation: its arrays follow the common layout
+    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(A.S_cap, A.cap, A.MM).total, A.cn_len, A.MM) : CphdLds();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1097,6 +1319,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
 
     // ---- classification + per-feature EKF terms -----------------------------------------------
     float pdw_local = 0.f; // sum_j pd_j w_j (cardinality_predict, :2160)
+    float wall_local = 0.f; // CPHD: <1, map>
     {
         int n_in = 0, n_out0 = 0;
         for (int i0 = 0; i0 < n_map; i0 += PHD_T) {
@@ -1109,6 +1332,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                 w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
                 pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
                 ekf_terms(mx, my, pxx, pxy, pyy, pose, cfg, t);
+                wall_local += w;
                 // computeInRangeKernel, src/phdfilter.cu:1333-1346 (0.8/1.2 are double literals)
                 const float ab = fabsf(t.b);
                 if (t.r >= cfg.minRange && t.r <= cfg.maxRange && ab <= cfg.maxBearing) cls = 1;
@@ -1140,7 +1364,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             // straight into the survivor list: nearly-in-range features, which skip the update and join
             // the merge (:3242-3257), and the non-detection term of an in-range feature — the prior
             // with weight w(1-pd) (:2145-2148) — unless it is pruned (:2314)
-            {
+            if (CPHD) {
+                // the CPHD weights carry the factor <Y1,p>/<Y0,p>, known after the ESFs: emission is deferred;
+                // remember the nearly-in-range features at the top of out_idx
+                if (cls == 2) L.out_idx[cap - 1 - atomicAdd((int*)&L.ctr[CTR_NNEAR], 1)] = (u16)i;
+            } else {
                 const float wnd = w * (1 - t.pd);
                 const bool keep = (cls == 2) || (cls == 1 && !(wnd < cfg.minFeatureWeight));
                 const int slot = alloc_slots(keep, L.ctr);
@@ -1188,6 +1416,54 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     }
     __syncthreads();
     float lz_local = 0.f;
+    if (CPHD) {
+        // roots Xi_m = (lambda/kappa)(sum_j pd w_j g_jm + birthWeight) (.bak:1205-1222)
+        const float lrat = safe_log(cfg.clutterRate) - safe_log(cfg.clutterDensity);
+        for (int m = tid; m < M; m += PHD_T) {
+            float sum = L.zpart[0 * A.MM + m];
+#pragma unroll
+            for (int wv = 1; wv < PHD_NW; ++wv) sum += L.zpart[wv * A.MM + m];
+            Q.lxi[m] = safe_log(sum + cfg.birthWeight) + lrat;
+        }
+        const float pdw = block_sum(pdw_local, L.red, tid);
+        const float w_all = block_sum(wall_local, L.red, tid);
+        __syncthreads();
+        cphd_block(L, Q, cfg, M, A.MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
+                   A.cn_out + (size_t)p * A.cn_len, w_all, pdw, tid);
+        const float r1 = Q.scal[CQ_R1];
+        // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
+        for (int m0 = 0; m0 < M; m0 += PHD_T) {
+            const int m = m0 + tid;
+            const bool mv = m < M;
+            const float wb = (mv && L.zok[mv ? m : 0]) ? expf(safe_log(cfg.birthWeight) - L.logZ[mv ? m : 0]) : 0.f;
+            const bool keep = mv && !(wb < cfg.minFeatureWeight);
+            const int slot = alloc_slots(keep, L.ctr);
+            if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
+                                     L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m);
+        }
+        // missed detections of the in-range features: w (1 - pd) r1 (.bak:1445-1460)
+        for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
+            const int j = j0 + tid;
+            const bool jv = j < n_in;
+            const int i = L.f_idx[jv ? j : 0];
+            const float wnd = jv ? in[0 * cap + i] * (1 - cfg.pd) * r1 : 0.f;
+            const bool keep = jv && !(wnd < cfg.minFeatureWeight);
+            const int slot = alloc_slots(keep, L.ctr);
+            if (keep) store_survivor(L, slot, S_cap, wnd, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i], in[4 * cap + i],
+                                     in[5 * cap + i], j);
+        }
+        // nearly-in-range features (pD = 0): weight w r1, join the merge unpruned like HEAD (:3242-3257)
+        const int n_near = L.ctr[CTR_NNEAR];
+        for (int k0 = 0; k0 < n_near; k0 += PHD_T) {
+            const int k = k0 + tid;
+            const bool kv = k < n_near;
+            const int i = L.out_idx[cap - 1 - (kv ? k : 0)];
+            const int slot = alloc_slots(kv, L.ctr);
+            if (kv) store_survivor(L, slot, S_cap, in[0 * cap + i] * r1, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i],
+                                   in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i);
+        }
+        if (tid == 0) A.dlogw[p] = Q.scal[CQ_LY0];                                                   // .bak:2661-2667
+    } else {
     for (int m = tid; m < M; m += PHD_T) {
         float sum = L.zpart[0 * A.MM + m];
 #pragma unroll
@@ -1214,6 +1490,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             else A.dlogw[p] = dl;
         }
     }
+    } // !CPHD
     __syncthreads();
 
     STAMP(2);
@@ -1301,10 +1578,12 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // append the untouched out-of-range features (src/phdfilter.cu:3311-3318)
     int n_app = n_out0;
     if (k_out + n_app > cap) { n_app = cap - k_out; status |= PHD_STATUS_MAP_OVERFLOW; }
+    const float r_out = CPHD ? Q.scal[CQ_R1] : 1.f; // CPHD: undetected mass outside the field of view takes r1 too
     for (int i = tid; i < n_app; i += PHD_T) {
         const int s = L.out_idx[i];
+        out[k_out + i] = CPHD ? in[s] * r_out : in[s];
 #pragma unroll
-        for (int pl = 0; pl < 6; ++pl) out[pl * cap + k_out + i] = in[pl * cap + s];
+        for (int pl = 1; pl < 6; ++pl) out[pl * cap + k_out + i] = in[pl * cap + s];
     }
     if (tid == 0) {
         if (A.parent_reset) { // the output slab of particle p is its own again
@@ -1889,6 +2168,21 @@ __global__ void phd_gather_maps_kernel(const float* __restrict__ src, const int*
     if (pose_dst && threadIdx.x < 6) ((float*)&pose_dst[p])[threadIdx.x] = ((const float*)&pose_src[q])[threadIdx.x];
 }
 
+// rows of `len` floats (per-particle cardinality vectors): gather through up to two index maps, scatter through one
+__global__ void phd_copy_rows_kernel(const float* __restrict__ src, size_t src_stride, const int* __restrict__ a,
+                                     const int* __restrict__ b, float* __restrict__ dst, size_t dst_stride,
+                                     const int* __restrict__ c, int len)
+{
+    const int k = blockIdx.x;
+    int si = a ? a[k] : k;
+    if (si < 0) return;
+    if (b) si = b[si];
+    const int di = c ? c[k] : k;
+    const float* s = src + (size_t)si * src_stride;
+    float* d = dst + (size_t)di * dst_stride;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) d[i] = s[i];
+}
+
 __global__ void phd_fill_kernel(float* a, float v, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1909,9 +2203,11 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     static bool attr_set = false;
     if (!attr_set) {
         // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
-        const void* fns[3] = {(const void*)phd_update_merge_kernel<false, false>, (const void*)phd_update_merge_kernel<true, false>,
-                              (const void*)phd_update_merge_kernel<false, true>};
-        for (int k = 0; k < 3; ++k) {
+        const void* fns[4] = {(const void*)phd_update_merge_kernel<false, false, false>,
+                              (const void*)phd_update_merge_kernel<true, false, false>,
+                              (const void*)phd_update_merge_kernel<false, true, false>,
+                              (const void*)phd_update_merge_kernel<false, false, true>};
+        for (int k = 0; k < 4; ++k) {
             hipFuncAttributes fa;
             hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
             if (e != hipSuccess) return e;
@@ -1920,9 +2216,18 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         }
         attr_set = true;
     }
-    if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else hipLaunchKernelGGL((phd_update_merge_kernel<false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    if (a.cphd) hipLaunchKernelGGL((phd_update_merge_kernel<false, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else hipLaunchKernelGGL((phd_update_merge_kernel<false, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, const int* b, float* dst, size_t dst_stride,
+                            const int* c, int len, int n, hipStream_t st)
+{
+    if (n <= 0 || len <= 0) return hipSuccess;
+    hipLaunchKernelGGL(phd_copy_rows_kernel, dim3(n), dim3(256), 0, st, src, src_stride, a, b, dst, dst_stride, c, len);
     return hipGetLastError();
 }
 

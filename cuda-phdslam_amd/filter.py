@@ -181,6 +181,25 @@ class PhdFilter:
             check(rc, "phd_expected_map")
             return out[:n.value].copy()
 
+    # -- CPHD variant (filter_type = 1): per-particle log cardinality distributions --------------
+    def cardinalities(self):
+        k = lib().phd_cardinality_length(self._h)
+        out = np.zeros((self.n, k), np.float32)
+        check(lib().phd_get_cardinalities(self._h, ptr(out)), "phd_get_cardinalities")
+        return out
+
+    def set_cardinalities(self, cn):
+        k = lib().phd_cardinality_length(self._h)
+        cn = np.ascontiguousarray(cn, np.float32)
+        assert cn.shape == (self.n, k), (cn.shape, (self.n, k))
+        check(lib().phd_set_cardinalities(self._h, ptr(cn)), "phd_set_cardinalities")
+
+    def cardinality_estimate(self):
+        out = np.zeros(lib().phd_cardinality_length(self._h), np.float32)
+        who = C.c_int32(0)
+        check(lib().phd_cardinality_estimate(self._h, ptr(out), C.byref(who)), "phd_cardinality_estimate")
+        return out, who.value
+
     def gm_reduce(self, comps, min_distance):
         """reduceGaussianMixture (src/gm_reduce.cpp:57-134) of an arbitrary mixture on this filter's device"""
         comps = np.ascontiguousarray(comps, dtype=GAUSSIAN)

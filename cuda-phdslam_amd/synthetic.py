@@ -18,6 +18,7 @@ CONFIGS = {
     2: dict(N=256, G=64, M=32, clustered=False),
     3: dict(N=4096, G=256, M=64, clustered=True),
     4: dict(N=16384, G=256, M=64, clustered=True),
+    5: dict(N=4096, G=256, M=64, clustered=True),   # CPHD variant (filter_type = 1, max_cardinality 255)
 }
 
 SENSOR = dict(max_range=15.0, max_bearing=3.141593, std_range=0.25, std_bearing=0.008727)

@@ -226,6 +226,19 @@ int phd_expected_map(phd_filter* f, phd_gaussian2d* out, int capacity, int32_t* 
 int phd_gm_reduce(phd_filter* f, const phd_gaussian2d* in, int64_t n, float min_distance,
                   phd_gaussian2d* out, int capacity, int32_t* n_out);
 
+/* CPHD variant (config filter_type = 1; configs[4] of BASELINE.json).  The reference's HEAD carries
+ * the per-particle cardinality distributions (SynthSLAM::cardinalities, src/slamtypes.h:296, uniform
+ * start src/main.cpp:1140-1143) but its CPHD kernels are commented out; the recursion implemented
+ * here is the one of src/phdfilter.cu.bak:369-448,518-545,779-790,989-1503 (see DESIGN.md §CPHD for
+ * the exact statement and the deviations).  phd_update/phd_step_dev run the CPHD update when the
+ * filter was created with filter_type = 1; these calls expose the cardinality state:
+ * rows of phd_cardinality_length() = max_cardinality + 1 log-probabilities, particle-major. */
+int phd_cardinality_length(const phd_filter* f);
+int phd_get_cardinalities(phd_filter* f, float* out);
+int phd_set_cardinalities(phd_filter* f, const float* in);
+/* replaces: cn_estimate of recoverSlamState (src/main.cpp:360): the arg-max-weight particle's row */
+int phd_cardinality_estimate(phd_filter* f, float* out, int32_t* particle_out);
+
 /* The two halves of phd_expected_map for the multi-GPU host: the weighted concatenation of this
  * rank's maps as SoA planes in device memory ([6][total]: weight, mean x, mean y, cov xx, xy, yy;
  * valid until the next call), and the reduction of `total` Gaussians given as n_planes = 6

@@ -52,7 +52,7 @@ def test_compute_fails_loudly_without_a_gpu():
 
 def test_out_of_scope_configs_are_rejected():
     P = pkg()
-    for over in (dict(featureModel=2), dict(particleWeighting=1), dict(filterType=1), dict(motionType=0)):
+    for over in (dict(featureModel=2), dict(particleWeighting=1), dict(motionType=0)):
         with pytest.raises(P.PhdError) as e:
             P.PhdFilter(P.default_config(**over), n_particles=4)
         assert e.value.code == -4, over
