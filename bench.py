@@ -49,7 +49,12 @@ def cpu_baseline(w, cfg_id, budget_s):
     maps[:, :G] = w["maps"][:n]
     lw = O.normalize_weights(w["logw"][:n])
 
+    cn0 = np.full((n, 256), -np.log(256.0), np.float32)      # config 5: uniform cardinality rows (src/main.cpp:1142)
+
     def one(threads):
+        if cfg_id == 5:
+            return O.cphd_step(w["poses"][:n], lw, maps, w["sizes"][:n], cap, 0.05, 2.0, w["noise"][0][:n], w["z"][0], ocfg,
+                               20.0, cn0, w["uniform"][0], True, n_threads=threads)
         return O.step(w["poses"][:n], lw, maps, w["sizes"][:n], cap, 0.05, 2.0, w["noise"][0][:n], w["z"][0], ocfg,
                       w["uniform"][0], True, n_threads=threads)
 
@@ -75,7 +80,7 @@ def cpu_baseline(w, cfg_id, budget_s):
             break
     steps_per_s = k / el * (n / N)  # a slice of n particles is n/N of a step
     return {"value": steps_per_s, "unit": "steps/s", "cores": best_t, "kind": "port",
-            "sample": "%d steps of the oracle (oracle/scphd_cpu.c, -O3 -march=native, OpenMP over particles, %d threads "
+            "sample": "%d steps of the oracle (oracle/scphd_cpu.c + cphd_cpu.c, -O3 -march=native, OpenMP over particles, %d threads "
                       "— the fastest of 1..%d visible) on %d of the %d particles of config %d (%dx%dx%d), %.1f s"
                       % (k, best_t, avail, n, N, cfg_id, N, G, M, el)}
 
@@ -85,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (2 or 3)")
+    ap.add_argument("--config", type=int, default=2, help="workload: 2, 3 (BASELINE.json configs[1], [2]) or 5 (configs[4], CPHD)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -111,6 +116,9 @@ def main():
     # every rank's shard: the same distribution, a different seed
     w = S.make_workload(N, G, M, seed=0x5EED0000 + args.config + 1000 * rank, clustered=c["clustered"])
     cfg = P.default_config(n_particles=N * world)
+    if args.config == 5:                                      # BASELINE.json configs[4]: the CPHD variant
+        cfg.filterType = 1
+        cfg.maxCardinality = 255
     # one stream for everything: the filter's kernels and (N > 1) the RCCL collectives torch enqueues
     ts = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(ts)
@@ -150,11 +158,17 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # HIP events on the stream the kernels run on (torch's current stream IS the filter's stream), bracketing
+    # the timed region: GPU time of the K steps without the per-launch event pairs of the pass below
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(ts)
     for _ in range(args.steps):
         step()
+    ev1.record(ts)
     sync()
     elapsed = time.perf_counter() - t0
+    gpu_region_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,7 +189,15 @@ def main():
     if rank == 0:
         b_step = S.algorithmic_bytes(N, G, M)               # per launch of the update+merge kernel (one shard)
         b_min = N * (28 * G + 28 * G + 32)                   # compulsory traffic
-        ker_s = avg_ms[P._lib.K_UPDATE_MERGE] * 1e-3
+        if args.config == 5:                                 # CPHD: + one cardinality row read and written per particle
+            b_step += N * 2 * 4 * 256
+            b_min += N * 2 * 4 * 256
+        pair_ms = avg_ms[P._lib.K_UPDATE_MERGE]              # event pair around every launch (separate pass)
+        one_launch_per_step = world == 1 and cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0
+        # when the whole step is ONE launch of the dominant kernel (fused step), the events bracketing the timed
+        # region give its average duration directly (launch-to-launch), free of the pair's marker packets
+        ker_ms = gpu_region_ms / args.steps if one_launch_per_step else pair_ms
+        ker_s = ker_ms * 1e-3
         achieved = b_step / ker_s / 1e9 if ker_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh writes the
         # summary; rocprofv3 cannot run inside the bench) — null if this configuration was not profiled
@@ -206,7 +228,8 @@ def main():
                        "max_survivors": st["max_survivors"], "max_map": st["max_map"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * avg_ms[P._lib.K_UPDATE_MERGE],
+                         "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
+                         "kernel_avg_us_event_pairs": 1e3 * pair_ms, "gpu_region_ms_per_step": gpu_region_ms / args.steps,
                          "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
                          "other_kernels_avg_us": {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT],
                                                   "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}},

@@ -137,6 +137,8 @@ SYMBOLS = {
     "phd_load_timestamps": (_i, [C.c_char_p, _vp, _sz, _vp]),
     "phd_load_trajectory": (_i, [C.c_char_p, _vp, _sz, _vp]),
     "phd_write_state_log7": (_i, [C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i]),
+    "phd_write_state_log_cphd": (_i, [C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i]),
+    "phd_write_state_log7_cphd": (_i, [C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i]),
 }
 
 _lib = None

@@ -65,6 +65,15 @@ void upload(const SynthSLAM& p)
         concat.insert(concat.end(), p.maps_static[i].begin(), p.maps_static[i].end());
     }
     CHK(phd_set_maps(g_filter, concat.data(), sizes.data()));
+    if (config.filterType == 1) {
+        // CPHD: SynthSLAM::cardinalities (src/slamtypes.h:296), rows of maxCardinality+1 log-probabilities;
+        // rows the caller never sized start uniform (src/main.cpp:1140-1143)
+        const int k = phd_cardinality_length(g_filter);
+        std::vector<float> cn((size_t)p.n_particles * k, -logf((float)k));
+        for (int i = 0; i < p.n_particles; ++i)
+            if ((int)p.cardinalities[i].size() == k) std::copy(p.cardinalities[i].begin(), p.cardinalities[i].end(), cn.begin() + (size_t)i * k);
+        CHK(phd_set_cardinalities(g_filter, cn.data()));
+    }
 }
 
 void download(SynthSLAM& p, bool maps)
@@ -81,6 +90,12 @@ void download(SynthSLAM& p, bool maps)
     for (int i = 0; i < p.n_particles; ++i) {
         p.maps_static[i].assign(concat.begin() + off, concat.begin() + off + sizes[i]);
         off += sizes[i];
+    }
+    if (config.filterType == 1) {
+        const int k = phd_cardinality_length(g_filter);
+        std::vector<float> cn((size_t)p.n_particles * k);
+        CHK(phd_get_cardinalities(g_filter, cn.data()));
+        for (int i = 0; i < p.n_particles; ++i) p.cardinalities[i].assign(cn.begin() + (size_t)i * k, cn.begin() + (size_t)(i + 1) * k);
     }
 }
 } // namespace

@@ -106,6 +106,7 @@ int main(int argc, char** argv)
     std::vector<int32_t> ridx(n_max);
     std::vector<phd_gaussian2d> map(opt.map_capacity), eap(4 * (size_t)opt.map_capacity);
     std::vector<phd_ackerman_noise> noise((size_t)n_max);
+    std::vector<float> cn_est;
     std::string timefile = out_dir + "/loopTime.log";
     printf("STARTING SIMULATION\n");
     size_t z_idx = 0, c_idx = 0;
@@ -209,15 +210,27 @@ int main(int argc, char** argv)
             }
         }
         CHK(phd_get_particles(f, poses.data(), logw.data()));
+        if (config.filterType == 1) {                                                        // cn_estimate (:360)
+            cn_est.resize((size_t)phd_cardinality_length(f));
+            CHK(phd_cardinality_estimate(f, cn_est.data(), nullptr));
+        }
         // nEff test and resampling (:1281-1297)
         int32_t did = 0;
         CHK(phd_resample_if_needed(f, randu01(), M > 0, &did, ridx.data()));
+        const bool cphd = config.filterType == 1;
         if (log7) {
             // weights and poses are those of the step (before resampling); a resample that shrinks a grown
             // (shotgun) particle set yields fewer parent indices than particles: the rest is marked -1
             if (did) for (int i = phd_n_particles(f); i < n_cur; ++i) ridx[i] = -1;
-            CHK(phd_write_state_log7(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), ridx.data(),
-                                     n_cur, config.maxCardinality, kshot));
+            if (cphd)
+                CHK(phd_write_state_log7_cphd(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(),
+                                              ridx.data(), n_cur, kshot, cn_est.data(), (int)cn_est.size()));
+            else
+                CHK(phd_write_state_log7(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(),
+                                         ridx.data(), n_cur, config.maxCardinality, kshot));
+        } else if (cphd) {
+            CHK(phd_write_state_log_cphd(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), n_cur,
+                                         cn_est.data(), (int)cn_est.size()));
         } else {
             CHK(phd_write_state_log(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), n_cur,
                                     config.maxCardinality));

@@ -368,8 +368,8 @@ extern "C" int phd_load_trajectory(const char* path, phd_pose* out, size_t capac
 // state_estimate%05d.log — the 5-line consumer contract (README:31-39; python/batch_analyze.py:16-24;
 // python/plot_phdslam.py:205-226): default operator<< float formatting, space separated, trailing space
 // ---------------------------------------------------------------------------------------------
-extern "C" int phd_write_state_log(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
-                                   const float* log_weights, const phd_pose* poses, int n_particles, int max_cardinality)
+static int write_log5(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                      const float* log_weights, const phd_pose* poses, int n_particles, int max_cardinality, const float* cn)
 {
     if (!e) return host_fail(PHD_ERR_INVALID_ARG, "null pose");
     std::ostringstream name;
@@ -393,17 +393,35 @@ extern "C" int phd_write_state_log(const char* dir, int step, const phd_pose* e,
         s << poses[n].px << " " << poses[n].py << " " << poses[n].ptheta << " " << poses[n].vx << " " << poses[n].vy << " "
           << poses[n].vtheta << " ";
     s << std::endl;
-    for (int n = 0; n < max_cardinality + 1; ++n) s << "0 "; // PHD: zeros (:942-949)
+    for (int n = 0; n < max_cardinality + 1; ++n) { // PHD: zeros, CPHD: cn_estimate (:942-949)
+        if (cn) s << cn[n] << " ";
+        else s << "0 ";
+    }
     s << std::endl;
     return s.good() ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name.str());
+}
+
+extern "C" int phd_write_state_log(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                                   const float* log_weights, const phd_pose* poses, int n_particles, int max_cardinality)
+{
+    return write_log5(dir, step, e, map, n_map, log_weights, poses, n_particles, max_cardinality, nullptr);
+}
+
+// CPHD (filter_type = 1): the last line carries cn_estimate[0..max_cardinality] (src/main.cpp:944-949)
+extern "C" int phd_write_state_log_cphd(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                                        const float* log_weights, const phd_pose* poses, int n_particles,
+                                        const float* cn_estimate, int cn_len)
+{
+    if (!cn_estimate || cn_len < 1) return host_fail(PHD_ERR_INVALID_ARG, "null cardinality estimate");
+    return write_log5(dir, step, e, map, n_map, log_weights, poses, n_particles, cn_len - 1, cn_estimate);
 }
 
 // HEAD's writeLog (src/main.cpp:848-954): 7 lines — pose / static map / dynamic map (empty: static
 // model) / log-weights / poses / resample indices / cardinality — opened in APPEND mode; at t = 0 the
 // weights and poses are repeated nPredictParticles times (:901-934).
-extern "C" int phd_write_state_log7(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
-                                    const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
-                                    int n_particles, int max_cardinality, int n_predict_particles)
+static int write_log7(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                      const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
+                      int n_particles, int max_cardinality, int n_predict_particles, const float* cn)
 {
     if (!e) return host_fail(PHD_ERR_INVALID_ARG, "null pose");
     std::ostringstream name;
@@ -433,7 +451,27 @@ extern "C" int phd_write_state_log7(const char* dir, int step, const phd_pose* e
     s << std::endl;
     for (int n = 0; n < n_particles; ++n) s << (resample_idx ? resample_idx[n] : n) << " ";
     s << std::endl;
-    for (int n = 0; n < max_cardinality + 1; ++n) s << "0 ";
+    for (int n = 0; n < max_cardinality + 1; ++n) {
+        if (cn) s << cn[n] << " ";
+        else s << "0 ";
+    }
     s << std::endl;
     return s.good() ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name.str());
+}
+
+extern "C" int phd_write_state_log7(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                                    const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
+                                    int n_particles, int max_cardinality, int n_predict_particles)
+{
+    return write_log7(dir, step, e, map, n_map, log_weights, poses, resample_idx, n_particles, max_cardinality,
+                      n_predict_particles, nullptr);
+}
+
+extern "C" int phd_write_state_log7_cphd(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
+                                         const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
+                                         int n_particles, int n_predict_particles, const float* cn_estimate, int cn_len)
+{
+    if (!cn_estimate || cn_len < 1) return host_fail(PHD_ERR_INVALID_ARG, "null cardinality estimate");
+    return write_log7(dir, step, e, map, n_map, log_weights, poses, resample_idx, n_particles, cn_len - 1,
+                      n_predict_particles, cn_estimate);
 }

@@ -350,6 +350,15 @@ int phd_write_state_log7(const char* dir, int step, const phd_pose* expected_pos
                          int n_map, const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
                          int n_particles, int max_cardinality, int n_predict_particles);
 
+/* the same two writers with filter_type = CPHD: the cardinality line carries cn_estimate[0..cn_len)
+ * instead of zeros (src/main.cpp:944-949) */
+int phd_write_state_log_cphd(const char* dir, int step, const phd_pose* expected_pose, const phd_gaussian2d* map,
+                             int n_map, const float* log_weights, const phd_pose* poses, int n_particles,
+                             const float* cn_estimate, int cn_len);
+int phd_write_state_log7_cphd(const char* dir, int step, const phd_pose* expected_pose, const phd_gaussian2d* map,
+                              int n_map, const float* log_weights, const phd_pose* poses, const int32_t* resample_idx,
+                              int n_particles, int n_predict_particles, const float* cn_estimate, int cn_len);
+
 /* replaces: the state_estimate%05d.log contract (README:31-39; writer src/main.cpp:848-954):
  * 5 lines: pose / map (weight mx my c0 c1 c2 c3) / log-weights / poses / cardinality zeros */
 int phd_write_state_log(const char* dir, int step, const phd_pose* expected_pose,

@@ -254,3 +254,53 @@ int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map,
     free(cls); free(f_in); free(f_near); free(f_out); free(births); free(pre); free(pd); free(slab); free(flag);
     return nm;
 }
+
+/* whole CPHD filter step over fixed-capacity slabs, OpenMP over particles — o_step with the CPHD
+ * update and the per-particle cardinality rows cn[p*cn_len ..) (the timed CPU baseline of config 5);
+ * the rows follow the resampled particles (copy_particles, src/slamtypes.h:313-333) */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int o_cphd_step(o_pose* poses, float* logw, o_gaussian* maps, int32_t* sizes, int n_particles, int cap,
+                float alpha, float v_encoder, const float* noise, const o_meas* z, int M,
+                const o_config* cfg, float clutter_rate, const float* cn, int cn_len, double uniform, int force_resample,
+                o_gaussian* maps_out, int32_t* sizes_out, float* cn_out, int32_t* idx_out, float* neff_out, int n_threads)
+{
+    int overflow = 0;
+    o_predict_ackerman(poses, n_particles, alpha, v_encoder, noise, cfg);
+    float* dlogw = (float*)malloc(sizeof(float) * n_particles);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        size_t tmp_n = (size_t)cap * (M + 2) + M + 1;
+        o_gaussian* tmp = (o_gaussian*)malloc(sizeof(o_gaussian) * tmp_n);
+#pragma omp for schedule(dynamic, 4)
+        for (int p = 0; p < n_particles; p++) {
+            int nm = o_cphd_update_particle(&poses[p], maps + (size_t)p * cap, sizes[p], z, M, cfg, clutter_rate,
+                                            cn + (size_t)p * cn_len, cn_len, tmp, &dlogw[p], cn_out + (size_t)p * cn_len,
+                                            NULL, NULL, NULL, NULL);
+            if (nm > cap) {
+#pragma omp atomic write
+                overflow = 1;
+                nm = cap;
+            }
+            memcpy(maps_out + (size_t)p * cap, tmp, sizeof(o_gaussian) * nm);
+            sizes_out[p] = nm;
+        }
+        free(tmp);
+    }
+    o_normalize_weights(logw, dlogw, n_particles);
+    float neff = o_neff(logw, n_particles);
+    if (neff_out) *neff_out = neff;
+    if (force_resample || (neff <= cfg->resampleThresh && M > 0)) {
+        o_resample(logw, n_particles, &uniform, 1, n_particles, idx_out);
+    } else {
+        for (int i = 0; i < n_particles; i++) idx_out[i] = i;
+    }
+    free(dlogw);
+    return overflow ? -1 : 0;
+}

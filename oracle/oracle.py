@@ -90,6 +90,8 @@ def lib():
         L.o_cphd_terms.argtypes = [vp, i32, vp, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         L.o_cphd_update_particle.restype = i32
         L.o_cphd_update_particle.argtypes = [vp, vp, i32, vp, i32, cp, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.o_cphd_step.restype = i32
+        L.o_cphd_step.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, cp, f32, vp, i32, f64, i32, vp, vp, vp, vp, vp, i32]
         L.o_argmax_weight.restype = i32; L.o_argmax_weight.argtypes = [vp, i32]
         L.o_step.restype = i32
         L.o_step.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, cp, f64, i32, vp, vp, vp, vp, i32]
@@ -291,4 +293,22 @@ def step(poses, logw, maps, sizes, cap, alpha, v_encoder, noise, z, cfg, uniform
                       _p(z), len(z), C.byref(cfg), float(uniform), int(force_resample),
                       _p(maps_out), _p(sizes_out), _p(idx), _p(ne), int(n_threads))
     return dict(rc=rc, poses=poses, logw=logw, maps=maps_out.reshape(N, cap), sizes=sizes_out, idx=idx,
+                neff=float(ne[0]))
+
+
+def cphd_step(poses, logw, maps, sizes, cap, alpha, v_encoder, noise, z, cfg, clutter_rate, cn, uniform, force_resample,
+              n_threads=0):
+    """o_step with the CPHD update; cn: [N, cn_len] log cardinalities.  Inputs are copied."""
+    poses = _c(poses, POSE).copy(); logw = _c(logw, np.float32).copy()
+    maps = _c(maps, GAUSSIAN).reshape(-1); sizes = _c(sizes, np.int32)
+    cn = _c(cn, np.float32)
+    N = len(poses)
+    z = _c(z, MEAS)
+    noise = None if noise is None else _c(noise, np.float32)
+    maps_out = np.zeros(N * cap, GAUSSIAN); sizes_out = np.zeros(N, np.int32); cn_out = np.zeros_like(cn)
+    idx = np.zeros(N, np.int32); ne = np.zeros(1, np.float32)
+    rc = lib().o_cphd_step(_p(poses), _p(logw), _p(maps), _p(sizes), N, cap, float(alpha), float(v_encoder), _p(noise),
+                           _p(z), len(z), C.byref(cfg), float(clutter_rate), _p(cn), cn.shape[1], float(uniform),
+                           int(force_resample), _p(maps_out), _p(sizes_out), _p(cn_out), _p(idx), _p(ne), int(n_threads))
+    return dict(rc=rc, poses=poses, logw=logw, maps=maps_out.reshape(N, cap), sizes=sizes_out, cn=cn_out, idx=idx,
                 neff=float(ne[0]))

@@ -124,6 +124,11 @@ int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map,
                            o_gaussian* map_out, float* dlogw, float* cn_out,
                            o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out);
 
+int o_cphd_step(o_pose* poses, float* logw, o_gaussian* maps, int32_t* sizes, int n_particles, int cap,
+                float alpha, float v_encoder, const float* noise, const o_meas* z, int M,
+                const o_config* cfg, float clutter_rate, const float* cn, int cn_len, double uniform, int force_resample,
+                o_gaussian* maps_out, int32_t* sizes_out, float* cn_out, int32_t* idx_out, float* neff_out, int n_threads);
+
 /* src/phdfilter.cu:3741-3755 + src/device_math.cuh:549-558 */
 void o_normalize_weights(float* logw, const float* dlogw, int n);
 /* src/main.cpp:1281-1284 */

@@ -112,8 +112,9 @@ def python_loop(cfg_path, seed, capacity=256):
             if eap is not None and not (cfg.mapEstimate & 1):
                 gm = eap
             poses, lw = f.get_particles()
+            cn = f.cardinality_estimate()[0] if cfg.filterType == 1 else None
             did, idx = f.resample_if_needed(rng.randu01(), had_measurements=len(zz) > 0)
-            recs.append(dict(pose=e, map=gm, lw=lw, poses=poses, did=did, idx=idx, n=len(lw), M=len(zz), eap=eap))
+            recs.append(dict(pose=e, map=gm, lw=lw, poses=poses, did=did, idx=idx, n=len(lw), M=len(zz), eap=eap, cn=cn))
             f.status()
     return recs
 
@@ -200,3 +201,20 @@ def test_expected_map_in_the_log(tmp_path):
         e = np.array(open(os.path.join(d, "o3", "expected_map%05d.log" % n)).read().split(), float).reshape(-1, 7)
         assert len(e) == len(rec["eap"]) and np.allclose(e[:, 0], rec["eap"]["weight"], rtol=2e-5)
         assert np.array_equal(rec["eap"], recs[n]["eap"])            # same filter run, same EAP map
+
+
+def test_cphd_driver(tmp_path):
+    """filter_type = 1: the driver runs the CPHD variant; the log's last line is cn_estimate (src/main.cpp:944-949)"""
+    d = str(tmp_path)
+    cfg_path = write_data(d, 5, 5, dict(n_particles=20, filter_type=1, max_cardinality=63, resample_threshold=0.6))
+    recs = python_loop(cfg_path, 12)
+    assert all(r["cn"] is not None for r in recs)
+    run_driver(cfg_path, os.path.join(d, "o"), 12)
+    compare(recs, os.path.join(d, "o"))
+    for n, rec in enumerate(recs):
+        last = open(os.path.join(d, "o", "state_estimate%05d.log" % n)).read().split("\n")[4]
+        cn = np.array(last.split(), float)
+        assert len(cn) == 64 and np.allclose(cn, rec["cn"], rtol=2e-5, atol=1e-6)
+    # the cardinality estimate is a normalised distribution that moved away from the uniform start
+    pn = np.exp(recs[-1]["cn"].astype(np.float64))
+    assert abs(pn.sum() - 1) < 5e-3 and pn.max() > 0.1

@@ -11,10 +11,12 @@ python bench.py > gpurun_out/bench_cfg2_$tag.json 2> gpurun_out/bench_cfg2_$tag.
 cat gpurun_out/bench_cfg2_$tag.json
 python bench.py --config 3 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out/bench_cfg3_$tag.json 2> gpurun_out/bench_cfg3_$tag.err
 cat gpurun_out/bench_cfg3_$tag.json
+python bench.py --config 5 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out/bench_cfg5_$tag.json 2> gpurun_out/bench_cfg5_$tag.err
+cat gpurun_out/bench_cfg5_$tag.json
 python tools/phase_profile.py 2 3 > gpurun_out/phase_$tag.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-for cfg in 2 3; do
-  st=400; [ $cfg = 3 ] && st=50
+for cfg in 2 3 5; do
+  st=400; [ $cfg != 2 ] && st=50
   rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --steps $st --warmup 40 --cpu-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag.log 2>&1
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_cfg${cfg}_$tag.csv && head -5 $f
