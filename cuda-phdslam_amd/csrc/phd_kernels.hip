@@ -85,10 +85,95 @@ __device__ __forceinline__ u64 lanemask_lt()
     return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 }
 
+// ------------------------------------------------------------------------------------------
+// cross-lane exchange on the VALU.  hipcc lowers __shfl_xor / __shfl_up to ds_bpermute_b32 (an LDS-pipe
+// round trip of ~100 cycles plus the address VGPR); for the partners the sorts, scans and reductions
+// need, gfx950 has single-issue VALU forms (encodings verified on hardware by tools/dpp_probe.hip):
+//   lane ^ 1, ^ 2   DPP quad_perm            lane ^ 16   v_permlane16_swap + select
+//   lane ^ 4        two DPP row_ror (banks)  lane ^ 32   v_permlane32_swap + select
+//   lane ^ 8        DPP row_ror:8            lane - 1    DPP wave_shr:1
+// Same values as the shuffles they replace, bit for bit.
+// ------------------------------------------------------------------------------------------
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int BANKS>
+__device__ __forceinline__ u32 dpp_mov(u32 old, u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, BANKS, false);
+}
+
+template <int OFF>
+__device__ __forceinline__ u32 xor_lane_c(u32 v)
+{
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "power of two < 64");
+    if (OFF == 1) return dpp_mov<0xB1, 0xF>(v, v);                 // quad_perm [1,0,3,2]
+    if (OFF == 2) return dpp_mov<0x4E, 0xF>(v, v);                 // quad_perm [2,3,0,1]
+    if (OFF == 4) return dpp_mov<0x124, 0xA>(dpp_mov<0x12C, 0x5>(v, v), v); // row_ror:12 into banks 0,2; row_ror:4 into 1,3
+    if (OFF == 8) return dpp_mov<0x128, 0xF>(v, v);                // row_ror:8
+    if (OFF == 16) {
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (__lane_id() & 16) ? r.x : r.y;
+    }
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (__lane_id() & 32) ? r.x : r.y;
+}
+
+// off: wave-uniform power of two in 1..32 (a scalar branch selects the encoding)
+__device__ __forceinline__ u32 xor_lane(u32 v, int off)
+{
+    switch (off) {
+    case 1: return xor_lane_c<1>(v);
+    case 2: return xor_lane_c<2>(v);
+    case 4: return xor_lane_c<4>(v);
+    case 8: return xor_lane_c<8>(v);
+    case 16: return xor_lane_c<16>(v);
+    default: return xor_lane_c<32>(v);
+    }
+}
+__device__ __forceinline__ float xor_lane(float v, int off) { return __uint_as_float(xor_lane(__float_as_uint(v), off)); }
+__device__ __forceinline__ int xor_lane(int v, int off) { return (int)xor_lane((u32)v, off); }
+__device__ __forceinline__ double xor_lane(double v, int off)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u64 r = ((u64)xor_lane((u32)(b >> 32), off) << 32) | xor_lane((u32)b, off);
+    return __longlong_as_double((long long)r);
+}
+template <int OFF> __device__ __forceinline__ float xor_lane_c(float v) { return __uint_as_float(xor_lane_c<OFF>(__float_as_uint(v))); }
+
+// value of lane - 1 (lane 0 keeps its own), = __shfl_up(v, 1)
+__device__ __forceinline__ u32 lane_up1(u32 v) { return dpp_mov<0x138, 0xF>(v, v); }
+__device__ __forceinline__ float lane_up1(float v) { return __uint_as_float(lane_up1(__float_as_uint(v))); }
+__device__ __forceinline__ int lane_up1(int v) { return (int)lane_up1((u32)v); }
+
+// inclusive prefix sum over the wave (integers: any association is exact): Kogge-Stone inside each row of
+// 16 lanes with DPP row_shr (zero fill), then the row totals through row_bcast15 / row_bcast31
+template <int CTRL, int ROWS>
+__device__ __forceinline__ u32 dpp_zero(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, true);
+}
+__device__ __forceinline__ u32 wave_incl_scan(u32 v)
+{
+    v += dpp_zero<0x111, 0xF>(v); v += dpp_zero<0x112, 0xF>(v);
+    v += dpp_zero<0x114, 0xF>(v); v += dpp_zero<0x118, 0xF>(v);
+    v += dpp_zero<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    v += dpp_zero<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u64 wave_incl_scan(u64 v)
+{
+#define PHD_SCAN64_STEP(CTRL, ROWS)                                                                      \
+    v += ((u64)dpp_zero<CTRL, ROWS>((u32)(v >> 32)) << 32) | dpp_zero<CTRL, ROWS>((u32)v);
+    PHD_SCAN64_STEP(0x111, 0xF) PHD_SCAN64_STEP(0x112, 0xF) PHD_SCAN64_STEP(0x114, 0xF) PHD_SCAN64_STEP(0x118, 0xF)
+    PHD_SCAN64_STEP(0x142, 0xA) PHD_SCAN64_STEP(0x143, 0xC)
+#undef PHD_SCAN64_STEP
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    v += xor_lane_c<32>(v); v += xor_lane_c<16>(v); v += xor_lane_c<8>(v);
+    v += xor_lane_c<4>(v); v += xor_lane_c<2>(v); v += xor_lane_c<1>(v);
     return v;
 }
 
@@ -335,7 +420,7 @@ __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
         int base = 0;
         if ((u64)(1ull << __lane_id()) == (bal & (~bal + 1))) base = atomicAdd((int*)&ctr[CTR_NSURV], __popcll(bal));
         int leader = __builtin_ctzll(bal);
-        base = __shfl(base, leader);
+        base = __builtin_amdgcn_readlane(base, leader);
         slot = base + __popcll(bal & lanemask_lt());
     }
     return slot;
@@ -389,6 +474,7 @@ __device__ __forceinline__ void reg_sort_desc64(u32 (&khi)[E], u32 (&klo)[E], u3
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const int i = tid * E + e;
+                    // (ds_bpermute on purpose: this sort runs when the kernel is VALU-bound, the LDS pipe is idle)
                     const u32 ohi = __shfl_xor(khi[e], lm), olo = __shfl_xor(klo[e], lm), op = __shfl_xor(pay[e], lm);
                     const u64 mine = ((u64)khi[e] << 32) | klo[e];
                     const u64 oth = ((u64)ohi << 32) | olo;
@@ -855,12 +941,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 cmask[e] = merged ? 0ull : 1ull; // reuse as the keep flag of the compaction
             }
             // exclusive scan of `kept` over the workgroup (wave shuffle scan + wave totals)
-            int incl = kept;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off) incl += v;
-            }
+            const int incl = (int)wave_incl_scan((u32)kept);
             if (lane == 63) L.ctr[CTR_TMP + wave] = incl;
             __syncthreads();
             int woff = 0, total = 0;
@@ -1085,7 +1166,7 @@ __device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
 __device__ __forceinline__ float wave_max_f(float v)
 {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, xor_lane(v, off));
     return v;
 }
 
@@ -1160,28 +1241,52 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     __syncthreads();
     // ESF jobs (.bak:1224-1272): q < M leaves measurement q out, q == M is the full set.
     // e[j], j = 1..M, lives in registers: lane l holds j = l + 1 + 64 c, c < 4 (M <= 256)
+    // The recursion e_j <- e_j + xi_m e_{j-1} runs in the linear domain (as in HEAD's commented version,
+    // src/phdfilter.cu:1555-1579); e_j spans hundreds of decades, so each value is a float mantissa with
+    // its own integer exponent (m 2^k, m in [0.5,1) or 0): align with v_ldexp, renormalise with v_frexp —
+    // exact operations around one correctly rounded multiply and add, so the device and the oracle agree
+    // bit for bit, at a tenth of the cost of a log-sum-exp per step.
     const int tiles = (M + 63) >> 6;
+    const int XF_ZERO_K = -(1 << 28);
     for (int q = wave; q <= M; q += PHD_NW) {
-        float ev[4] = {LOG0F, LOG0F, LOG0F, LOG0F};
+        float em[4] = {0.f, 0.f, 0.f, 0.f};
+        int ek[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
         int done = 0;
         for (int m = 0; m < M; ++m) {
             if (m == q) continue;
             const float x = Q.lxi[m];
-            float prev[4];
+            float pm[4];
+            int pk[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                prev[c] = 0.f;
+                pm[c] = 0.f; pk[c] = XF_ZERO_K;
                 if (c < tiles) {
-                    const float up = __shfl_up(ev[c], 1);
-                    const float carry = (c > 0) ? __shfl(ev[c > 0 ? c - 1 : 0], 63) : 0.f; // e[0] = log 1
-                    prev[c] = (lane == 0) ? carry : up;
+                    const float up_m = lane_up1(em[c]);
+                    const int up_k = lane_up1(ek[c]);
+                    const float cm = (c > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(em[c > 0 ? c - 1 : 0]), 63))
+                                             : 0.5f;                                       // e_0 = 1 = 0.5 * 2^1
+                    const int ck = (c > 0) ? __builtin_amdgcn_readlane(ek[c > 0 ? c - 1 : 0], 63) : 1;
+                    pm[c] = (lane == 0) ? cm : up_m;
+                    pk[c] = (lane == 0) ? ck : up_k;
                 }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 64 * c <= done) ev[c] = lse2f(ev[c], x + prev[c]);
+                if (c < tiles && lane + 64 * c <= done) {
+                    const float tm = pm[c] * x;
+                    const int tk = pk[c];
+                    const int k = ek[c] > tk ? ek[c] : tk;
+                    const int da = ek[c] - k, db = tk - k;
+                    const float s = (da < -64 ? 0.f : ldexpf(em[c], da)) + (db < -64 ? 0.f : ldexpf(tm, db));
+                    int dk = 0;
+                    em[c] = frexpf(s, &dk);
+                    ek[c] = k + dk;
+                }
             ++done;
         }
+        float ev[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ev[c] = em[c] > 0.f ? logf(em[c]) + (float)ek[c] * 0.69314718f : LOG0F;
         // inner products with the n-sums
         const int Ms = (q == M) ? M : M - 1;                  // size of this job's measurement set
         float t0[5], t1[5];
@@ -1411,19 +1516,19 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const float e = __expf(lw);                                                               // :2205
             acc += (mvalid && j < n_in) ? e : 0.f;
         }
-        for (int off = Mp; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+        for (int off = Mp; off < 64; off <<= 1) acc += xor_lane(acc, off);
         if (js == 0 && m < M) L.zpart[wave * A.MM + m] = acc;
     }
     __syncthreads();
     float lz_local = 0.f;
     if (CPHD) {
         // roots Xi_m = (lambda/kappa)(sum_j pd w_j g_jm + birthWeight) (.bak:1205-1222)
-        const float lrat = safe_log(cfg.clutterRate) - safe_log(cfg.clutterDensity);
+        const float rat = cfg.clutterRate / cfg.clutterDensity;
         for (int m = tid; m < M; m += PHD_T) {
             float sum = L.zpart[0 * A.MM + m];
 #pragma unroll
             for (int wv = 1; wv < PHD_NW; ++wv) sum += L.zpart[wv * A.MM + m];
-            Q.lxi[m] = safe_log(sum + cfg.birthWeight) + lrat;
+            Q.lxi[m] = (sum + cfg.birthWeight) * rat;
         }
         const float pdw = block_sum(pdw_local, L.red, tid);
         const float w_all = block_sum(wall_local, L.red, tid);
@@ -1679,12 +1784,7 @@ __device__ __forceinline__ u64 block_scan_u64(u64* q, int m, u64 carry, u64* s_w
     const int lo = tid * per, hi = (lo + per < m) ? lo + per : m;
     u64 local = 0;
     for (int e = lo; e < hi; ++e) local += q[e];
-    u64 incl = local;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const u64 v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-    }
+    const u64 incl = wave_incl_scan(local);
     if (lane == 63) s_wtot[wave] = incl;
     __syncthreads();
     u64 woff = carry, total = carry;
@@ -1707,7 +1807,7 @@ __device__ __forceinline__ float block_reduce_w(float v, float* sc, int tid, boo
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        float o = __shfl_xor(v, off);
+        float o = xor_lane(v, off);
         v = is_max ? fmaxf(v, o) : (v + o);
     }
     __syncthreads();
@@ -1808,8 +1908,8 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(besti, off);
+            const double ob = xor_lane(best, off);
+            const int oi = xor_lane(besti, off);
             if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
         if ((tid & 63) == 0) { s_bestv[tid >> 6] = best; s_besti[tid >> 6] = besti; }
@@ -1977,8 +2077,8 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
         if (overflow) { // uniform
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(besti, off);
+                const double ob = xor_lane(best, off);
+                const int oi = xor_lane(besti, off);
                 if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
             }
             if ((tid & 63) == 0) { s_bestv[tid >> 6] = best; s_besti[tid >> 6] = besti; }
@@ -2102,8 +2202,8 @@ __global__ __launch_bounds__(PHD_WT) void phd_state_kernel(const phd_pose* __res
     // arg-max with ties to the lowest index (strict '>' scan in the reference)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off);
-        const int oi = __shfl_xor(besti, off);
+        const float ob = xor_lane(best, off);
+        const int oi = xor_lane(besti, off);
         if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
     if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_besti[tid >> 6] = besti; }

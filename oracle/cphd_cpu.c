@@ -64,17 +64,36 @@ void o_cphd_log_factorials(float* lfact, int n)                      /* initCphd
     for (int k = 1; k < n; k++) lfact[k] = lfact[k - 1] + o_safe_log((float)k);
 }
 
-/* ESF of the roots lxi[0..M) without root `skip` (skip < 0: none), log domain: e[0..M] (.bak:1224-1272) */
-static void esf_log(const float* lxi, int M, int skip, float* e)
+/* ESF of the roots xi[0..M) without root `skip` (skip < 0: none): e_j <- e_j + xi_m e_{j-1}, the
+ * recursion of computeEsfKernel (.bak:1224-1272; linear domain as in HEAD's commented version,
+ * src/phdfilter.cu:1555-1579).  e_j spans hundreds of decades, so each value is a float mantissa with
+ * a separate integer exponent (m * 2^k, m in [0.5,1) or 0); additions align with ldexpf and renormalise
+ * with frexpf — exact operations around one correctly rounded add and multiply, hence identical on
+ * every IEEE machine.  Output: log e_j, j = 0..M. */
+#define XF_ZERO_K (-(1 << 28))
+static void esf_xf(const float* xi, int M, int skip, float* le)
 {
-    e[0] = 0;
-    for (int j = 1; j <= M; j++) e[j] = LOG0;
+    float* em = (float*)malloc(sizeof(float) * (M + 1));
+    int* ek = (int*)malloc(sizeof(int) * (M + 1));
+    em[0] = 0.5f; ek[0] = 1;                                         /* e_0 = 1 */
+    for (int j = 1; j <= M; j++) { em[j] = 0; ek[j] = XF_ZERO_K; }
     int done = 0;
     for (int m = 0; m < M; m++) {
         if (m == skip) continue;
-        for (int j = done + 1; j >= 1; j--) e[j] = lse2(e[j], lxi[m] + e[j - 1]);
+        for (int j = done + 1; j >= 1; j--) {
+            const float tm = em[j - 1] * xi[m];
+            const int tk = ek[j - 1];
+            const int k = ek[j] > tk ? ek[j] : tk;
+            const int da = ek[j] - k, db = tk - k;
+            const float s = (da < -64 ? 0.f : ldexpf(em[j], da)) + (db < -64 ? 0.f : ldexpf(tm, db));
+            int dk = 0;
+            em[j] = frexpf(s, &dk);
+            ek[j] = k + dk;
+        }
         done++;
     }
+    for (int j = 0; j <= M; j++) le[j] = em[j] > 0 ? logf(em[j]) + (float)ek[j] * 0.69314718f : LOG0;
+    free(em); free(ek);
 }
 
 /*
@@ -116,8 +135,9 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
         for (int k = 0; k <= kmax; k++) t[k] = cnb[k] + cn_prior[n - k];
         cnp[n] = lse_n(t, kmax + 1);
     }
-    /* 2. roots (.bak:1205-1222) */
-    for (int m = 0; m < M; m++) lxi[m] = o_safe_log(S[m] + birth_weight) + llam - lkap;
+    /* 2. roots Xi_m = (lambda/kappa)(S_m + w_b) (.bak:1205-1222) */
+    const float rat = clutter_rate / clutter_density;
+    for (int m = 0; m < M; m++) lxi[m] = (S[m] + birth_weight) * rat;
     /* 3. inner products over n that do not depend on the measurements:
      *    I_u[j] = log sum_n p(n) P(n, j+u) Wq^(n-j-u) / W1^n */
     for (int j = 0; j <= M; j++) {
@@ -131,14 +151,14 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
         I1[j] = lse_n(t, c);
     }
     /* 4. full ESF, <Y0,p>, <Y1,p>;  (M-j)! p_K(M-j) = lambda^(M-j) e^-lambda for Poisson clutter (.bak:398-400) */
-    esf_log(lxi, M, -1, e);
+    esf_xf(lxi, M, -1, e);
     for (int j = 0; j <= M; j++) t[j] = e[j] + I0[j] + ((float)(M - j) * llam - clutter_rate);
     const float lY0 = lse_n(t, M + 1);
     for (int j = 0; j <= M; j++) t[j] = e[j] + I1[j] + ((float)(M - j) * llam - clutter_rate);
     const float lY1 = lse_n(t, M + 1);
     /* 5. leave-one-out ESFs and <Y1[Z\m],p> */
     for (int m = 0; m < M; m++) {
-        esf_log(lxi, M, m, em);
+        esf_xf(lxi, M, m, em);
         for (int j = 0; j <= M - 1; j++) t[j] = em[j] + I1[j] + ((float)(M - 1 - j) * llam - clutter_rate);
         const float lD = lse_n(t, M);
         lz[m] = -((llam - lkap) + lD - lY0);
