@@ -120,6 +120,7 @@ struct phd_filter {
     float* cn[2] = {nullptr, nullptr};
     float* d_lfact = nullptr;
     int lfact_len = 0;
+    float2* cphd_scratch = nullptr; // [n_max][MM][MM]: rows of the ESF backward sweep (phd_kernels.hip, cphd_block)
     GmWorkspace* gm = nullptr; // expected-map / gm_reduce workspace, created on first use
     int gm_rounds = 0;
 
@@ -249,6 +250,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     if (f->cphd) {
         A(dalloc(&f->cn[0], (size_t)f->n_max * f->cn_len)); A(dalloc(&f->cn[1], (size_t)f->n_max * f->cn_len));
         A(dalloc(&f->d_lfact, f->lfact_len));
+        A(dalloc(&f->cphd_scratch, (size_t)f->n_max * f->MM * f->MM));
     }
     if (e != hipSuccess) {
         phd_destroy(f);
@@ -300,7 +302,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
     hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
-    hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact);
+    hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     gm_workspace_destroy(f->gm);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
@@ -691,6 +693,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         a.cn_len = f->cn_len;
         a.lfact = f->d_lfact;
         a.lfact_len = f->lfact_len;
+        a.cphd_scratch = f->cphd_scratch;
     }
     a.cfg = f->dcfg;
     int free_pose = 0;

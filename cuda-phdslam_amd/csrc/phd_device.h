@@ -96,6 +96,7 @@ struct UpdateArgs {
     int cn_len;
     const float* lfact;         // log factorials 0..lfact_len-1 (initCphdConstants, src/phdfilter.cu.bak:421-425)
     int lfact_len;
+    float2* cphd_scratch;       // [n][MM][MM] (mantissa, exponent) rows of the ESF backward sweep
     DevConfig cfg;
 };
 

@@ -140,6 +140,10 @@ __device__ __forceinline__ double xor_lane(double v, int off)
 }
 template <int OFF> __device__ __forceinline__ float xor_lane_c(float v) { return __uint_as_float(xor_lane_c<OFF>(__float_as_uint(v))); }
 
+// value of lane + 1 (lane 63 keeps its own), = __shfl_down(v, 1)
+__device__ __forceinline__ u32 lane_down1(u32 v) { return dpp_mov<0x130, 0xF>(v, v); }
+__device__ __forceinline__ float lane_down1(float v) { return __uint_as_float(lane_down1(__float_as_uint(v))); }
+__device__ __forceinline__ int lane_down1(int v) { return (int)lane_down1((u32)v); }
 // value of lane - 1 (lane 0 keeps its own), = __shfl_up(v, 1)
 __device__ __forceinline__ u32 lane_up1(u32 v) { return dpp_mov<0x138, 0xF>(v, v); }
 __device__ __forceinline__ float lane_up1(float v) { return __uint_as_float(lane_up1(__float_as_uint(v))); }
@@ -1165,8 +1169,14 @@ __device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
 
 __device__ __forceinline__ float wave_max_f(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, xor_lane(v, off));
+    v = fmaxf(v, xor_lane_c<32>(v)); v = fmaxf(v, xor_lane_c<16>(v)); v = fmaxf(v, xor_lane_c<8>(v));
+    v = fmaxf(v, xor_lane_c<4>(v)); v = fmaxf(v, xor_lane_c<2>(v)); v = fmaxf(v, xor_lane_c<1>(v));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = max(v, (int)xor_lane_c<32>((u32)v)); v = max(v, (int)xor_lane_c<16>((u32)v)); v = max(v, (int)xor_lane_c<8>((u32)v));
+    v = max(v, (int)xor_lane_c<4>((u32)v)); v = max(v, (int)xor_lane_c<2>((u32)v)); v = max(v, (int)xor_lane_c<1>((u32)v));
     return v;
 }
 
@@ -1180,7 +1190,8 @@ __device__ __forceinline__ float clamp_log(float x) { return x < -1e30f ? -1e30f
 
 __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const DevConfig& cfg, int M, int MM, int cn_len,
                                         const float* __restrict__ lfact_g, int lfact_len, const float* __restrict__ cn_prior,
-                                        float* __restrict__ cn_out, float w_all, float pdw, int tid)
+                                        float* __restrict__ cn_out, float2* __restrict__ T_scratch, float w_all, float pdw,
+                                        int tid)
 {
 #pragma clang fp contract(off)
     const int lane = tid & 63, wave = tid >> 6;
@@ -1207,97 +1218,204 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
         float mx = Q.cnb[0] + Q.cnq[n];
         for (int k = 1; k <= kmax; ++k) mx = fmaxf(mx, Q.cnb[k] + Q.cnq[n - k]);
         float s = 0.f;
-        for (int k = 0; k <= kmax; ++k) s += expf(Q.cnb[k] + Q.cnq[n - k] - mx);
+        for (int k = 0; k <= kmax; ++k) s += __expf(Q.cnb[k] + Q.cnq[n - k] - mx);
         Q.cnp[n] = safe_log(s) + mx;
     }
     __syncthreads();
-    // I_u[j], u = 0, 1: wave per j, lanes over n
-    for (int j = wave; j <= M; j += PHD_NW) {
-        float mx0 = LOG0F, mx1 = LOG0F;
-        for (int n = j + lane; n <= Nmax; n += 64) {
-            const float t0 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
-            mx0 = fmaxf(mx0, t0);
-            if (n >= j + 1) {
-                const float t1 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j - 1]) + (float)(n - j - 1) * lWq - (float)n * lW1;
-                mx1 = fmaxf(mx1, t1);
+    // I_u[j] = log sum_n p(n) P(n,j+u) Wq^(n-j-u) / W1^n.  Since P(n,j+1) Wq^(n-j-1) is the u = 0 term of j+1,
+    // I_1[j] = I_0[j+1] (the same floating-point expression): one family J[j] = I_0[j], j = 0..M+1.
+    // Wave per j, lanes over n; the terms stay in registers between the max and the sum pass (n <= 1023).
+    for (int j = wave; j <= M + 1; j += PHD_NW) {
+        float tv[16];
+        float mx = LOG0F;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int n = j + lane + 64 * c;
+            tv[c] = LOG0F;
+            if (n <= Nmax) {
+                tv[c] = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
+                mx = fmaxf(mx, tv[c]);
             }
         }
-        mx0 = wave_max_f(mx0); mx1 = wave_max_f(mx1);
-        float s0 = 0.f, s1 = 0.f;
-        for (int n = j + lane; n <= Nmax; n += 64) {
-            const float t0 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
-            s0 += expf(t0 - mx0);
-            if (n >= j + 1) {
-                const float t1 = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j - 1]) + (float)(n - j - 1) * lWq - (float)n * lW1;
-                s1 += expf(t1 - mx1);
-            }
-        }
-        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        mx = wave_max_f(mx);
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (j + lane + 64 * c <= Nmax) sacc += __expf(tv[c] - mx);
+        sacc = wave_sum(sacc);
         if (lane == 0) {
-            Q.I0[j] = (j <= Nmax) ? safe_log(s0) + mx0 : LOG0F;
-            Q.I1[j] = (j + 1 <= Nmax) ? safe_log(s1) + mx1 : LOG0F;
+            const float v = (j <= Nmax) ? safe_log(sacc) + mx : LOG0F;
+            if (j <= M) Q.I0[j] = v;
+            if (j >= 1) Q.I1[j - 1] = v;
         }
     }
     __syncthreads();
-    // ESF jobs (.bak:1224-1272): q < M leaves measurement q out, q == M is the full set.
-    // e[j], j = 1..M, lives in registers: lane l holds j = l + 1 + 64 c, c < 4 (M <= 256)
-    // The recursion e_j <- e_j + xi_m e_{j-1} runs in the linear domain (as in HEAD's commented version,
-    // src/phdfilter.cu:1555-1579); e_j spans hundreds of decades, so each value is a float mantissa with
-    // its own integer exponent (m 2^k, m in [0.5,1) or 0): align with v_ldexp, renormalise with v_frexp —
-    // exact operations around one correctly rounded multiply and add, so the device and the oracle agree
-    // bit for bit, at a tenth of the cost of a log-sum-exp per step.
+    // ESFs (.bak:1224-1272).  The .bak runs one full recursion per left-out measurement (O(M^3)); here
+    //   e(Xi \ m) = P_m (*) S_{m+1}   (ESFs of the roots before and after m), so
+    //   <Y1[Z\m],p> = sum_a P_m[a] T_{m+1}[a],  T_{m+1}[a] = sum_b S_{m+1}[b] c_{a+b},  c_j = exp(I1[j]) lambda^(M-1-j) e^-lambda
+    // and T obeys the same one-root recursion run backwards, T_m[a] = T_{m+1}[a] + xi_m T_{m+1}[a+1], T_M = c:
+    // O(M^2), all terms positive.  One wave: a backward sweep that parks the rows T_{m+1}[0..m] in HBM scratch
+    // (M^2 x 8 B per particle — what 288 GB are for; they come back out of L2), then a forward sweep that
+    // carries P in registers and takes one dot product per measurement.  Values span hundreds of decades, so
+    // each is a float mantissa with its own integer exponent (m 2^k): align with v_ldexp, renormalise with
+    // v_frexp — exact operations around one correctly rounded multiply and add (the oracle does the same).
     const int tiles = (M + 63) >> 6;
     const int XF_ZERO_K = -(1 << 28);
-    for (int q = wave; q <= M; q += PHD_NW) {
-        float em[4] = {0.f, 0.f, 0.f, 0.f};
-        int ek[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
-        int done = 0;
-        for (int m = 0; m < M; ++m) {
-            if (m == q) continue;
+    if (wave == 0) {
+        float tm[4];
+        int tk[4];
+        // T_M[a] = c_a, a = lane + 64 c
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int a = lane + 64 * c;
+            tm[c] = 0.f; tk[c] = XF_ZERO_K;
+            if (c < tiles && a < M) {
+                const float Lg = Q.I1[a] + ((float)(M - 1 - a) * llam - lam);
+                if (Lg > -1e30f) {
+                    const double t = (double)Lg * 1.4426950408889634;
+                    const double kf = ceil(t);
+                    tm[c] = (float)exp2(t - kf);
+                    tk[c] = (int)kf;
+                }
+                T_scratch[(size_t)(M - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
+            }
+        }
+        for (int m = M - 1; m >= 1; --m) {
             const float x = Q.lxi[m];
-            float pm[4];
-            int pk[4];
+            float nm[4];
+            int nk[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                pm[c] = 0.f; pk[c] = XF_ZERO_K;
+                nm[c] = 0.f; nk[c] = XF_ZERO_K;
                 if (c < tiles) {
-                    const float up_m = lane_up1(em[c]);
-                    const int up_k = lane_up1(ek[c]);
-                    const float cm = (c > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(em[c > 0 ? c - 1 : 0]), 63))
-                                             : 0.5f;                                       // e_0 = 1 = 0.5 * 2^1
-                    const int ck = (c > 0) ? __builtin_amdgcn_readlane(ek[c > 0 ? c - 1 : 0], 63) : 1;
-                    pm[c] = (lane == 0) ? cm : up_m;
-                    pk[c] = (lane == 0) ? ck : up_k;
+                    const float dn_m = lane_down1(tm[c]);
+                    const int dn_k = lane_down1(tk[c]);
+                    const float cm = (c < 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tm[c < 3 ? c + 1 : 3]), 0)) : 0.f;
+                    const int ck = (c < 3) ? __builtin_amdgcn_readlane(tk[c < 3 ? c + 1 : 3], 0) : XF_ZERO_K;
+                    nm[c] = (lane == 63) ? cm : dn_m;
+                    nk[c] = (lane == 63) ? ck : dn_k;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int a = lane + 64 * c;
+                if (c < tiles && a <= m - 1) {
+                    const float pr = nm[c] * x;
+                    const int k = tk[c] > nk[c] ? tk[c] : nk[c];
+                    const float s = ldexpf(tm[c], tk[c] - k) + ldexpf(pr, nk[c] - k);
+                    int dk = 0;
+                    tm[c] = frexpf(s, &dk);
+                    tk[c] = k + dk;
+                    T_scratch[(size_t)(m - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
+                }
+            }
+        }
+        __threadfence(); // the rows are read back by other lanes of this wave
+        // forward: P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
+        float pm[4] = {0.f, 0.f, 0.f, 0.f};
+        int pk[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
+        // the rows come back from L2 / HBM: keep PF of them in flight ahead of the step that uses them
+        constexpr int PF = 4;
+        float2 rbuf[PF][4], r0buf[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const float2* row = T_scratch + (size_t)u * M;
+            r0buf[u] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rbuf[u][c] = make_float2(0.f, 0.f);
+            if (u < M) {
+                r0buf[u] = row[0];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < tiles && lane + 1 + 64 * c <= u) rbuf[u][c] = row[lane + 1 + 64 * c];
+            }
+        }
+        for (int m0 = 0; m0 < M; m0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int m = m0 + u;
+            if (m < M) {
+            const float x = Q.lxi[m];
+            // D_m = T_{m+1}[0] + sum_{a=1..m} P_m[a] T_{m+1}[a]
+            float qm[5];
+            int qk[5];
+            int kmax = 2 * XF_ZERO_K;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int a = lane + 1 + 64 * c;
+                qm[c] = 0.f; qk[c] = 2 * XF_ZERO_K;
+                if (c < tiles && a <= m) {
+                    const float2 t = rbuf[u][c];
+                    qm[c] = pm[c] * t.x;
+                    qk[c] = pk[c] + __float_as_int(t.y);
+                }
+                kmax = max(kmax, qk[c]);
+            }
+            {
+                const float2 t0 = r0buf[u];
+                qm[4] = (lane == 0) ? t0.x : 0.f;
+                qk[4] = (lane == 0) ? __float_as_int(t0.y) : 2 * XF_ZERO_K;
+                kmax = max(kmax, qk[4]);
+            }
+            if (m + PF < M) { // refill this slot with the row PF steps ahead
+                const float2* row = T_scratch + (size_t)(m + PF) * M;
+                r0buf[u] = row[0];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < tiles && lane + 1 + 64 * c <= m + PF) rbuf[u][c] = row[lane + 1 + 64 * c];
+            }
+            kmax = wave_max_i(kmax);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) s += ldexpf(qm[c], qk[c] - kmax);
+            s = wave_sum(s);
+            if (lane == 0) {
+                int dk = 0;
+                const float dm = frexpf(s, &dk);
+                Q.lD[m] = dm > 0.f ? logf(dm) + (float)(kmax + dk) * 0.69314718f : LOG0F;   // log <Y1[Z \ m], p>
+            }
+            // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
+            float um[4];
+            int uk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                um[c] = 0.f; uk[c] = XF_ZERO_K;
+                if (c < tiles) {
+                    const float up_m = lane_up1(pm[c]);
+                    const int up_k = lane_up1(pk[c]);
+                    const float cm = (c > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm[c > 0 ? c - 1 : 0]), 63))
+                                             : 0.5f;                                       // P[0] = 1 = 0.5 * 2^1
+                    const int ck = (c > 0) ? __builtin_amdgcn_readlane(pk[c > 0 ? c - 1 : 0], 63) : 1;
+                    um[c] = (lane == 0) ? cm : up_m;
+                    uk[c] = (lane == 0) ? ck : up_k;
                 }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 64 * c <= done) {
-                    const float tm = pm[c] * x;
-                    const int tk = pk[c];
-                    const int k = ek[c] > tk ? ek[c] : tk;
-                    const int da = ek[c] - k, db = tk - k;
-                    const float s = (da < -64 ? 0.f : ldexpf(em[c], da)) + (db < -64 ? 0.f : ldexpf(tm, db));
+                if (c < tiles && lane + 64 * c <= m) {
+                    const float pr = um[c] * x;
+                    const int k = pk[c] > uk[c] ? pk[c] : uk[c];
+                    const float s2 = ldexpf(pm[c], pk[c] - k) + ldexpf(pr, uk[c] - k);
                     int dk = 0;
-                    em[c] = frexpf(s, &dk);
-                    ek[c] = k + dk;
+                    pm[c] = frexpf(s2, &dk);
+                    pk[c] = k + dk;
                 }
-            ++done;
+            } // m < M
         }
+        }
+        // full set: e_j = P_M[j]; <Y0,p> and <Y1,p>
         float ev[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ev[c] = em[c] > 0.f ? logf(em[c]) + (float)ek[c] * 0.69314718f : LOG0F;
-        // inner products with the n-sums
-        const int Ms = (q == M) ? M : M - 1;                  // size of this job's measurement set
+        for (int c = 0; c < 4; ++c) ev[c] = pm[c] > 0.f ? logf(pm[c]) + (float)pk[c] * 0.69314718f : LOG0F;
         float t0[5], t1[5];
         float mx0 = LOG0F, mx1 = LOG0F;
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             // c == 4: the j = 0 term (e_0 = 1), carried by lane 0
             const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
-            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= Ms);
+            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
             const float e = (c == 4) ? 0.f : ev[c < 4 ? c : 0];
-            const float kterm = (float)(Ms - j) * llam - lam;  // (Ms-j)! p_K(Ms-j), Poisson clutter (.bak:398-400)
+            const float kterm = (float)(M - j) * llam - lam;   // (M-j)! p_K(M-j), Poisson clutter (.bak:398-400)
             t0[c] = ok ? e + Q.I0[ok ? j : 0] + kterm : LOG0F;
             t1[c] = ok ? e + Q.I1[ok ? j : 0] + kterm : LOG0F;
             mx0 = fmaxf(mx0, t0[c]); mx1 = fmaxf(mx1, t1[c]);
@@ -1307,18 +1425,14 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
-            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= Ms);
+            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
             if (ok) { s0 += expf(t0[c] - mx0); s1 += expf(t1[c] - mx1); }
         }
         s0 = wave_sum(s0); s1 = wave_sum(s1);
-        if (q == M) {
-            if (lane == 0) { Q.scal[CQ_LY0] = safe_log(s0) + mx0; Q.scal[CQ_LY1] = safe_log(s1) + mx1; Q.efull[0] = 0.f; }
+        if (lane == 0) { Q.scal[CQ_LY0] = safe_log(s0) + mx0; Q.scal[CQ_LY1] = safe_log(s1) + mx1; Q.efull[0] = 0.f; }
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
-        } else if (lane == 0) {
-            Q.lD[q] = safe_log(s1) + mx1;                      // log <Y1[Z \ q], p>
-        }
+        for (int c = 0; c < 4; ++c)
+            if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
     }
     __syncthreads();
     const float lY0 = Q.scal[CQ_LY0];
@@ -1337,7 +1451,7 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
         for (int j = 0; j <= jmax; ++j) {
             const float t = Q.efull[j] + ((float)(M - j) * llam - lam) + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq
                             - (float)n * lW1;
-            s += expf(t - mx);
+            s += __expf(t - mx);
         }
         cn_out[n] = Q.cnp[n] + (safe_log(s) + mx) - lY0;
     }
@@ -1534,7 +1648,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
         cphd_block(L, Q, cfg, M, A.MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
-                   A.cn_out + (size_t)p * A.cn_len, w_all, pdw, tid);
+                   A.cn_out + (size_t)p * A.cn_len, A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid);
         const float r1 = Q.scal[CQ_R1];
         // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
         for (int m0 = 0; m0 < M; m0 += PHD_T) {

@@ -41,10 +41,40 @@
 
 static float clampl(float x) { return x < -1e30f ? -1e30f : x; }
 
-static float lse2(float a, float b)
+/* 1: leave-one-out ESFs by M separate recursions (the .bak's O(M^3) structure) instead of the O(M^2)
+ * prefix/suffix form — kept as an independent check of the latter (tests/test_cphd_oracle.py) */
+static int g_reference_esf = 0;
+void o_cphd_set_reference_esf(int on) { g_reference_esf = on; }
+
+/* A positive number spanning hundreds of decades: float mantissa, separate integer exponent (m 2^k).
+ * Additions align with ldexpf and renormalise with frexpf — exact operations around one correctly
+ * rounded multiply and add, hence identical on every IEEE machine (the device uses v_ldexp / v_frexp). */
+typedef struct { float m; int k; } xf;
+#define XF_ZERO_K (-(1 << 28))
+
+static xf xf_axpy(xf a, xf b, float x)                              /* a + x b */
 {
-    const float mx = a > b ? a : b, mn = a > b ? b : a;
-    return mx + log1pf(expf(mn - mx));
+    const float tm = b.m * x;
+    const int k = a.k > b.k ? a.k : b.k;
+    const float s = ldexpf(a.m, a.k - k) + ldexpf(tm, b.k - k);
+    int dk = 0;
+    xf r;
+    r.m = frexpf(s, &dk);
+    r.k = k + dk;
+    return r;
+}
+
+static float xf_log(xf a) { return a.m > 0 ? logf(a.m) + (float)a.k * 0.69314718f : LOG0; }
+
+static xf xf_from_log(float L)
+{
+    xf r;
+    if (!(L > -1e30f)) { r.m = 0; r.k = XF_ZERO_K; return r; }
+    const double t = (double)L * 1.4426950408889634;
+    const double kf = ceil(t);
+    r.m = (float)exp2(t - kf);                                       /* in (0.5, 1] */
+    r.k = (int)kf;
+    return r;
 }
 
 /* log sum exp of t[0..n) (two passes: max, then the sum in index order) */
@@ -70,30 +100,19 @@ void o_cphd_log_factorials(float* lfact, int n)                      /* initCphd
  * a separate integer exponent (m * 2^k, m in [0.5,1) or 0); additions align with ldexpf and renormalise
  * with frexpf — exact operations around one correctly rounded add and multiply, hence identical on
  * every IEEE machine.  Output: log e_j, j = 0..M. */
-#define XF_ZERO_K (-(1 << 28))
 static void esf_xf(const float* xi, int M, int skip, float* le)
 {
-    float* em = (float*)malloc(sizeof(float) * (M + 1));
-    int* ek = (int*)malloc(sizeof(int) * (M + 1));
-    em[0] = 0.5f; ek[0] = 1;                                         /* e_0 = 1 */
-    for (int j = 1; j <= M; j++) { em[j] = 0; ek[j] = XF_ZERO_K; }
+    xf* e = (xf*)malloc(sizeof(xf) * (M + 1));
+    e[0].m = 0.5f; e[0].k = 1;                                       /* e_0 = 1 */
+    for (int j = 1; j <= M; j++) { e[j].m = 0; e[j].k = XF_ZERO_K; }
     int done = 0;
     for (int m = 0; m < M; m++) {
         if (m == skip) continue;
-        for (int j = done + 1; j >= 1; j--) {
-            const float tm = em[j - 1] * xi[m];
-            const int tk = ek[j - 1];
-            const int k = ek[j] > tk ? ek[j] : tk;
-            const int da = ek[j] - k, db = tk - k;
-            const float s = (da < -64 ? 0.f : ldexpf(em[j], da)) + (db < -64 ? 0.f : ldexpf(tm, db));
-            int dk = 0;
-            em[j] = frexpf(s, &dk);
-            ek[j] = k + dk;
-        }
+        for (int j = done + 1; j >= 1; j--) e[j] = xf_axpy(e[j], e[j - 1], xi[m]);
         done++;
     }
-    for (int j = 0; j <= M; j++) le[j] = em[j] > 0 ? logf(em[j]) + (float)ek[j] * 0.69314718f : LOG0;
-    free(em); free(ek);
+    for (int j = 0; j <= M; j++) le[j] = xf_log(e[j]);
+    free(e);
 }
 
 /*
@@ -156,12 +175,44 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
     const float lY0 = lse_n(t, M + 1);
     for (int j = 0; j <= M; j++) t[j] = e[j] + I1[j] + ((float)(M - j) * llam - clutter_rate);
     const float lY1 = lse_n(t, M + 1);
-    /* 5. leave-one-out ESFs and <Y1[Z\m],p> */
-    for (int m = 0; m < M; m++) {
-        esf_xf(lxi, M, m, em);
-        for (int j = 0; j <= M - 1; j++) t[j] = em[j] + I1[j] + ((float)(M - 1 - j) * llam - clutter_rate);
-        const float lD = lse_n(t, M);
-        lz[m] = -((llam - lkap) + lD - lY0);
+    /* 5. <Y1[Z\m],p> = sum_j e_j(Xi \ m) c_j,  c_j = exp(I1[j]) lambda^(M-1-j) e^-lambda. */
+    if (g_reference_esf) {
+        /* the .bak's way (:1247-1272): one full ESF recursion per left-out measurement, O(M^3) */
+        for (int m = 0; m < M; m++) {
+            esf_xf(lxi, M, m, em);
+            for (int j = 0; j <= M - 1; j++) t[j] = em[j] + I1[j] + ((float)(M - 1 - j) * llam - clutter_rate);
+            const float lD = lse_n(t, M);
+            lz[m] = -((llam - lkap) + lD - lY0);
+        }
+    } else {
+        /* O(M^2): e(Xi \ m) = P_m (*) S_{m+1} (ESFs of the roots before and after m), hence
+         *   <Y1[Z\m],p> = sum_a P_m[a] T_{m+1}[a],   T_{m+1}[a] = sum_b S_{m+1}[b] c_{a+b},
+         * and T obeys the same one-root recursion run backwards: T_m[a] = T_{m+1}[a] + xi_m T_{m+1}[a+1],
+         * T_M = c.  All terms are positive: no cancellation.  (The device kernel does exactly this.) */
+        xf* T = (xf*)malloc(sizeof(xf) * (size_t)M * M);             /* row m holds T_{m+1}[0..m] */
+        xf* cur = (xf*)malloc(sizeof(xf) * (M + 1));
+        xf* P = (xf*)malloc(sizeof(xf) * (M + 1));
+        for (int a = 0; a < M; a++) cur[a] = xf_from_log(I1[a] + ((float)(M - 1 - a) * llam - clutter_rate));
+        for (int a = 0; a < M; a++) T[(size_t)(M - 1) * M + a] = cur[a];
+        for (int m = M - 1; m >= 1; m--) {
+            for (int a = 0; a <= m - 1; a++) cur[a] = xf_axpy(cur[a], cur[a + 1], lxi[m]);
+            for (int a = 0; a <= m - 1; a++) T[(size_t)(m - 1) * M + a] = cur[a];
+        }
+        P[0].m = 0.5f; P[0].k = 1;                                    /* P_0 = [1] */
+        for (int a = 1; a <= M; a++) { P[a].m = 0; P[a].k = XF_ZERO_K; }
+        for (int m = 0; m < M; m++) {
+            /* dot product in the mantissa+exponent form: align to the largest exponent, add, renormalise */
+            int K = XF_ZERO_K * 2;
+            for (int a = 0; a <= m; a++) { const int k = P[a].k + T[(size_t)m * M + a].k; if (k > K) K = k; }
+            float s = 0;
+            for (int a = 0; a <= m; a++)
+                s += ldexpf(P[a].m * T[(size_t)m * M + a].m, P[a].k + T[(size_t)m * M + a].k - K);
+            int dk = 0;
+            xf D; D.m = frexpf(s, &dk); D.k = K + dk;
+            lz[m] = -((llam - lkap) + xf_log(D) - lY0);
+            for (int a = m + 1; a >= 1; a--) P[a] = xf_axpy(P[a], P[a - 1], lxi[m]);
+        }
+        free(T); free(cur); free(P);
     }
     *r1_out = expf(lY1 - lY0);
     /* 6. updated cardinality (.bak:1409-1411) */

@@ -260,6 +260,11 @@ def cphd_terms(cn_prior, S, w_all, pdw, birth_weight, clutter_rate, clutter_dens
     return dict(lz=lz[:M], r1=float(r1[0]), cn=cn, lY0=float(ly0[0]))
 
 
+def cphd_set_reference_esf(on):
+    """True: leave-one-out ESFs by M separate recursions (the .bak's O(M^3) structure); False: the O(M^2) form"""
+    lib().o_cphd_set_reference_esf(int(bool(on)))
+
+
 def cphd_update_particle(pose, gmap, z, cfg, clutter_rate, cn_prior):
     """-> dict(map, dlogw, cn, survivors, slab_idx, r1)"""
     pose = _c(pose, POSE).reshape(1)

@@ -112,6 +112,8 @@ int o_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, cons
 
 /* ---- CPHD variant (cphd_cpu.c; parity unpinned, see its header) ---- */
 void o_cphd_log_factorials(float* lfact, int n);
+/* 1: leave-one-out ESFs by M separate recursions (src/phdfilter.cu.bak:1247-1272, O(M^3)); 0 (default): O(M^2) */
+void o_cphd_set_reference_esf(int on);
 void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, float w_all, float pdw,
                   float birth_weight, float clutter_rate, float clutter_density,
                   float* lz, float* r1_out, float* cn_out, float* lY0_out);

@@ -120,6 +120,22 @@ def test_terms_against_polynomial_expansion(M, nmax, nt, seed):
     assert abs(np.log(np.exp(got["cn"].astype(np.float64)).sum())) < 2e-3
 
 
+@pytest.mark.parametrize("M,nmax,nt,seed", [(9, 30, 4, 20), (64, 255, 40, 21), (130, 255, 90, 22)])
+def test_prefix_suffix_form_equals_leave_one_out_recursions(M, nmax, nt, seed):
+    """<Y1[Z\\m],p> from the O(M^2) prefix/suffix recursion (what the device runs) against M separate ESF
+    recursions (the .bak's O(M^3) structure): same numbers up to fp32 rounding of different sum orders"""
+    rng = np.random.default_rng(seed)
+    prior, S, w_all, pdw = random_case(rng, M, nmax, nt)
+    fast = O.cphd_terms(prior, S, w_all, pdw, BW, LAM, KAP)
+    O.cphd_set_reference_esf(True)
+    try:
+        ref = O.cphd_terms(prior, S, w_all, pdw, BW, LAM, KAP)
+    finally:
+        O.cphd_set_reference_esf(False)
+    assert np.allclose(fast["lz"], ref["lz"], atol=3e-4)
+    assert fast["r1"] == ref["r1"] and fast["lY0"] == ref["lY0"] and np.array_equal(fast["cn"], ref["cn"])
+
+
 def test_poisson_prior_reduces_to_the_phd_update():
     """CPHD with a Poisson cardinality of mean <1,v> is the PHD filter: weights, missed-detection
     factor 1 and the particle weight up to the particle-independent constant M log(lambda/kappa) - lambda"""
