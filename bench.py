@@ -106,10 +106,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # PHD_BENCH_SHARE_GPU=1: dry run of the N > 1 path on a one-GPU box (every rank on device 0, gloo transport
+    # staged through host memory) — exercises this file's multi-rank code, its numbers are not a measurement
+    share = os.environ.get("PHD_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     c = S.CONFIGS[args.config]
     N, G, M = c["N"], c["G"], c["M"]
@@ -131,7 +139,8 @@ def main():
     d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
     d_noise = torch.from_numpy(w["noise"][0].copy()).to(dev)
     control = (2.0, 0.05)
-    u = float(w["uniform"][0])
+    # the resampling uniform is one draw shared by all ranks (every rank must compute the same global indices)
+    u = float(np.random.default_rng(0x5EED0000 + args.config).random())
     torch.cuda.synchronize()
 
     f.set_frozen(True)  # steady state: no step commits, every iteration restarts from the same snapshot
@@ -143,11 +152,11 @@ def main():
         sf = D.ShardedFilter(shard, N * world, rank, world)
 
         def step():
-            f.predict_dev(control, d_noise.data_ptr())
-            shard.update_local_dev(d_z.data_ptr(), M)
+            # one launch for predict + update + prune + merge + raw weights, one RCCL all-gather, one launch for the
+            # global normalise + resample indices, one RCCL all-to-all for the migrating particles, commit
+            shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
             allw = sf.gather_logweights()
-            sf.normalize(allw, want_neff=False)     # the bench forces the resample: no host round trip for nEff
-            sf.resample(u)
+            sf.resample(u, all_raw_logw=allw)       # the bench forces the resample: no host round trip for nEff
 
     def sync():
         f.sync()
@@ -170,7 +179,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_region_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = f.status()

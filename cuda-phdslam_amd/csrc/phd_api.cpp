@@ -121,6 +121,11 @@ struct phd_filter {
     float* d_lfact = nullptr;
     int lfact_len = 0;
     float2* cphd_scratch = nullptr; // [n_max][MM][MM]: rows of the ESF backward sweep (phd_kernels.hip, cphd_block)
+    // migration plan of a global resample in flight (phd_global_resample_begin .. _end)
+    std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots;
+    void* send_buf = nullptr;
+    size_t send_buf_bytes = 0;
+    bool want_raw = false; // the update kernel also writes raw = logw + dlogw (multi-GPU step: no weights launch before the all-gather)
     GmWorkspace* gm = nullptr; // expected-map / gm_reduce workspace, created on first use
     int gm_rounds = 0;
 
@@ -302,7 +307,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
     hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
-    hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch);
+    hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     gm_workspace_destroy(f->gm);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
@@ -667,6 +672,8 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     }
     a.z = d_z;
     a.dlogw = f->dlogw;
+    a.logw_in = f->logw;
+    a.raw_out = f->want_raw ? f->logw_raw : nullptr;
     a.M = M;
     a.MM = f->MM;
     a.cap = f->cap;
@@ -1082,6 +1089,26 @@ extern "C" int phd_update_local_dev(phd_filter* f, const phd_measurement* d_z, i
     return do_weights(f, WM_ACCUMULATE, nullptr, 1); // raw_out = logw + dlogw, no normalisation
 }
 
+// predict + update + prune + merge of the local shard in ONE launch, raw = logw + dlogw written by the same kernel
+extern "C" int phd_step_local_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
+                                  const phd_measurement* d_z, int n_meas)
+{
+    CHECK_F(f);
+    int M = std::min(n_meas, f->MM);
+    if (M <= 0) {
+        int rc = do_predict(f, u, d_noise);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(f->logw_raw, f->logw, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+        return PHD_OK;
+    }
+    if (f->n != f->n_base) return fail(PHD_ERR_UNSUPPORTED, "phd_step_local_dev: particle shotgun shards use the staged calls");
+    FusedPredict fp = {u, d_noise};
+    f->want_raw = true;
+    int rc = do_update_merge(f, d_z, M, &fp);
+    f->want_raw = false;
+    return rc;
+}
+
 extern "C" int phd_global_normalize(phd_filter* f, const float* d_all_logw, int n_global, float* neff_out)
 {
     CHECK_F(f);
@@ -1153,7 +1180,8 @@ extern "C" int phd_export_particles_dev(phd_filter* f, const int32_t* particles,
     // one particle may be the parent of slots on every other rank: up to n_global exports
     if (n > std::max(f->n, f->n_global)) return fail(PHD_ERR_INVALID_ARG, "phd_export_particles_dev: n > n_global");
     HIPCHK(hipMemcpyAsync(f->d_sizes, particles, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
-    HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->pose[f->pose_cur], f->d_sizes,
+    HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur],
+                         f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], f->d_sizes,
                          d_buffer, f->cap, phd_particle_pack_bytes(f), n, f->stream));
     if (f->cphd) // the cardinality row travels behind the slab
         HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, f->d_sizes, f->parent[f->pcur], (float*)d_buffer + 8 + 6 * f->cap,
@@ -1166,9 +1194,10 @@ extern "C" int phd_apply_parents(phd_filter* f, const int32_t* local_parent)
 {
     CHECK_F(f);
     HIPCHK(hipMemcpyAsync(f->d_tmp_int, local_parent, f->n * sizeof(int), hipMemcpyHostToDevice, f->stream));
-    const int pnext = (f->pose_cur + 1) % 3;
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3; // frozen fused predict parks the predicted poses in +1
     HIPCHK(launch_gather_maps(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur], f->d_tmp_int, f->maps[f->cur ^ 1],
-                              f->counts[f->cur ^ 1], f->pose[f->pose_cur], f->pose[pnext], f->cap, f->n, f->stream));
+                              f->counts[f->cur ^ 1], f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], f->pose[pnext],
+                              f->cap, f->n, f->stream));
     if (f->cphd)
         HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, f->d_tmp_int, f->parent[f->pcur], f->cn[f->cur ^ 1], f->cn_len, nullptr,
                                 f->cn_len, f->n, f->stream));
@@ -1180,7 +1209,7 @@ extern "C" int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int
     CHECK_F(f);
     if (n <= 0) return PHD_OK;
     if (n > f->n) return fail(PHD_ERR_INVALID_ARG, "phd_import_particles_dev: n > n_particles");
-    const int pnext = (f->pose_cur + 1) % 3;
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3;
     HIPCHK(hipMemcpyAsync(f->d_sizes, slots, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
     HIPCHK(launch_import(f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], f->d_sizes, d_buffer, f->cap,
                          phd_particle_pack_bytes(f), n, f->stream));
@@ -1200,6 +1229,96 @@ extern "C" int phd_finish_resample(phd_filter* f)
     f->parent_dirty = false;
     HIPCHK(launch_fill(f->logw, (float)(-log((double)f->n_global)), f->n, f->stream)); // src/slamtypes.h:327
     return PHD_OK; // stream-ordered: no host synchronisation
+}
+
+// The exchange above in two calls (what the multi-GPU host runs per resampling step):
+//   begin: indices on the device (identical on every rank) -> download -> this rank's part of the plan
+//          (a pure function of the indices: slot j of rank q receives particle idx[q n + j], owned by rank
+//          idx / n) -> export of the particles other ranks need into one send buffer, grouped by
+//          destination rank in the order the destination's slots appear
+//   [caller: all_to_all_single(recv, send, recv_counts, send_counts) over RCCL]
+//   end:   local parents gathered, received particles imported into their slots, weights <- -log N
+extern "C" int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_logw, double uniform, int world, int rank,
+                                         int32_t* send_counts, int32_t* recv_counts, void** d_send_buffer, int32_t* idx_out)
+{
+    CHECK_F(f);
+    if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
+        return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_begin: world/rank do not match the filter's shard");
+    if (!send_counts || !recv_counts || !d_send_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_begin: null output");
+    const int ng = f->n_global, n = f->n, off = rank * n;
+    f->plan_idx.resize(ng);
+    int rc;
+    if (d_all_raw_logw) {
+        // gathered un-normalised weights: normalise and draw the indices in one launch (forced resample)
+        WeightArgs w;
+        memset(&w, 0, sizeof(w));
+        w.u0 = uniform;
+        w.logw_in = d_all_raw_logw;
+        w.logw = f->logw_scratch;
+        w.n = ng;
+        w.n_new = ng;
+        w.mode = WM_NORMALIZE | WM_RESAMPLE_FORCE;
+        w.uniforms = f->d_uniforms;
+        w.n_uniforms = 1;
+        w.cdf = f->cdf;
+        w.idx_out = f->idx;
+        w.neff_out = f->neff;
+        w.did_resample = f->did;
+        w.n_weight_norm = ng;
+        t_begin(f, PHD_K_WEIGHTS);
+        HIPCHK(launch_weights(w, f->stream));
+        t_end(f);
+        HIPCHK(hipMemcpyAsync(f->plan_idx.data(), f->idx, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    } else {
+        rc = phd_global_resample_indices(f, nullptr, ng, &uniform, 1, f->plan_idx.data());
+        if (rc) return rc;
+    }
+    const int32_t* idx = f->plan_idx.data();
+    f->plan_local_parent.assign(n, -1);
+    f->plan_send.clear();
+    f->plan_recv_slots.clear();
+    for (int j = 0; j < n; ++j)
+        if (idx[off + j] / n == rank) f->plan_local_parent[j] = idx[off + j] - off;
+    for (int r = 0; r < world; ++r) {
+        send_counts[r] = recv_counts[r] = 0;
+        if (r == rank) continue;
+        for (int g = r * n; g < (r + 1) * n; ++g)                  // what rank r needs from this rank, in r's slot order
+            if (idx[g] / n == rank) { f->plan_send.push_back(idx[g] - off); ++send_counts[r]; }
+        for (int j = 0; j < n; ++j)                                 // what this rank needs from rank r, in slot order
+            if (idx[off + j] / n == r) { f->plan_recv_slots.push_back(j); ++recv_counts[r]; }
+    }
+    const size_t need = std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f);
+    if (need > f->send_buf_bytes) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        if (f->send_buf) hipFree(f->send_buf);
+        f->send_buf = nullptr;
+        f->send_buf_bytes = 0;
+        HIPCHK(hipMalloc(&f->send_buf, need * 2));
+        f->send_buf_bytes = need * 2;
+    }
+    if (!f->plan_send.empty()) {
+        rc = phd_export_particles_dev(f, f->plan_send.data(), (int)f->plan_send.size(), f->send_buf);
+        if (rc) return rc;
+    }
+    *d_send_buffer = f->send_buf;
+    if (idx_out) memcpy(idx_out, idx, (size_t)ng * sizeof(int32_t));
+    return PHD_OK;
+}
+
+extern "C" int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer)
+{
+    CHECK_F(f);
+    if ((int)f->plan_local_parent.size() != f->n) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_end: no plan (call _begin first)");
+    int rc = phd_apply_parents(f, f->plan_local_parent.data());
+    if (rc) return rc;
+    if (!f->plan_recv_slots.empty()) {
+        if (!d_recv_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_end: null receive buffer");
+        rc = phd_import_particles_dev(f, f->plan_recv_slots.data(), (int)f->plan_recv_slots.size(), d_recv_buffer);
+        if (rc) return rc;
+    }
+    f->plan_local_parent.clear();
+    return phd_finish_resample(f);
 }
 
 // ---------------------------------------------------------------------------------------------

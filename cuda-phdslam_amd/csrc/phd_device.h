@@ -66,6 +66,8 @@ struct UpdateArgs {
     const phd_pose* pose;       // [n_particles]
     const phd_measurement* z;   // [M] device
     float* dlogw;               // [n_particles] out
+    const float* logw_in;       // [n_particles] current log-weights (read only when raw_out is set)
+    float* raw_out;             // optional: raw_out[p] = logw_in[p] + dlogw[p] (multi-GPU step: feeds the all-gather)
     int M;
     int MM;                     // max measurements (LDS sizing)
     int cap;

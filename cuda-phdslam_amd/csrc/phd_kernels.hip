@@ -1681,7 +1681,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (kv) store_survivor(L, slot, S_cap, in[0 * cap + i] * r1, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i],
                                    in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i);
         }
-        if (tid == 0) A.dlogw[p] = Q.scal[CQ_LY0];                                                   // .bak:2661-2667
+        if (tid == 0) {
+            A.dlogw[p] = Q.scal[CQ_LY0];                                                             // .bak:2661-2667
+            if (A.raw_out) A.raw_out[p] = A.logw_in[p] + Q.scal[CQ_LY0];
+        }
     } else {
     for (int m = tid; m < M; m += PHD_T) {
         float sum = L.zpart[0 * A.MM + m];
@@ -1707,6 +1710,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const float dl = lz_sum - (pdw + (float)M * cfg.birthWeight);
             if (FUSEW) __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else A.dlogw[p] = dl;
+            if (!FUSEW && A.raw_out) A.raw_out[p] = A.logw_in[p] + dl;                                // :3741-3744
         }
     }
     } // !CPHD

@@ -91,8 +91,41 @@ class ShardedFilter:
         the shard's normalised weights are adopted"""
         return self.b.global_normalize(all_logw, want_neff)
 
-    def resample(self, uniform):
-        """global systematic resample + migration.  Returns the global parent indices."""
+    def _exchange(self, out_buf, send_counts, recv_counts, pack):
+        """rows of out_buf grouped by destination rank -> rows grouped by source rank"""
+        if dist.get_backend(self.group) == "gloo":
+            # gloo has no all_to_all: pairwise exchange through host memory (CPU tests, and several
+            # ranks sharing one GPU); rank order breaks the send/recv symmetry
+            host_out = out_buf.cpu()
+            so = np.concatenate([[0], np.cumsum(send_counts)])
+            pieces = []
+            for r in range(self.world):
+                piece = torch.empty((recv_counts[r], pack), dtype=torch.uint8)
+                if r != self.rank:
+                    mine = host_out[so[r]:so[r + 1]].contiguous()
+                    if self.rank < r:
+                        dist.send(mine, r, group=self.group)
+                        dist.recv(piece, r, group=self.group)
+                    else:
+                        dist.recv(piece, r, group=self.group)
+                        dist.send(mine, r, group=self.group)
+                pieces.append(piece)
+            return torch.cat(pieces).to(out_buf.device)
+        in_buf = torch.empty((max(sum(recv_counts), 1), pack), dtype=torch.uint8, device=out_buf.device)
+        dist.all_to_all_single(in_buf[:sum(recv_counts)], out_buf, output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+        return in_buf
+
+    def resample(self, uniform, all_raw_logw=None):
+        """global systematic resample + migration.  Returns the global parent indices.
+        all_raw_logw: the gathered UN-normalised weights — normalisation and indices then come from one launch
+        (forced resample; skip normalize())"""
+        if self.world > 1 and hasattr(self.b, "resample_begin"):
+            # library path: one call plans (in C++) and exports, one collective, one call imports and commits
+            send_counts, recv_counts, send, idx = self.b.resample_begin(uniform, self.world, self.rank, all_raw_logw)
+            recv = self._exchange(send[:sum(send_counts)], send_counts, recv_counts, self.b.pack_bytes())
+            self.b.resample_end(recv)
+            return idx
         idx = self.b.global_resample_indices(uniform)       # numpy [n_global], identical on all ranks
         local_parent, send, recv_slots = plan_migration(idx, self.n_global, self.world, self.rank)
         if self.world > 1:
@@ -100,29 +133,7 @@ class ShardedFilter:
             recv_counts = [len(s) for s in recv_slots]
             order = np.concatenate(send) if sum(send_counts) else np.zeros(0, np.int32)
             out_buf = self.b.export_particles(order)        # tensor [n_send, pack] (uint8)
-            pack = self.b.pack_bytes()
-            if dist.get_backend(self.group) == "gloo":
-                # gloo has no all_to_all: pairwise exchange through host memory (CPU tests, and several
-                # ranks sharing one GPU); rank order breaks the send/recv symmetry
-                host_out = out_buf.cpu()
-                so = np.concatenate([[0], np.cumsum(send_counts)])
-                pieces = []
-                for r in range(self.world):
-                    piece = torch.empty((recv_counts[r], pack), dtype=torch.uint8)
-                    if r != self.rank:
-                        mine = host_out[so[r]:so[r + 1]].contiguous()
-                        if self.rank < r:
-                            dist.send(mine, r, group=self.group)
-                            dist.recv(piece, r, group=self.group)
-                        else:
-                            dist.recv(piece, r, group=self.group)
-                            dist.send(mine, r, group=self.group)
-                    pieces.append(piece)
-                in_buf = torch.cat(pieces).to(out_buf.device)
-            else:
-                in_buf = torch.empty((sum(recv_counts), pack), dtype=torch.uint8, device=out_buf.device)
-                dist.all_to_all_single(in_buf, out_buf, output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                       group=self.group)
+            in_buf = self._exchange(out_buf, send_counts, recv_counts, self.b.pack_bytes())
             self.b.apply_parents(local_parent)
             slots = np.concatenate(recv_slots) if sum(recv_counts) else np.zeros(0, np.int32)
             self.b.import_particles(slots, in_buf)
@@ -240,6 +251,32 @@ class GpuShard:
 
     def finish_resample(self):
         self._check(self._lib().phd_finish_resample(self.f._h), "phd_finish_resample")
+
+    def step_local_dev(self, control, d_noise, d_z, n_meas):
+        from .filter import _ctrl
+        self._check(self._lib().phd_step_local_dev(self.f._h, _ctrl(control), self._ptr(d_noise), self._ptr(d_z), int(n_meas)),
+                    "phd_step_local_dev")
+
+    def resample_begin(self, uniform, world, rank, all_raw_logw=None):
+        C = self._C
+        sc = (C.c_int32 * world)()
+        rc = (C.c_int32 * world)()
+        buf = C.c_void_p()
+        idx = np.zeros(self.n_global, np.int32)
+        self._torch_to_filter()
+        raw = self._ptr(all_raw_logw.data_ptr()) if all_raw_logw is not None else None
+        self._check(self._lib().phd_global_resample_begin(self.f._h, raw, float(uniform), int(world), int(rank), sc, rc,
+                                                          C.byref(buf), self._ptr(idx)), "phd_global_resample_begin")
+        sc, rc = list(sc), list(rc)
+        self._filter_to_torch()
+        pack = self.pack_bytes()
+        n_send = max(sum(sc), 1)
+        send = self._wrap(buf.value, n_send * pack // 4).view(torch.uint8).view(n_send, pack)
+        return sc, rc, send, idx
+
+    def resample_end(self, recv):
+        self._torch_to_filter()
+        self._check(self._lib().phd_global_resample_end(self.f._h, self._ptr(recv.data_ptr())), "phd_global_resample_end")
 
     def expected_map_concat(self):
         d, total = self.f.expected_map_concat_dev()          # synchronises the filter's stream

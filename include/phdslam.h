@@ -263,6 +263,10 @@ int phd_raw_logweights_dev(phd_filter* f, float** d_logw_out);
 /* Multi-GPU: update + prune + merge of the local shard WITHOUT the local normalisation: leaves
  * raw = logw + dlogw in the buffer of phd_raw_logweights_dev for the all-gather */
 int phd_update_local_dev(phd_filter* f, const phd_measurement* d_z, int n_meas);
+/* predict + local update in ONE launch (the vehicle predict and raw = logw + dlogw are done by the
+ * update kernel); d_noise as in phd_predict_ackerman_dev */
+int phd_step_local_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
+                       const phd_measurement* d_z, int n_meas);
 
 /* Multi-GPU: normalise / nEff / resample over the all-gathered vector of
  * n_global un-normalised log-weights (device pointer, identical on every rank).  Every rank
@@ -280,6 +284,19 @@ size_t phd_particle_pack_bytes(const phd_filter* f);
 int phd_export_particles_dev(phd_filter* f, const int32_t* particles, int n, void* d_buffer);
 int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int n, const void* d_buffer);
 int phd_finish_resample(phd_filter* f); /* weights <- -log(global_particles) */
+
+/* The same exchange in two calls (one host round trip per resampling step).  begin: global indices
+ * (phd_global_resample_indices on the gathered, normalised weights of phd_global_normalize), this
+ * rank's part of the migration plan, export of the particles other ranks need into a library-owned
+ * send buffer (grouped by destination rank; send_counts/recv_counts[world] in particles of
+ * phd_particle_pack_bytes()).  The caller runs all_to_all_single(recv, send, recv_counts,
+ * send_counts) (RCCL).  end: copy_particles on the shard (local parents + received particles),
+ * weights <- -log(global_particles).  idx_out (optional, host, global_particles entries).
+ * d_all_raw_logw: NULL after phd_global_normalize; or the gathered UN-normalised weights, in which case
+ * the normalisation and the indices come from one launch (forced resample, no nEff round trip). */
+int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_logw, double uniform, int world, int rank,
+                              int32_t* send_counts, int32_t* recv_counts, void** d_send_buffer, int32_t* idx_out);
+int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer);
 
 /* ------------------------------------------------------------------------------------
  * Bench / steady-state protocol and instrumentation
