@@ -103,6 +103,31 @@ def main():
              n_steps_full=n_steps_full)
     print("loader KAT: %d head steps, bundled file has %d steps" % (n_head, n_steps_full))
 
+    # end-to-end data (BASELINE.json configs[0]): the whole bundled simulation —
+    # true trajectory, noise-free controls, every scan (true detections + clutter), the landmarks seen so far
+    flat, offs = [], [0]
+    for d in sim.data:
+        mk = np.atleast_2d(np.asarray(d.measurements, dtype=np.float64))
+        if mk.shape[0] != 2:
+            mk = mk.reshape(2, -1)
+        flat.append(mk.T)
+        offs.append(offs[-1] + mk.shape[1])
+    gt_final = np.asarray(sim.groundTruth[-1].loc, dtype=np.float64).reshape(2, -1).T
+    # groundTruth(k).loc lists the landmarks seen up to step k: every column is one of the final list's
+    seen = np.zeros((len(sim.groundTruth), len(gt_final)), bool)
+    for k, g in enumerate(sim.groundTruth):
+        loc = np.asarray(g.loc, dtype=np.float64).reshape(2, -1).T
+        for p in loc:
+            j = int(np.argmin(np.abs(gt_final - p).sum(axis=1)))
+            assert np.array_equal(gt_final[j], p)
+            seen[k, j] = True
+        assert seen[k].sum() == len(loc)
+    np.savez_compressed(os.path.join(OUT, "sim_ackerman_e2e.npz"), traj=traj.T.astype(np.float32), u=u.astype(np.float32),
+                        dt=dts.astype(np.float32), z=np.concatenate(flat).astype(np.float32),
+                        z_offsets=np.array(offs, np.int32), landmarks=gt_final.astype(np.float32),
+                        seen=np.packbits(seen, axis=1), vehicle=np.array([2.83, 0.76, 3.78, 0.5], np.float32))
+    print("e2e data: %d steps, %d measurements, %d landmarks" % (len(sim.data), offs[-1], len(gt_final)))
+
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,131 @@
+"""End to end on hardware, on the reference's bundled simulation (tests/golden/sim_ackerman_e2e.npz, see
+tests/e2e_utils.py): BASELINE.json configs[0] (one particle on the true trajectory) through the C-ABI and
+through the `phdslam` driver binary, and Rao-Blackwellised SLAM with 256 particles and noisy odometry.
+Scored with the OSPA metric (c = 5 m, p = 1) against the simulation's landmarks, and against the CPU oracle
+run on the same data."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from e2e_utils import CLUTTER_RATE, ODOMETRY, SENSOR, VEHICLE, confirmed, load, oracle_mapping, ospa, scan_struct
+from oracle import oracle as O
+from parity_utils import pkg
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cuda-phdslam_amd")
+
+
+def device_config(P, n_particles, **over):
+    kw = dict(SENSOR, clutterRate=CLUTTER_RATE, dt=1.0, n_particles=n_particles, **VEHICLE, **ODOMETRY)
+    kw.update(over)
+    return P.default_config(**kw)
+
+
+def test_mapping_one_particle_matches_the_oracle_and_the_landmarks():
+    P = pkg()
+    data = load()
+    cfg = device_config(P, 1)
+    with P.PhdFilter(cfg, n_particles=1, map_capacity=512, max_measurements=64) as f:
+        for k, scan in enumerate(data["scans"]):
+            q = np.zeros(1, P.POSE)
+            q["px"], q["py"], q["ptheta"] = data["traj"][k]
+            f.set_particles(q, np.zeros(1, np.float32))                          # follow_trajectory (src/main.cpp:1239-1243)
+            f.update(scan_struct(P.MEAS, scan))
+        st = f.status()
+        gmap = f.get_maps()[0]
+    ref = oracle_mapping(O, data)
+    est, est_ref = confirmed(gmap), confirmed(ref)
+    truth = data["landmarks"]
+    assert st["max_map"] <= 512
+    assert abs(len(est) - len(est_ref)) <= 1 and ospa(est, est_ref) < 0.15      # 331 chained fp32 updates on both sides
+    assert abs(float(gmap["weight"].sum()) - float(ref["weight"].sum())) < 0.05 * float(ref["weight"].sum())
+    assert 35 <= len(est) <= 50 and ospa(est, truth) < 1.5
+
+
+def test_slam_256_particles_noisy_odometry():
+    P = pkg()
+    data = load()
+    N = 256
+    cfg = device_config(P, N)
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    n_resampled = 0
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=512, max_measurements=64) as f:
+        q = np.zeros(N, P.POSE)
+        q["px"], q["py"], q["ptheta"] = data["traj"][0]
+        f.set_particles(q, np.full(N, -np.log(N), np.float32))
+        for k, scan in enumerate(data["scans"]):
+            if k > 0:
+                noise = np.stack([ODOMETRY["stdAlpha"] * rng.standard_normal(N),
+                                  ODOMETRY["stdEncoder"] * rng.standard_normal(N)], 1).astype(np.float32)
+                f.predict((float(data["u"][k - 1, 0]), float(data["u"][k - 1, 1])), noise)
+            f.update(scan_struct(P.MEAS, scan))
+            e = f.expected_pose()
+            err = float(np.hypot(e["px"] - data["traj"][k, 0], e["py"] - data["traj"][k, 1]))
+            worst = max(worst, err)
+            did, _ = f.resample_if_needed(rng.random(), had_measurements=True)
+            n_resampled += int(did)
+        f.status()
+        gmap, _ = f.map_estimate()
+        eap = f.expected_map()
+    assert err < 1.0 and worst < 2.0, (err, worst)
+    assert 50 < n_resampled < 331
+    est = confirmed(gmap)
+    assert 33 <= len(est) <= 50 and ospa(est, data["landmarks"]) < 1.8
+    # the expected-a-posteriori map (all particles, weighted) tells the same story
+    est_eap = confirmed(eap)
+    assert 33 <= len(est_eap) <= 52 and ospa(est_eap, data["landmarks"]) < 1.8
+
+
+def test_driver_on_the_bundled_data(tmp_path):
+    """the executable's contract on a data directory in the reference's formats: measurements.txt, controls.txt,
+    traj.txt + follow_trajectory; the logs are scored with phd_evaluate_state_log (python/batch_analyze.py:16-37)"""
+    P = pkg()
+    data = load()
+    d = str(tmp_path)
+    with open(os.path.join(d, "measurements.txt"), "w") as f:
+        f.write("% range bearing pairs, one scan per line\n")
+        for scan in data["scans"]:
+            f.write(" ".join("%.6f %.6f" % (r, b) for r, b in scan) + " \n")
+    with open(os.path.join(d, "controls.txt"), "w") as f:
+        f.write("% velocity\tsteering angle\n")
+        for v, a in data["u"]:
+            f.write("%.6f %.6f\n" % (v, a))
+    with open(os.path.join(d, "traj.txt"), "w") as f:
+        f.write("% px py ptheta vx vy vtheta\n")
+        for x, y, th in data["traj"]:
+            f.write("%.6f %.6f %.6f 0 0 0\n" % (x, y, th))
+    cfg = open(os.path.join(ROOT, "tests", "golden", "config_sample.cfg")).read()
+    repl = dict(max_range="10.0", std_range="1.0", std_bearing="0.0349", dt="1.0", l="2.83", h="0.76", a="3.78", b="0.5",
+                n_particles="1", data_directory=d + "/")
+    import re
+    for k, v in repl.items():
+        cfg, n = re.subn(r"^%s\s*=.*$" % k, "%s = %s" % (k, v), cfg, flags=re.M)
+        assert n == 1, k
+    cfg += "follow_trajectory = 1\n"
+    cfg_path = os.path.join(d, "config.cfg")
+    open(cfg_path, "w").write(cfg)
+    out = os.path.join(d, "logs")
+    os.makedirs(out)
+    r = subprocess.run([os.path.join(PKG, "bin", "phdslam"), cfg_path, "synth", "--out", out, "--capacity", "512"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    L = P._lib.lib()
+    res = np.zeros(5, np.float64)
+    truth = np.ascontiguousarray(data["landmarks"], np.float32)
+    scores = []
+    for k in (165, 330):
+        tp = np.ascontiguousarray(data["traj"][k, :2], np.float32)
+        seen = np.ascontiguousarray(data["landmarks"][data["seen"][k]], np.float32)
+        rc = L.phd_evaluate_state_log(os.path.join(out, "state_estimate%05d.log" % k).encode(), tp.ctypes.data_as(C.c_void_p),
+                                      seen.ctypes.data_as(C.c_void_p), len(seen), 1.0, 5.0, res.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        scores.append(res.copy())
+    assert scores[1][0] < 1e-4                      # follow_trajectory: the logged pose is the true pose
+    assert scores[0][1] < 2.5 and scores[1][1] < 1.5  # OSPA of the logged map (top round(sum w) features) vs the landmarks seen
+    assert not os.path.exists(os.path.join(out, "state_estimate%05d.log" % 331)) and len(truth) == 50
