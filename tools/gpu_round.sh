@@ -14,6 +14,8 @@ cat gpurun_out/bench_cfg3_$tag.json
 python bench.py --config 5 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out/bench_cfg5_$tag.json 2> gpurun_out/bench_cfg5_$tag.err
 cat gpurun_out/bench_cfg5_$tag.json
 python tools/phase_profile.py 2 3 > gpurun_out/phase_$tag.log 2>&1
+(python tools/e2e_run.py 256; python tools/e2e_run.py 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/e2e_$tag.log
+cat gpurun_out/e2e_$tag.log
 cd /tmp && export TMPDIR=/tmp
 for cfg in 2 3 5; do
   st=400; [ $cfg != 2 ] && st=50
