@@ -195,6 +195,34 @@ def main():
     f.timing(False)
     avg_ms = ms / np.maximum(cnt, 1)
 
+    # the same loop with the reference's trigger instead of a forced resample (nEff <= resample_threshold)
+    unforced = None
+    if world == 1:
+        k_un = min(args.steps, 200)
+        for _ in range(5):
+            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
+        sync()
+        tu = time.perf_counter()
+        for _ in range(k_un):
+            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
+        sync()
+        unforced = k_un / (time.perf_counter() - tu)
+
+    # in-run HBM ceiling: a device-to-device copy of 1 GiB on the same stream, read + write bytes
+    copy_gbs = None
+    if world == 1:
+        src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst_t = torch.empty_like(src_t)
+        dst_t.copy_(src_t)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(ts)
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        c1.record(ts)
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src_t.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src_t, dst_t
+
     if rank == 0:
         b_step = S.algorithmic_bytes(N, G, M)               # per launch of the update+merge kernel (one shard)
         b_min = N * (28 * G + 28 * G + 32)                   # compulsory traffic
@@ -234,12 +262,15 @@ def main():
                                    "Ackerman motion, forced resample every step, frozen snapshot" % (args.config - 1, N, G, M),
                        "particles_total": N * world, "gaussians_per_particle": G, "measurements_per_step": M,
                        "value_counts": "shard-steps (ranks x steps) per second",
-                       "max_survivors": st["max_survivors"], "max_map": st["max_map"]},
+                       "max_survivors": st["max_survivors"], "max_map": st["max_map"],
+                       "steps_per_s_unforced_resample": unforced},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
                          "kernel_avg_us_event_pairs": 1e3 * pair_ms, "gpu_region_ms_per_step": gpu_region_ms / args.steps,
                          "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
+                         "device_copy_ceiling_gbs": copy_gbs,
+                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "other_kernels_avg_us": {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT],
                                                   "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}},
         }

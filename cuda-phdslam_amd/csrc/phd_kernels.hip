@@ -1481,14 +1481,6 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const int src = A.parent[p];
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
     float* __restrict__ out = A.map_out + (size_t)p * 6 * cap;
-    // the first tile of the map is requested before its length is known (slabs are `cap` long, so the reads
-    // are in bounds): the count, the pose, the measurements and the six planes are then all in flight
-    // together instead of one HBM round trip after the other
-    float h_w = 0.f, h_mx = 0.f, h_my = 0.f, h_xx = 0.f, h_xy = 0.f, h_yy = 0.f;
-    if (tid < cap) {
-        h_w = in[0 * cap + tid]; h_mx = in[1 * cap + tid]; h_my = in[2 * cap + tid];
-        h_xx = in[3 * cap + tid]; h_xy = in[4 * cap + tid]; h_yy = in[5 * cap + tid];
-    }
     const int n_map = A.count_in[src];
     phd_pose pose = A.pose[p];
     if (A.do_predict) {
@@ -1556,12 +1548,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             EkfTerms t;
             t.pd = 0.f;
             if (i < n_map) {
-                if (i0 == 0) {
-                    w = h_w; mx = h_mx; my = h_my; pxx = h_xx; pxy = h_xy; pyy = h_yy;
-                } else {
-                    w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
-                    pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
-                }
+                w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
+                pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
                 ekf_terms(mx, my, pxx, pxy, pyy, pose, cfg, t);
                 wall_local += w;
                 // computeInRangeKernel, src/phdfilter.cu:1333-1346 (0.8/1.2 are double literals)
@@ -2117,7 +2105,6 @@ template <int BT, int R, bool HANDOFF>
 __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn)
 {
     __shared__ float sc[BT / 64];
-    __shared__ int s_flag;
     __shared__ int s_argmax;
     __shared__ u64 s_wtot[BT / 64];
     __shared__ double s_bestv[BT / 64];
