@@ -1188,6 +1188,189 @@ __device__ __forceinline__ float lse2f(float a, float b)
 
 __device__ __forceinline__ float clamp_log(float x) { return x < -1e30f ? -1e30f : x; }
 
+// the two sweeps of cphd_block for a compile-time number of 64-lane tiles (M <= 64 TILES): with TILES = 1 — every
+// configuration of BASELINE.json — the tile loops and their guards fold away, which halves the instruction count
+// of this single-wave, latency-bound section
+template <int tiles>
+__device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __restrict__ T_scratch, int M, int lane, float llam,
+                                                float lam)
+{
+#pragma clang fp contract(off)
+    const float LOG0F = -FLT_MAX;
+    const int XF_ZERO_K = -(1 << 28);
+    float tm[4];
+    int tk[4];
+    // T_M[a] = c_a, a = lane + 64 c
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int a = lane + 64 * c;
+        tm[c] = 0.f; tk[c] = XF_ZERO_K;
+        if (c < tiles && a < M) {
+            const float Lg = Q.I1[a] + ((float)(M - 1 - a) * llam - lam);
+            if (Lg > -1e30f) {
+                const double t = (double)Lg * 1.4426950408889634;
+                const double kf = ceil(t);
+                tm[c] = (float)exp2(t - kf);
+                tk[c] = (int)kf;
+            }
+            T_scratch[(size_t)(M - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
+        }
+    }
+    for (int m = M - 1; m >= 1; --m) {
+        const float x = Q.lxi[m];
+        float nm[4];
+        int nk[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            nm[c] = 0.f; nk[c] = XF_ZERO_K;
+            if (c < tiles) {
+                const float dn_m = lane_down1(tm[c]);
+                const int dn_k = lane_down1(tk[c]);
+                const float cm = (c < 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tm[c < 3 ? c + 1 : 3]), 0)) : 0.f;
+                const int ck = (c < 3) ? __builtin_amdgcn_readlane(tk[c < 3 ? c + 1 : 3], 0) : XF_ZERO_K;
+                nm[c] = (lane == 63) ? cm : dn_m;
+                nk[c] = (lane == 63) ? ck : dn_k;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int a = lane + 64 * c;
+            if (c < tiles && a <= m - 1) {
+                const float pr = nm[c] * x;
+                const int k = tk[c] > nk[c] ? tk[c] : nk[c];
+                const float s = ldexpf(tm[c], tk[c] - k) + ldexpf(pr, nk[c] - k);
+                int dk = 0;
+                tm[c] = frexpf(s, &dk);
+                tk[c] = k + dk;
+                T_scratch[(size_t)(m - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
+            }
+        }
+    }
+    __threadfence(); // the rows are read back by other lanes of this wave
+    // forward: P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
+    float pm[4] = {0.f, 0.f, 0.f, 0.f};
+    int pk[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
+    // the rows come back from L2 / HBM: keep PF of them in flight ahead of the step that uses them
+    constexpr int PF = 4;
+    float2 rbuf[PF][4], r0buf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const float2* row = T_scratch + (size_t)u * M;
+        r0buf[u] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rbuf[u][c] = make_float2(0.f, 0.f);
+        if (u < M) {
+            r0buf[u] = row[0];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < tiles && lane + 1 + 64 * c <= u) rbuf[u][c] = row[lane + 1 + 64 * c];
+        }
+    }
+    for (int m0 = 0; m0 < M; m0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int m = m0 + u;
+        if (m < M) {
+        const float x = Q.lxi[m];
+        // D_m = T_{m+1}[0] + sum_{a=1..m} P_m[a] T_{m+1}[a]
+        float qm[5];
+        int qk[5];
+        int kmax = 2 * XF_ZERO_K;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int a = lane + 1 + 64 * c;
+            qm[c] = 0.f; qk[c] = 2 * XF_ZERO_K;
+            if (c < tiles && a <= m) {
+                const float2 t = rbuf[u][c];
+                qm[c] = pm[c] * t.x;
+                qk[c] = pk[c] + __float_as_int(t.y);
+            }
+            kmax = max(kmax, qk[c]);
+        }
+        {
+            const float2 t0 = r0buf[u];
+            qm[4] = (lane == 0) ? t0.x : 0.f;
+            qk[4] = (lane == 0) ? __float_as_int(t0.y) : 2 * XF_ZERO_K;
+            kmax = max(kmax, qk[4]);
+        }
+        if (m + PF < M) { // refill this slot with the row PF steps ahead
+            const float2* row = T_scratch + (size_t)(m + PF) * M;
+            r0buf[u] = row[0];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < tiles && lane + 1 + 64 * c <= m + PF) rbuf[u][c] = row[lane + 1 + 64 * c];
+        }
+        kmax = wave_max_i(kmax);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) s += ldexpf(qm[c], qk[c] - kmax);
+        s = wave_sum(s);
+        if (lane == 0) {
+            int dk = 0;
+            const float dm = frexpf(s, &dk);
+            Q.lD[m] = dm > 0.f ? logf(dm) + (float)(kmax + dk) * 0.69314718f : LOG0F;   // log <Y1[Z \ m], p>
+        }
+        // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
+        float um[4];
+        int uk[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            um[c] = 0.f; uk[c] = XF_ZERO_K;
+            if (c < tiles) {
+                const float up_m = lane_up1(pm[c]);
+                const int up_k = lane_up1(pk[c]);
+                const float cm = (c > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm[c > 0 ? c - 1 : 0]), 63))
+                                         : 0.5f;                                       // P[0] = 1 = 0.5 * 2^1
+                const int ck = (c > 0) ? __builtin_amdgcn_readlane(pk[c > 0 ? c - 1 : 0], 63) : 1;
+                um[c] = (lane == 0) ? cm : up_m;
+                uk[c] = (lane == 0) ? ck : up_k;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < tiles && lane + 64 * c <= m) {
+                const float pr = um[c] * x;
+                const int k = pk[c] > uk[c] ? pk[c] : uk[c];
+                const float s2 = ldexpf(pm[c], pk[c] - k) + ldexpf(pr, uk[c] - k);
+                int dk = 0;
+                pm[c] = frexpf(s2, &dk);
+                pk[c] = k + dk;
+            }
+        } // m < M
+    }
+    }
+    // full set: e_j = P_M[j]; <Y0,p> and <Y1,p>
+    float ev[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ev[c] = pm[c] > 0.f ? logf(pm[c]) + (float)pk[c] * 0.69314718f : LOG0F;
+    float t0[5], t1[5];
+    float mx0 = LOG0F, mx1 = LOG0F;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        // c == 4: the j = 0 term (e_0 = 1), carried by lane 0
+        const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
+        const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
+        const float e = (c == 4) ? 0.f : ev[c < 4 ? c : 0];
+        const float kterm = (float)(M - j) * llam - lam;   // (M-j)! p_K(M-j), Poisson clutter (.bak:398-400)
+        t0[c] = ok ? e + Q.I0[ok ? j : 0] + kterm : LOG0F;
+        t1[c] = ok ? e + Q.I1[ok ? j : 0] + kterm : LOG0F;
+        mx0 = fmaxf(mx0, t0[c]); mx1 = fmaxf(mx1, t1[c]);
+    }
+    mx0 = wave_max_f(mx0); mx1 = wave_max_f(mx1);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
+        const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
+        if (ok) { s0 += expf(t0[c] - mx0); s1 += expf(t1[c] - mx1); }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (lane == 0) { Q.scal[CQ_LY0] = safe_log(s0) + mx0; Q.scal[CQ_LY1] = safe_log(s1) + mx1; Q.efull[0] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
+}
+
 __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const DevConfig& cfg, int M, int MM, int cn_len,
                                         const float* __restrict__ lfact_g, int lfact_len, const float* __restrict__ cn_prior,
                                         float* __restrict__ cn_out, float2* __restrict__ T_scratch, float w_all, float pdw,
@@ -1259,180 +1442,11 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // carries P in registers and takes one dot product per measurement.  Values span hundreds of decades, so
     // each is a float mantissa with its own integer exponent (m 2^k): align with v_ldexp, renormalise with
     // v_frexp — exact operations around one correctly rounded multiply and add (the oracle does the same).
-    const int tiles = (M + 63) >> 6;
-    const int XF_ZERO_K = -(1 << 28);
     if (wave == 0) {
-        float tm[4];
-        int tk[4];
-        // T_M[a] = c_a, a = lane + 64 c
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int a = lane + 64 * c;
-            tm[c] = 0.f; tk[c] = XF_ZERO_K;
-            if (c < tiles && a < M) {
-                const float Lg = Q.I1[a] + ((float)(M - 1 - a) * llam - lam);
-                if (Lg > -1e30f) {
-                    const double t = (double)Lg * 1.4426950408889634;
-                    const double kf = ceil(t);
-                    tm[c] = (float)exp2(t - kf);
-                    tk[c] = (int)kf;
-                }
-                T_scratch[(size_t)(M - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
-            }
-        }
-        for (int m = M - 1; m >= 1; --m) {
-            const float x = Q.lxi[m];
-            float nm[4];
-            int nk[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                nm[c] = 0.f; nk[c] = XF_ZERO_K;
-                if (c < tiles) {
-                    const float dn_m = lane_down1(tm[c]);
-                    const int dn_k = lane_down1(tk[c]);
-                    const float cm = (c < 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tm[c < 3 ? c + 1 : 3]), 0)) : 0.f;
-                    const int ck = (c < 3) ? __builtin_amdgcn_readlane(tk[c < 3 ? c + 1 : 3], 0) : XF_ZERO_K;
-                    nm[c] = (lane == 63) ? cm : dn_m;
-                    nk[c] = (lane == 63) ? ck : dn_k;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int a = lane + 64 * c;
-                if (c < tiles && a <= m - 1) {
-                    const float pr = nm[c] * x;
-                    const int k = tk[c] > nk[c] ? tk[c] : nk[c];
-                    const float s = ldexpf(tm[c], tk[c] - k) + ldexpf(pr, nk[c] - k);
-                    int dk = 0;
-                    tm[c] = frexpf(s, &dk);
-                    tk[c] = k + dk;
-                    T_scratch[(size_t)(m - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
-                }
-            }
-        }
-        __threadfence(); // the rows are read back by other lanes of this wave
-        // forward: P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
-        float pm[4] = {0.f, 0.f, 0.f, 0.f};
-        int pk[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
-        // the rows come back from L2 / HBM: keep PF of them in flight ahead of the step that uses them
-        constexpr int PF = 4;
-        float2 rbuf[PF][4], r0buf[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const float2* row = T_scratch + (size_t)u * M;
-            r0buf[u] = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) rbuf[u][c] = make_float2(0.f, 0.f);
-            if (u < M) {
-                r0buf[u] = row[0];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < tiles && lane + 1 + 64 * c <= u) rbuf[u][c] = row[lane + 1 + 64 * c];
-            }
-        }
-        for (int m0 = 0; m0 < M; m0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int m = m0 + u;
-            if (m < M) {
-            const float x = Q.lxi[m];
-            // D_m = T_{m+1}[0] + sum_{a=1..m} P_m[a] T_{m+1}[a]
-            float qm[5];
-            int qk[5];
-            int kmax = 2 * XF_ZERO_K;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int a = lane + 1 + 64 * c;
-                qm[c] = 0.f; qk[c] = 2 * XF_ZERO_K;
-                if (c < tiles && a <= m) {
-                    const float2 t = rbuf[u][c];
-                    qm[c] = pm[c] * t.x;
-                    qk[c] = pk[c] + __float_as_int(t.y);
-                }
-                kmax = max(kmax, qk[c]);
-            }
-            {
-                const float2 t0 = r0buf[u];
-                qm[4] = (lane == 0) ? t0.x : 0.f;
-                qk[4] = (lane == 0) ? __float_as_int(t0.y) : 2 * XF_ZERO_K;
-                kmax = max(kmax, qk[4]);
-            }
-            if (m + PF < M) { // refill this slot with the row PF steps ahead
-                const float2* row = T_scratch + (size_t)(m + PF) * M;
-                r0buf[u] = row[0];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < tiles && lane + 1 + 64 * c <= m + PF) rbuf[u][c] = row[lane + 1 + 64 * c];
-            }
-            kmax = wave_max_i(kmax);
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) s += ldexpf(qm[c], qk[c] - kmax);
-            s = wave_sum(s);
-            if (lane == 0) {
-                int dk = 0;
-                const float dm = frexpf(s, &dk);
-                Q.lD[m] = dm > 0.f ? logf(dm) + (float)(kmax + dk) * 0.69314718f : LOG0F;   // log <Y1[Z \ m], p>
-            }
-            // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
-            float um[4];
-            int uk[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                um[c] = 0.f; uk[c] = XF_ZERO_K;
-                if (c < tiles) {
-                    const float up_m = lane_up1(pm[c]);
-                    const int up_k = lane_up1(pk[c]);
-                    const float cm = (c > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm[c > 0 ? c - 1 : 0]), 63))
-                                             : 0.5f;                                       // P[0] = 1 = 0.5 * 2^1
-                    const int ck = (c > 0) ? __builtin_amdgcn_readlane(pk[c > 0 ? c - 1 : 0], 63) : 1;
-                    um[c] = (lane == 0) ? cm : up_m;
-                    uk[c] = (lane == 0) ? ck : up_k;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 64 * c <= m) {
-                    const float pr = um[c] * x;
-                    const int k = pk[c] > uk[c] ? pk[c] : uk[c];
-                    const float s2 = ldexpf(pm[c], pk[c] - k) + ldexpf(pr, uk[c] - k);
-                    int dk = 0;
-                    pm[c] = frexpf(s2, &dk);
-                    pk[c] = k + dk;
-                }
-            } // m < M
-        }
-        }
-        // full set: e_j = P_M[j]; <Y0,p> and <Y1,p>
-        float ev[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ev[c] = pm[c] > 0.f ? logf(pm[c]) + (float)pk[c] * 0.69314718f : LOG0F;
-        float t0[5], t1[5];
-        float mx0 = LOG0F, mx1 = LOG0F;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            // c == 4: the j = 0 term (e_0 = 1), carried by lane 0
-            const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
-            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
-            const float e = (c == 4) ? 0.f : ev[c < 4 ? c : 0];
-            const float kterm = (float)(M - j) * llam - lam;   // (M-j)! p_K(M-j), Poisson clutter (.bak:398-400)
-            t0[c] = ok ? e + Q.I0[ok ? j : 0] + kterm : LOG0F;
-            t1[c] = ok ? e + Q.I1[ok ? j : 0] + kterm : LOG0F;
-            mx0 = fmaxf(mx0, t0[c]); mx1 = fmaxf(mx1, t1[c]);
-        }
-        mx0 = wave_max_f(mx0); mx1 = wave_max_f(mx1);
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
-            const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
-            if (ok) { s0 += expf(t0[c] - mx0); s1 += expf(t1[c] - mx1); }
-        }
-        s0 = wave_sum(s0); s1 = wave_sum(s1);
-        if (lane == 0) { Q.scal[CQ_LY0] = safe_log(s0) + mx0; Q.scal[CQ_LY1] = safe_log(s1) + mx1; Q.efull[0] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
+        const int tiles = (M + 63) >> 6;
+        if (tiles == 1) cphd_esf_sweeps<1>(Q, T_scratch, M, lane, llam, lam);
+        else if (tiles == 2) cphd_esf_sweeps<2>(Q, T_scratch, M, lane, llam, lam);
+        else cphd_esf_sweeps<4>(Q, T_scratch, M, lane, llam, lam);
     }
     __syncthreads();
     const float lY0 = Q.scal[CQ_LY0];
