@@ -203,7 +203,7 @@ def test_capacity_overflow_is_reported():
 # ----------------------------------------------------------------------------------------------
 # particle weights, nEff, resampling
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 255, 256, 2048, 2049, 5000])
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 2048, 2049, 5000, 16384, 65536])
 def test_resample_bit_exact(n):
     P = pkg()
     rng = np.random.default_rng(n)
@@ -360,7 +360,7 @@ def test_frozen_steps_restart_from_the_same_snapshot():
 # ----------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties + sampled oracle comparison
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg_id,sample", [(2, 24), (3, 6)])
+@pytest.mark.parametrize("cfg_id,sample", [(2, 24), (3, 6), (4, 4)])
 def test_full_size_properties(cfg_id, sample):
     P, S = pkg(), synthetic()
     w = S.config_workload(cfg_id)
