@@ -172,12 +172,22 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(ts)
-    for _ in range(args.steps):
+    chunk = max(1, args.steps // 20)            # an (asynchronous) event every `chunk` steps: the spread of the step time
+    marks = []
+    for k in range(args.steps):
         step()
+        if (k + 1) % chunk == 0 and k + 1 < args.steps:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(ts)
+            marks.append(e)
     ev1.record(ts)
     sync()
     elapsed = time.perf_counter() - t0
     gpu_region_ms = ev0.elapsed_time(ev1)
+    edges = [ev0] + marks + [ev1]
+    counts = [chunk] * len(marks) + [args.steps - chunk * len(marks)]
+    per_step = sorted(a.elapsed_time(b) / c for a, b, c in zip(edges[:-1], edges[1:], counts) if c > 0)
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,6 +263,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_gpu_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
