@@ -379,6 +379,9 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
                 float mg = fabsf(d - cfg->minSeparation) / (fabsf(cfg->minSeparation) + FLT_MIN);
                 if (mg < margin_d) margin_d = mg;
             }
+            /* a NaN distance (Hellinger metric on a near-singular covariance: sqrt of a cancelled, slightly
+             * negative determinant, src/device_math.cuh:403-408) decides by the rounding noise of its inputs */
+            if (d != d) margin_d = 0;
             if (d < cfg->minSeparation) {                                /* :2806 */
                 member[i] = 1;
                 W += in[i].weight;

@@ -33,8 +33,12 @@ def make_filter(cfg, w, cap=None, mm=64, scap=0):
     return f
 
 
-def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, scap=0):
-    """one measurement update of every particle: survivors, merged map, Δlog-weight"""
+def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, scap=0, structural_maps=True):
+    """one measurement update of every particle: survivors, merged map, Δlog-weight.
+    structural_maps=False skips the device-map vs oracle-map comparison (the merge stage is still checked bit for
+    bit on the device's own survivors): the Hellinger distance of near-singular covariances cancels
+    catastrophically (src/device_math.cuh:373-413), so a 1-ulp difference between the two survivor sets can move
+    a distance by more than any fixed margin."""
     ocfg = oracle_config_from(cfg)
     n_struct = 0
     with make_filter(cfg, w, cap, mm, scap) as f:
@@ -62,7 +66,7 @@ def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, 
             if structural:
                 assert np.array_equal(sidx, ref["slab_idx"]), "particle %d: survivor sets differ" % p
                 assert_maps_close(surv, ref["survivors"], ordered=True, what="survivors of particle %d" % p)
-                if ref["margin"][0] > MERGE_MARGIN:
+                if structural_maps and ref["margin"][0] > MERGE_MARGIN:
                     n_struct += 1
                     assert_maps_close(maps[p], ref["map"], what="map of particle %d" % p)
         # normalised particle weights
