@@ -205,6 +205,34 @@ def main():
     f.timing(False)
     avg_ms = ms / np.maximum(cnt, 1)
 
+    # N > 1: where a step's time goes ("report resample-with-migration time separately") — the phases
+    # run back to back with a device synchronisation after each, so the parts add up to more than a pipelined step
+    breakdown = None
+    if world > 1:
+        acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
+        k_bd = min(args.steps, 50)
+
+        def tick():
+            torch.cuda.synchronize()
+            return time.perf_counter()
+
+        for _ in range(k_bd):
+            t_a = tick()
+            shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+            t_b = tick()
+            allw = sf.gather_logweights()
+            t_c = tick()
+            sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)
+            t_d = tick()
+            recv = sf._exchange(send[:sum(sc)], sc, rc, shard.pack_bytes())
+            t_e = tick()
+            shard.resample_end(recv)
+            t_f = tick()
+            for key, dt_ in zip(acc, (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)):
+                acc[key] += dt_
+        breakdown = {key: 1e6 * v / k_bd for key, v in acc.items()}
+        sync()
+
     # the same loop with the reference's trigger instead of a forced resample (nEff <= resample_threshold)
     unforced = None
     if world == 1:
@@ -274,7 +302,7 @@ def main():
                        "particles_total": N * world, "gaussians_per_particle": G, "measurements_per_step": M,
                        "value_counts": "shard-steps (ranks x steps) per second",
                        "max_survivors": st["max_survivors"], "max_map": st["max_map"],
-                       "steps_per_s_unforced_resample": unforced},
+                       "steps_per_s_unforced_resample": unforced, "multi_gpu_phase_us_rank0": breakdown},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,

@@ -2431,7 +2431,11 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st)
 {
-    static bool attr_set = false;
+    // function attributes are per device: set once for every device this process launches on
+    static bool attr_set_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
         // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
         const void* fns[4] = {(const void*)phd_update_merge_kernel<false, false, false>,
@@ -2486,7 +2490,10 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
     // one workgroup; small particle sets use a small one (cheaper barriers, same results: the
     // reductions are fixed trees per block size)
     // (the commit of the small kernel writes logw[j] for j < n: it needs n_new <= n, true for every caller)
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
