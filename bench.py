@@ -246,6 +246,22 @@ def main():
         sync()
         unforced = k_un / (time.perf_counter() - tu)
 
+    # stage breakdown from the diagnostic instantiation of the update kernel: in-kernel s_memrealtime
+    # stamps per workgroup (shares of the per-particle critical path; the stamped kernel is not the timed one)
+    stages = None
+    if world == 1 and args.config != 5:
+        names = ["classify+ekf", "normalisers", "nondetect_emit", "detect_emit", "finalise+births", "sort", "merge_rounds",
+                 "sort_by_seed", "segments", "moment_matching", "append"]
+        f.debug(2)
+        for _ in range(2):
+            f.update(w["z"][0])
+        f.sync()
+        st_ = f.stamps().astype(np.int64)
+        dd = np.diff(st_[:, :12], axis=1) * 0.01
+        stages = {nm: float(dd[:, k].mean()) for k, nm in enumerate(names)}
+        stages["workgroup_total"] = float(((st_[:, 11] - st_[:, 0]) * 0.01).mean())
+        f.debug(0)
+
     # in-run HBM ceiling: a device-to-device copy of 1 GiB on the same stream, read + write bytes
     copy_gbs = None
     if world == 1:
@@ -303,6 +319,7 @@ def main():
                        "value_counts": "shard-steps (ranks x steps) per second",
                        "max_survivors": st["max_survivors"], "max_map": st["max_map"],
                        "steps_per_s_unforced_resample": unforced, "multi_gpu_phase_us_rank0": breakdown},
+            "stages_us_per_workgroup": stages,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
