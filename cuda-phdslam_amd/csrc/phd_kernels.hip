@@ -49,6 +49,7 @@ namespace phd {
 #define PHD_MIN_WAVES 4      // launch bound: waves per SIMD the register allocation must allow
 #endif
 #define PHD_COLS (64 / PHD_NW) // window columns (= candidate seeds) owned by one wave
+#define PHD_SMALL_S 256        // survivor counts up to this take the single-shot merge (merge_small)
 #define NEAR_U_BASE 0x40000000
 // phase stamps of the diagnostic instantiation (100 MHz s_memrealtime), thread 0 of each workgroup
 #define STAMP(k) do { if (STAMPS && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -140,6 +141,8 @@ __device__ __forceinline__ double xor_lane(double v, int off)
 }
 template <int OFF> __device__ __forceinline__ float xor_lane_c(float v) { return __uint_as_float(xor_lane_c<OFF>(__float_as_uint(v))); }
 
+// value of lane l (wave-uniform l) as a scalar broadcast
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 // value of lane + 1 (lane 63 keeps its own), = __shfl_down(v, 1)
 __device__ __forceinline__ u32 lane_down1(u32 v) { return dpp_mov<0x130, 0xF>(v, v); }
 __device__ __forceinline__ float lane_down1(float v) { return __uint_as_float(lane_down1(__float_as_uint(v))); }
@@ -342,6 +345,8 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
     u32 amax = feat > sort1 ? feat : sort1;
     amax = amax > sort2 ? amax : sort2;
+    const u32 small = 2u * PHD_SMALL_S * 32u + 64u; // merge_small(): closeness rows, member columns, seed mask
+    amax = amax > small ? amax : small;
     p += amax;
     o.out_idx = p; p += align16u(2u * (u32)C);
     o.z_r = p; p += align16u(4u * (u32)MM);
@@ -370,6 +375,9 @@ struct Lds {
     lds_u32 khi, klo, pay;                        // sort 1
     lds_u32 key2;                                 // sort 2
     lds_i32 seg;                                  // cluster starts, S+1
+    LDS_T(u64)* srow;                             // merge_small: [256][4] closeness to earlier positions
+    LDS_T(u64)* scol;                             // merge_small: [256][4] members of the cluster seeded at a position
+    LDS_T(u64)* sseed;                            // merge_small: [4] seed mask
     // not aliased
     lds_u16 out_idx;                  // C
     lds_f32 z_r, z_b, logZ, zpart;    // MM, MM, MM, 4*MM
@@ -398,6 +406,9 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.pay = (lds_u32)(base + o.alias + 2u * sv);
     L.key2 = (lds_u32)(base + o.alias);
     L.seg = (lds_i32)(base + o.alias + sv);
+    L.srow = (LDS_T(u64)*)(base + o.alias);
+    L.scol = (LDS_T(u64)*)(base + o.alias + PHD_SMALL_S * 32u);
+    L.sseed = (LDS_T(u64)*)(base + o.alias + 2u * PHD_SMALL_S * 32u);
     L.out_idx = (lds_u16)(base + o.out_idx);
     L.z_r = (lds_f32)(base + o.z_r); L.z_b = (lds_f32)(base + o.z_b); L.logZ = (lds_f32)(base + o.logZ);
     L.zpart = (lds_f32)(base + o.zpart); L.zok = (lds_u32)(base + o.zok);
@@ -776,6 +787,236 @@ __device__ __forceinline__ bool is_close(float smx, float smy, float sxx, float 
 }
 
 // ------------------------------------------------------------------------------------------
+// merge_small: the same greedy merge for S <= 256 survivors in ONE shot instead of rounds.
+//
+// With at most 256 survivors every position is a candidate seed, so the whole decision structure fits in
+// 256-bit masks:  rank (counting, the idle threads share the key scan) -> planes permuted into
+// (weight desc, slab index asc) order -> row_k = {l < k : close(k, l)} for all pairs (wave = 64 positions x a
+// 128-column chunk, column data by LDS broadcast; cheap trace filter, then the exact decision) ->
+// seeds s_k = not exists l < k : close(k,l) and s_l, resolved by one wave, 64 positions at a time (earlier
+// blocks are final, inside a block the ballot fixed point of the round-based version) -> every position
+// joins the first seed of its row (LDS atomic OR into the seed's member mask) -> the thread that owns a seed
+// walks its members in ascending position = (weight desc) order and does the moment matching
+// (src/gm_reduce.cpp:103-118's order), including the reference's stop rule (src/phdfilter.cu:2821).
+// No second sort, no segment pass, no list compaction: 6 barriers instead of ~25.
+// ------------------------------------------------------------------------------------------
+template <bool HELLINGER, bool STAMPS>
+__device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig& cfg, float* __restrict__ out_slab, int cap,
+                                            int tid, u64* st, int n_update)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const float T = cfg.minSeparation;
+    const float Tpre = (T > 0.f) ? T * 1.01f : -1.f;
+    // ---- rank by counting; P2 slots, PHD_T / P2 helper threads per survivor share the scan of the keys
+    int P2 = 64;
+    while (P2 < S) P2 <<= 1;
+    const int nh = PHD_T / P2;
+    const int i = tid & (P2 - 1), h = tid / P2;
+    LDS_T(u64)* skey = L.srow;                 // [256] 64-bit keys (the row area is free until the ranks are known)
+    lds_u32 scnt = (lds_u32)(L.srow + PHD_SMALL_S);
+    u32 mh = 0, ml = 0;
+    float rw = 0, rmx = 0, rmy = 0, rxx = 0, rxy = 0, ryy = 0;
+    if (h == 0 && i < S) {
+        const int u0 = L.u[i];
+        mh = orderable(L.w[i]);
+        ml = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
+        skey[i] = ((u64)mh << 32) | ml;
+        scnt[i] = 0u;
+        rw = L.w[i]; rmx = L.mx[i]; rmy = L.my[i]; rxx = L.xx[i]; rxy = L.xy[i]; ryy = L.yy[i];
+    }
+    __syncthreads();
+    if (i < S) {
+        const u64 mine = skey[i];
+        const int per = (S + nh - 1) / nh;
+        const int j0 = h * per, j1 = (j0 + per < S) ? j0 + per : S;
+        int cnt = 0;
+#pragma unroll 8
+        for (int j = j0; j < j1; ++j) cnt += (skey[j] > mine) ? 1 : 0; // keys are unique: (weight, slab index)
+        if (nh > 1) atomicAdd((u32*)&scnt[i], (u32)cnt);
+        else scnt[i] = (u32)cnt;
+    }
+    __syncthreads();
+    if (h == 0 && i < S) {
+        const int rank = (int)scnt[i];
+        L.w[rank] = rw; L.mx[rank] = rmx; L.my[rank] = rmy;
+        L.xx[rank] = rxx; L.xy[rank] = rxy; L.yy[rank] = ryy;
+        const bool spd = (rxx > 0.f) && (ryy > 0.f) && (rxx * ryy - rxy * rxy > 0.f);
+        L.tr[rank] = spd ? (rxx + ryy) : INFINITY;
+    }
+    __syncthreads();
+    STAMP(6);
+    u64 tq0 = 0, tq1 = 0, tq2 = 0;
+    // ---- closeness rows: work items (block of 64 positions kb, block of 64 columns lc <= kb), dealt to the waves;
+    //      the 64 columns of an item sit in the lanes' registers and are broadcast with v_readlane (no LDS round
+    //      trip inside the loop)
+    {
+        static_assert(PHD_SMALL_S == 256, "merge_small uses four 64-bit words per row");
+        for (int t = tid; t < PHD_SMALL_S * 4; t += PHD_T) { L.srow[t] = 0ull; L.scol[t] = 0ull; }
+        __syncthreads();
+        if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
+        const int nblk = (S + 63) >> 6;
+        const int n_items = nblk * (nblk + 1) / 2;
+        for (int item = wave; item < n_items; item += PHD_NW) {
+            int kb = 0, lc = item;
+            while (lc > kb) { lc -= kb + 1; ++kb; }            // item -> (kb, lc), lc <= kb
+            const int k = 64 * kb + lane;
+            const bool kvalid = k < S;
+            const int kk = kvalid ? k : S - 1;
+            const float kmx = L.mx[kk], kmy = L.my[kk], ktr = L.tr[kk], kxx = L.xx[kk], kxy = L.xy[kk], kyy = L.yy[kk];
+            // cheap conservative filter over the item's 64 columns, branch-free; the column data are LDS broadcast
+            // reads (same address in every lane), 8 iterations in flight.  Columns >= S hold stale data of earlier
+            // steps: the test l < k (< S) masks them.
+            u64 cand = 0;
+            const int lbase = 64 * lc;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const int l = lbase + j;
+                const float dx = L.mx[l] - kmx, dy = L.my[l] - kmy;
+                const bool near = HELLINGER || !(2.f * (dx * dx + dy * dy) >= Tpre * (L.tr[l] + ktr));
+                cand |= (near && l < k) ? (1ull << j) : 0ull;
+            }
+            if (!kvalid) cand = 0;
+            // ... then the exact decision on the marked columns only (a handful per position)
+            u64 bits = 0;
+            while (cand) {
+                const int j = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int l = 64 * lc + j;
+                if (is_close<HELLINGER>(L.mx[l], L.my[l], L.xx[l], L.xy[l], L.yy[l], kmx, kmy, kxx, kxy, kyy, T)) bits |= 1ull << j;
+            }
+            L.srow[k * 4 + lc] = bits;
+        }
+    }
+    __syncthreads();
+    if (STAMPS && tid == 0) tq1 = __builtin_amdgcn_s_memrealtime();
+    // ---- seeds: one wave, block by block
+    if (wave == 0) {
+        u64 sd[4] = {0ull, 0ull, 0ull, 0ull};
+        const int nblk = (S + 63) >> 6;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < nblk) {
+                const int k = 64 * b + lane;
+                const bool kvalid = k < S;
+                u64 r0 = L.srow[k * 4 + 0], r1 = L.srow[k * 4 + 1], r2 = L.srow[k * 4 + 2], r3 = L.srow[k * 4 + 3];
+                // blocked by a (final) seed of an earlier block?
+                bool blocked = false;
+                if (b > 0) blocked = blocked || ((r0 & sd[0]) != 0ull);
+                if (b > 1) blocked = blocked || ((r1 & sd[1]) != 0ull);
+                if (b > 2) blocked = blocked || ((r2 & sd[2]) != 0ull);
+                const u64 row = (b == 0) ? r0 : (b == 1) ? r1 : (b == 2) ? r2 : r3;   // within the block
+                const u64 live = __ballot(kvalid && !blocked);
+                u64 seeds = live;
+                for (int it = 0; it < 65; ++it) {
+                    const u64 blk = __ballot((row & seeds) != 0ull);
+                    const u64 nx = live & ~blk;
+                    if (nx == seeds) break;
+                    seeds = nx;
+                }
+                sd[b] = seeds;
+            }
+        }
+        if (lane < 4) L.sseed[lane] = (lane == 0) ? sd[0] : (lane == 1) ? sd[1] : (lane == 2) ? sd[2] : sd[3];
+    }
+    __syncthreads();
+    if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
+    // ---- membership: every position joins the first seed of its row (a seed joins itself)
+    const u64 s0 = L.sseed[0], s1 = L.sseed[1], s2 = L.sseed[2], s3 = L.sseed[3];
+    bool is_seed = false;
+    if (tid < S) {
+        const int k = tid;
+        const u64 sw = (k < 64) ? s0 : (k < 128) ? s1 : (k < 192) ? s2 : s3;
+        is_seed = (sw >> (k & 63)) & 1ull;
+        int owner = k;
+        if (!is_seed) {
+            const u64 m0 = L.srow[k * 4 + 0] & s0, m1 = L.srow[k * 4 + 1] & s1, m2 = L.srow[k * 4 + 2] & s2,
+                      m3 = L.srow[k * 4 + 3] & s3;
+            owner = m0 ? __builtin_ctzll(m0) : m1 ? 64 + __builtin_ctzll(m1) : m2 ? 128 + __builtin_ctzll(m2)
+                                                                            : 192 + __builtin_ctzll(m3);
+        }
+        atomicOr((u64*)&L.scol[owner * 4 + (k >> 6)], 1ull << (k & 63));
+    }
+    if (tid == 0) L.ctr[CTR_KOUT] = 0x7FFFFFFF;
+    __syncthreads();
+    if (STAMPS && tid == 0) {
+        const u64 tq3 = __builtin_amdgcn_s_memrealtime();
+        st[12] += tq1 - tq0; st[13] += tq2 - tq1; st[14] += tq3 - tq2; st[15] += 1;
+    }
+    STAMP(7);
+    STAMP(8);
+    STAMP(9);
+    // ---- moment matching: the thread that owns a seed, members in ascending position
+    const int n_clusters = __popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3);
+    if (is_seed) {
+#pragma clang fp contract(off)
+        const int k = tid;
+        const u64 below = (k & 63) ? (~0ull >> (64 - (k & 63))) : 0ull;
+        int c = 0; // cluster index = seeds before this one
+        c += (k >= 64) ? __popcll(s0) : __popcll(s0 & below);
+        if (k >= 64) c += (k >= 128) ? __popcll(s1) : __popcll(s1 & below);
+        if (k >= 128) c += (k >= 192) ? __popcll(s2) : __popcll(s2 & below);
+        if (k >= 192) c += __popcll(s3 & below);
+        u64 mem[4] = {L.scol[k * 4 + 0], L.scol[k * 4 + 1], L.scol[k * 4 + 2], L.scol[k * 4 + 3]};
+        const float smx = L.mx[k], smy = L.my[k], sxx = L.xx[k], sxy = L.xy[k], syy = L.yy[k];
+        const float dself = HELLINGER ? hellinger_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy)
+                                      : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
+        const bool selfok = dself < T;
+        if (!selfok) mem[k >> 6] &= ~(1ull << (k & 63)); // a seed that is not close to itself is not in its own cluster
+        float W = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            u64 m = mem[wd];
+            while (m) {
+                const int p = 64 * wd + __builtin_ctzll(m);
+                m &= m - 1;
+                const float w = L.w[p];
+                W += w;
+                sx += w * L.mx[p];
+                sy += w * L.my[p];
+            }
+        }
+        // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then
+        // yields W == 0
+        int stop_at = 0x7FFFFFFF;
+        if (W == 0.f) stop_at = c;
+        else if (!selfok) stop_at = c + 1;
+        if (stop_at != 0x7FFFFFFF) atomicMin((int*)&L.ctr[CTR_KOUT], stop_at);
+        if (W != 0.f && c < cap) {
+            const float mx = sx / W, my = sy / W;
+            float cxx = 0.f, cxy = 0.f, cyy = 0.f;
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                u64 m = mem[wd];
+                while (m) {
+                    const int p = 64 * wd + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float w = L.w[p];
+                    const float d0 = mx - L.mx[p];
+                    const float d1 = my - L.my[p];
+                    cxx += w * (L.xx[p] + d0 * d0);
+                    cxy += w * (L.xy[p] + d0 * d1);
+                    cyy += w * (L.yy[p] + d1 * d1);
+                }
+            }
+            out_slab[0 * cap + c] = W;
+            out_slab[1 * cap + c] = mx;
+            out_slab[2 * cap + c] = my;
+            out_slab[3 * cap + c] = cxx / W;
+            out_slab[4 * cap + c] = cxy / W;
+            out_slab[5 * cap + c] = cyy / W;
+        }
+    }
+    __syncthreads();
+    STAMP(10);
+    if (tid == 0) {
+        int k = L.ctr[CTR_KOUT];
+        if (k > n_clusters) k = n_clusters;
+        L.ctr[CTR_KOUT] = k;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
 // the greedy merge on the survivors held in LDS; writes the merged map to the output slab.
 // Returns (in ctr[CTR_KOUT]) the number of merged Gaussians.
 // ------------------------------------------------------------------------------------------
@@ -790,6 +1031,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     const int S = n_surv;
     if (tid == 0) { L.ctr[CTR_KOUT] = 0; L.ctr[CTR_NHEAD] = 0; }
     if (S == 0) { __syncthreads(); return; }
+    if (S <= PHD_SMALL_S) { merge_small<HELLINGER, STAMPS>(L, S, cfg, out_slab, cap, tid, st, n_update); return; }
 
     // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
     int n_pad = 2;

@@ -71,7 +71,7 @@ def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, 
                     assert_maps_close(maps[p], ref["map"], what="map of particle %d" % p)
         # normalised particle weights
         ref_lw = O.normalize_weights(w["logw"], dlw)
-        assert np.abs(logw - ref_lw).max() < 1e-5
+        assert np.abs(logw - ref_lw).max() < 1e-5 + 2e-6 * np.abs(ref_lw).max(), np.abs(logw - ref_lw).max()  # fp32 ulp of the values
     assert n_struct >= min_structural * w["N"], "only %d of %d particles were structurally comparable" % (n_struct, w["N"])
     return st
 
