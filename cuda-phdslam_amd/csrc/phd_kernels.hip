@@ -197,6 +197,20 @@ __device__ __forceinline__ float block_sum(float v, LDS_T(float)* scratch, int t
     return r;
 }
 
+// two block sums behind one pair of barriers (each value takes exactly block_sum's tree: same bits);
+// scratch: 2 * PHD_NW floats
+__device__ __forceinline__ void block_sum2(float a, float b, LDS_T(float)* scratch, int tid, float& ra, float& rb)
+{
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((tid & 63) == 0) { scratch[tid >> 6] = a; scratch[PHD_NW + (tid >> 6)] = b; }
+    __syncthreads();
+    ra = scratch[0]; rb = scratch[PHD_NW];
+#pragma unroll
+    for (int w = 1; w < PHD_NW; ++w) { ra += scratch[w]; rb += scratch[PHD_NW + w]; }
+}
+
 __device__ __forceinline__ u32 orderable(float w)
 {
     u32 b = __float_as_uint(w);
@@ -345,7 +359,7 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
     u32 amax = feat > sort1 ? feat : sort1;
     amax = amax > sort2 ? amax : sort2;
-    const u32 small = 2u * PHD_SMALL_S * 32u + 64u; // merge_small(): closeness rows, member columns, seed mask
+    const u32 small = 2u * PHD_SMALL_S * 32u + 64u + 2u * PHD_SMALL_S * 16u; // merge_small(): rows, member columns, seeds, staged planes
     amax = amax > small ? amax : small;
     p += amax;
     o.out_idx = p; p += align16u(2u * (u32)C);
@@ -357,7 +371,7 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.bgeo = p; p += align16u(20u * (u32)MM);
     o.part = p; p += 4u * PHD_NW * 64u;
     o.win = p; p += 4u * 7u * 64u;
-    o.red = p; p += align16u(4u * (PHD_NW + 4));
+    o.red = p; p += align16u(4u * (2 * PHD_NW + 4));
     o.ctr = p; p += 4u * 32u;
     o.total = p;
     return o;
@@ -378,6 +392,8 @@ struct Lds {
     LDS_T(u64)* srow;                             // merge_small: [256][4] closeness to earlier positions
     LDS_T(u64)* scol;                             // merge_small: [256][4] members of the cluster seeded at a position
     LDS_T(u64)* sseed;                            // merge_small: [4] seed mask
+    LDS_T(v4f)* sA;                               // merge_small: [256] (mx, my, 0.505 T tr, w) in sorted order
+    LDS_T(v4f)* sB;                               // merge_small: [256] (xx, xy, yy, -)
     // not aliased
     lds_u16 out_idx;                  // C
     lds_f32 z_r, z_b, logZ, zpart;    // MM, MM, MM, 4*MM
@@ -409,6 +425,8 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.srow = (LDS_T(u64)*)(base + o.alias);
     L.scol = (LDS_T(u64)*)(base + o.alias + PHD_SMALL_S * 32u);
     L.sseed = (LDS_T(u64)*)(base + o.alias + 2u * PHD_SMALL_S * 32u);
+    L.sA = (LDS_T(v4f)*)(base + o.alias + 2u * PHD_SMALL_S * 32u + 64u);
+    L.sB = (LDS_T(v4f)*)(base + o.alias + 2u * PHD_SMALL_S * 32u + 64u + PHD_SMALL_S * 16u);
     L.out_idx = (lds_u16)(base + o.out_idx);
     L.z_r = (lds_f32)(base + o.z_r); L.z_b = (lds_f32)(base + o.z_b); L.logZ = (lds_f32)(base + o.logZ);
     L.zpart = (lds_f32)(base + o.zpart); L.zok = (lds_u32)(base + o.zok);
@@ -838,53 +856,62 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
     __syncthreads();
     if (h == 0 && i < S) {
         const int rank = (int)scnt[i];
-        L.w[rank] = rw; L.mx[rank] = rmx; L.my[rank] = rmy;
-        L.xx[rank] = rxx; L.xy[rank] = rxy; L.yy[rank] = ryy;
         const bool spd = (rxx > 0.f) && (ryy > 0.f) && (rxx * ryy - rxy * rxy > 0.f);
-        L.tr[rank] = spd ? (rxx + ryy) : INFINITY;
+        const float tr = spd ? (rxx + ryy) : INFINITY;
+        // the sorted order lives in two float4 arrays (the SoA planes keep the arrival order): one ds_read_b128 per
+        // column in the filter, two per operand in the exact test and the moment matching
+        L.sA[rank] = (v4f){rmx, rmy, 0.5f * Tpre * tr, rw};
+        L.sB[rank] = (v4f){rxx, rxy, ryy, 0.f};
     }
     __syncthreads();
     STAMP(6);
     u64 tq0 = 0, tq1 = 0, tq2 = 0;
-    // ---- closeness rows: work items (block of 64 positions kb, block of 64 columns lc <= kb), dealt to the waves;
-    //      the 64 columns of an item sit in the lanes' registers and are broadcast with v_readlane (no LDS round
-    //      trip inside the loop)
+    // ---- closeness rows: work units (block of 64 positions kb, 16 columns of a column block lc <= kb), dealt
+    //      round-robin to the waves; a unit fills one 16-bit quarter of the row word srow[k][lc]
     {
         static_assert(PHD_SMALL_S == 256, "merge_small uses four 64-bit words per row");
-        for (int t = tid; t < PHD_SMALL_S * 4; t += PHD_T) { L.srow[t] = 0ull; L.scol[t] = 0ull; }
-        __syncthreads();
+        // (the rows are not cleared: every quarter a later phase reads — words lc <= kb of the rows k < S — is written
+        //  below; the member masks are cleared here, they are first touched two barriers later)
+        for (int t = tid; t < PHD_SMALL_S * 4; t += PHD_T) L.scol[t] = 0ull;
         if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
+        LDS_T(u16)* srow16 = (LDS_T(u16)*)L.srow;
         const int nblk = (S + 63) >> 6;
-        const int n_items = nblk * (nblk + 1) / 2;
-        for (int item = wave; item < n_items; item += PHD_NW) {
-            int kb = 0, lc = item;
+        const int n_units = 4 * (nblk * (nblk + 1) / 2);
+        for (int unit = wave; unit < n_units; unit += PHD_NW) {
+            const int q = unit & 3;
+            int kb = 0, lc = unit >> 2;
             while (lc > kb) { lc -= kb + 1; ++kb; }            // item -> (kb, lc), lc <= kb
+            const int lbase = 64 * lc + 16 * q;
             const int k = 64 * kb + lane;
+            if (lbase >= S) { srow16[(k * 4 + lc) * 4 + q] = 0; continue; }   // uniform: no such columns
             const bool kvalid = k < S;
             const int kk = kvalid ? k : S - 1;
-            const float kmx = L.mx[kk], kmy = L.my[kk], ktr = L.tr[kk], kxx = L.xx[kk], kxy = L.xy[kk], kyy = L.yy[kk];
-            // cheap conservative filter over the item's 64 columns, branch-free; the column data are LDS broadcast
-            // reads (same address in every lane), 8 iterations in flight.  Columns >= S hold stale data of earlier
-            // steps: the test l < k (< S) masks them.
-            u64 cand = 0;
-            const int lbase = 64 * lc;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
+            const v4f ka = L.sA[kk], kbv = L.sB[kk];
+            const float kmx = ka.x, kmy = ka.y, kat = ka.z, kxx = kbv.x, kxy = kbv.y, kyy = kbv.z;
+            // cheap conservative filter over the unit's 16 columns, branch-free: d^2 < 0.505 T (tr_l + tr_k)
+            // (d >= 2|dm|^2/(tr Pa + tr Pb) for SPD covariances, 1 % guard band; +inf trace = "always a candidate").
+            // The column data are LDS broadcast reads (same address in every lane), all 16 in flight.
+            // Columns >= S hold stale data of earlier steps: the test l < k (< S) masks them.
+            u32 cand = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
                 const int l = lbase + j;
-                const float dx = L.mx[l] - kmx, dy = L.my[l] - kmy;
-                const bool near = HELLINGER || !(2.f * (dx * dx + dy * dy) >= Tpre * (L.tr[l] + ktr));
-                cand |= (near && l < k) ? (1ull << j) : 0ull;
+                const v4f ca = L.sA[l];
+                const float dx = ca.x - kmx, dy = ca.y - kmy;
+                const bool near = HELLINGER || !(dx * dx + dy * dy >= ca.z + kat);
+                cand |= (near && l < k) ? (1u << j) : 0u;
             }
             if (!kvalid) cand = 0;
             // ... then the exact decision on the marked columns only (a handful per position)
-            u64 bits = 0;
+            u32 bits = 0;
             while (cand) {
-                const int j = __builtin_ctzll(cand);
+                const int j = __builtin_ctz(cand);
                 cand &= cand - 1;
-                const int l = 64 * lc + j;
-                if (is_close<HELLINGER>(L.mx[l], L.my[l], L.xx[l], L.xy[l], L.yy[l], kmx, kmy, kxx, kxy, kyy, T)) bits |= 1ull << j;
+                const int l = lbase + j;
+                const v4f la = L.sA[l], lb = L.sB[l];
+                if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, kmx, kmy, kxx, kxy, kyy, T)) bits |= 1u << j;
             }
-            L.srow[k * 4 + lc] = bits;
+            srow16[(k * 4 + lc) * 4 + q] = (u16)bits;
         }
     }
     __syncthreads();
@@ -929,8 +956,9 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
         is_seed = (sw >> (k & 63)) & 1ull;
         int owner = k;
         if (!is_seed) {
-            const u64 m0 = L.srow[k * 4 + 0] & s0, m1 = L.srow[k * 4 + 1] & s1, m2 = L.srow[k * 4 + 2] & s2,
-                      m3 = L.srow[k * 4 + 3] & s3;
+            const int kbk = k >> 6;                  // words beyond the position's own block were never written
+            const u64 m0 = L.srow[k * 4 + 0] & s0, m1 = (kbk >= 1) ? (L.srow[k * 4 + 1] & s1) : 0ull,
+                      m2 = (kbk >= 2) ? (L.srow[k * 4 + 2] & s2) : 0ull, m3 = (kbk >= 3) ? (L.srow[k * 4 + 3] & s3) : 0ull;
             owner = m0 ? __builtin_ctzll(m0) : m1 ? 64 + __builtin_ctzll(m1) : m2 ? 128 + __builtin_ctzll(m2)
                                                                             : 192 + __builtin_ctzll(m3);
         }
@@ -957,7 +985,8 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
         if (k >= 128) c += (k >= 192) ? __popcll(s2) : __popcll(s2 & below);
         if (k >= 192) c += __popcll(s3 & below);
         u64 mem[4] = {L.scol[k * 4 + 0], L.scol[k * 4 + 1], L.scol[k * 4 + 2], L.scol[k * 4 + 3]};
-        const float smx = L.mx[k], smy = L.my[k], sxx = L.xx[k], sxy = L.xy[k], syy = L.yy[k];
+        const v4f sa = L.sA[k], sb = L.sB[k];
+        const float smx = sa.x, smy = sa.y, sxx = sb.x, sxy = sb.y, syy = sb.z;
         const float dself = HELLINGER ? hellinger_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy)
                                       : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
         const bool selfok = dself < T;
@@ -969,10 +998,11 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
             while (m) {
                 const int p = 64 * wd + __builtin_ctzll(m);
                 m &= m - 1;
-                const float w = L.w[p];
+                const v4f pa = L.sA[p];
+                const float w = pa.w;
                 W += w;
-                sx += w * L.mx[p];
-                sy += w * L.my[p];
+                sx += w * pa.x;
+                sy += w * pa.y;
             }
         }
         // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then
@@ -990,12 +1020,13 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
                 while (m) {
                     const int p = 64 * wd + __builtin_ctzll(m);
                     m &= m - 1;
-                    const float w = L.w[p];
-                    const float d0 = mx - L.mx[p];
-                    const float d1 = my - L.my[p];
-                    cxx += w * (L.xx[p] + d0 * d0);
-                    cxy += w * (L.xy[p] + d0 * d1);
-                    cyy += w * (L.yy[p] + d1 * d1);
+                    const v4f pa = L.sA[p], pb = L.sB[p];
+                    const float w = pa.w;
+                    const float d0 = mx - pa.x;
+                    const float d1 = my - pa.y;
+                    cxx += w * (pb.x + d0 * d0);
+                    cxy += w * (pb.y + d0 * d1);
+                    cyy += w * (pb.z + d1 * d1);
                 }
             }
             out_slab[0 * cap + c] = W;
@@ -1959,8 +1990,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                                  L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m);
     }
     {
-        const float lz_sum = block_sum(lz_local, L.red, tid);
-        const float pdw = block_sum(pdw_local, L.red, tid);
+        float lz_sum, pdw;
+        block_sum2(lz_local, pdw_local, L.red, tid, lz_sum, pdw);
         // particle_weighting == 0 (:2260-2263): sum_m log Z_m - (sum_j pd_j w_j + M * birthWeight)
         if (tid == 0) {
             const float dl = lz_sum - (pdw + (float)M * cfg.birthWeight);
