@@ -354,7 +354,8 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.w = p; p += sv; o.mx = p; p += sv; o.my = p; p += sv; o.xx = p; p += sv;
     o.xy = p; p += sv; o.yy = p; p += sv; o.tr = p; p += sv; o.u = p; p += sv;
     o.alias = p;
-    const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C);
+    const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C) + 2u * align16u(16u * (u32)C) +
+                     align16u(8u * (u32)C);
     const u32 sort1 = 3u * sv;
     const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
     u32 amax = feat > sort1 ? feat : sort1;
@@ -386,6 +387,9 @@ struct Lds {
     LDS_T(v4f)* f_a;                           // per in-range feature: (r, b, S00, S01+S10)
     LDS_T(v2f)* f_c;                           //                       (S11, folded log-weight base)
     lds_u16 f_idx;                                // map index of in-range feature j
+    LDS_T(v4f)* f_k;                              // Kalman gain K0..K3 of in-range feature j
+    LDS_T(v4f)* f_p;                              // Joseph-form updated covariance (xx, xy, yy, -): the same for every measurement
+    LDS_T(v2f)* f_m;                              // prior mean
     lds_u32 khi, klo, pay;                        // sort 1
     lds_u32 key2;                                 // sort 2
     lds_i32 seg;                                  // cluster starts, S+1
@@ -415,7 +419,10 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     u32 f = o.alias;
     L.f_a = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
     L.f_c = (LDS_T(v2f)*)(base + f); f += align16u(8u * (u32)C);
-    L.f_idx = (lds_u16)(base + f);
+    L.f_idx = (lds_u16)(base + f); f += align16u(2u * (u32)C);
+    L.f_k = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
+    L.f_p = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
+    L.f_m = (LDS_T(v2f)*)(base + f);
     const u32 sv = align16u(4u * (u32)S);
     L.khi = (lds_u32)(base + o.alias);
     L.klo = (lds_u32)(base + o.alias + sv);
@@ -1862,6 +1869,15 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                 L.f_a[j] = (v4f){t.r, t.b, t.s00, t.s12};
                 L.f_c[j] = (v2f){t.s11, lw0 - safe_log(6.2831855f) - 0.5f * safe_log(t.det)};
                 L.f_idx[j] = (u16)i;
+                {
+                    // gain and Joseph covariance do not depend on the measurement (src/phdfilter.cu:1884-1901):
+                    // once per feature here, not once per surviving detection term in the finalise pass
+                    float oxx, oxy, oyy;
+                    joseph_cov(t, pxx, pxy, pyy, cfg, oxx, oxy, oyy);
+                    L.f_k[j] = (v4f){t.K0, t.K1, t.K2, t.K3};
+                    L.f_p[j] = (v4f){oxx, oxy, oyy, 0.f};
+                    L.f_m[j] = (v2f){mx, my};
+                }
                 pdw_local += t.pd * w;
                 nd_j = j;
             } else if (cls == 0) {
@@ -2044,18 +2060,13 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (u < u_det_lo || u >= u_det_hi) continue;
             const int m = (u - n_in) / n_in;
             const int j = (u - n_in) - m * n_in;
-            const int i = L.f_idx[j];
-            const float fmx = in[1 * cap + i], fmy = in[2 * cap + i];
-            const float pxx = in[3 * cap + i], pxy = in[4 * cap + i], pyy = in[5 * cap + i];
-            EkfTerms t;
-            ekf_terms(fmx, fmy, pxx, pxy, pyy, pose, cfg, t);
-            float oxx, oxy, oyy;
-            joseph_cov(t, pxx, pxy, pyy, cfg, oxx, oxy, oyy);
-            const float i0 = L.z_r[m] - t.r;
-            const float i1 = wrap_angle(L.z_b[m] - t.b);
-            L.mx[s] = fmx + t.K0 * i0 + t.K2 * i1;                                                   // :1903-1904
-            L.my[s] = fmy + t.K1 * i0 + t.K3 * i1;
-            L.xx[s] = oxx; L.xy[s] = oxy; L.yy[s] = oyy;
+            const v4f fa = L.f_a[j], K = L.f_k[j], Pn = L.f_p[j];
+            const v2f fm = L.f_m[j];
+            const float i0 = L.z_r[m] - fa.x;
+            const float i1 = wrap_angle(L.z_b[m] - fa.y);
+            L.mx[s] = fm.x + K.x * i0 + K.z * i1;                                                    // :1903-1904
+            L.my[s] = fm.y + K.y * i0 + K.w * i1;
+            L.xx[s] = Pn.x; L.xy[s] = Pn.y; L.yy[s] = Pn.z;
         }
     }
     __syncthreads();
