@@ -355,7 +355,7 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.xy = p; p += sv; o.yy = p; p += sv; o.tr = p; p += sv; o.u = p; p += sv;
     o.alias = p;
     const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C) + 2u * align16u(16u * (u32)C) +
-                     align16u(8u * (u32)C);
+                     align16u(4u * (u32)C);
     const u32 sort1 = 3u * sv;
     const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
     u32 amax = feat > sort1 ? feat : sort1;
@@ -388,8 +388,8 @@ struct Lds {
     LDS_T(v2f)* f_c;                           //                       (S11, folded log-weight base)
     lds_u16 f_idx;                                // map index of in-range feature j
     LDS_T(v4f)* f_k;                              // Kalman gain K0..K3 of in-range feature j
-    LDS_T(v4f)* f_p;                              // Joseph-form updated covariance (xx, xy, yy, -): the same for every measurement
-    LDS_T(v2f)* f_m;                              // prior mean
+    LDS_T(v4f)* f_p;                              // Joseph-form updated covariance (the same for every measurement) and prior mean x: (xx, xy, yy, mx)
+    lds_f32 f_my;                                 // prior mean y
     lds_u32 khi, klo, pay;                        // sort 1
     lds_u32 key2;                                 // sort 2
     lds_i32 seg;                                  // cluster starts, S+1
@@ -422,7 +422,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.f_idx = (lds_u16)(base + f); f += align16u(2u * (u32)C);
     L.f_k = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
     L.f_p = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
-    L.f_m = (LDS_T(v2f)*)(base + f);
+    L.f_my = (lds_f32)(base + f);
     const u32 sv = align16u(4u * (u32)S);
     L.khi = (lds_u32)(base + o.alias);
     L.klo = (lds_u32)(base + o.alias + sv);
@@ -1875,8 +1875,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                     float oxx, oxy, oyy;
                     joseph_cov(t, pxx, pxy, pyy, cfg, oxx, oxy, oyy);
                     L.f_k[j] = (v4f){t.K0, t.K1, t.K2, t.K3};
-                    L.f_p[j] = (v4f){oxx, oxy, oyy, 0.f};
-                    L.f_m[j] = (v2f){mx, my};
+                    L.f_p[j] = (v4f){oxx, oxy, oyy, mx};
+                    L.f_my[j] = my;
                 }
                 pdw_local += t.pd * w;
                 nd_j = j;
@@ -2061,11 +2061,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const int m = (u - n_in) / n_in;
             const int j = (u - n_in) - m * n_in;
             const v4f fa = L.f_a[j], K = L.f_k[j], Pn = L.f_p[j];
-            const v2f fm = L.f_m[j];
             const float i0 = L.z_r[m] - fa.x;
             const float i1 = wrap_angle(L.z_b[m] - fa.y);
-            L.mx[s] = fm.x + K.x * i0 + K.z * i1;                                                    // :1903-1904
-            L.my[s] = fm.y + K.y * i0 + K.w * i1;
+            L.mx[s] = Pn.w + K.x * i0 + K.z * i1;                                                    // :1903-1904
+            L.my[s] = L.f_my[j] + K.y * i0 + K.w * i1;
             L.xx[s] = Pn.x; L.xy[s] = Pn.y; L.yy[s] = Pn.z;
         }
     }
