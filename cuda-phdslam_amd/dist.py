@@ -82,8 +82,12 @@ class ShardedFilter:
             host = torch.empty(self.n_global, dtype=raw.dtype)
             dist.all_gather_into_tensor(host, raw.cpu().contiguous(), group=self.group)
             return host.to(raw.device)
-        allw = torch.empty(self.n_global, dtype=raw.dtype, device=raw.device)
-        dist.all_gather_into_tensor(allw, raw.contiguous(), group=self.group)
+        # the gather buffer lives as long as the filter (one allocation, not one per step); the kernels that read it
+        # are stream-ordered before the next step's gather overwrites it
+        allw = getattr(self, "_allw", None)
+        if allw is None or allw.device != raw.device:
+            allw = self._allw = torch.empty(self.n_global, dtype=raw.dtype, device=raw.device)
+        dist.all_gather_into_tensor(allw, raw, group=self.group)
         return allw
 
     def normalize(self, all_logw, want_neff=True):
@@ -111,7 +115,10 @@ class ShardedFilter:
                         dist.send(mine, r, group=self.group)
                 pieces.append(piece)
             return torch.cat(pieces).to(out_buf.device)
-        in_buf = torch.empty((max(sum(recv_counts), 1), pack), dtype=torch.uint8, device=out_buf.device)
+        # a shard receives at most one particle per slot: one receive buffer of n rows for the whole run
+        in_buf = getattr(self, "_recv", None)
+        if in_buf is None or in_buf.shape[1] != pack or in_buf.device != out_buf.device:
+            in_buf = self._recv = torch.empty((max(self.n, 1), pack), dtype=torch.uint8, device=out_buf.device)
         dist.all_to_all_single(in_buf[:sum(recv_counts)], out_buf, output_split_sizes=recv_counts,
                                input_split_sizes=send_counts, group=self.group)
         return in_buf
@@ -205,10 +212,13 @@ class GpuShard:
         return torch.as_tensor(h, device=self.device)
 
     def raw_logweights(self):
-        p = self._C.c_void_p()
-        self._check(self._lib().phd_raw_logweights_dev(self.f._h, self._C.byref(p)), "phd_raw_logweights_dev")
+        cached = getattr(self, "_raw", None)
+        if cached is None or cached[0] != self.f.n:          # the device buffer is fixed for the filter's lifetime
+            p = self._C.c_void_p()
+            self._check(self._lib().phd_raw_logweights_dev(self.f._h, self._C.byref(p)), "phd_raw_logweights_dev")
+            cached = self._raw = (self.f.n, self._wrap(p.value, self.f.n))
         self._filter_to_torch()
-        return self._wrap(p.value, self.f.n)
+        return cached[1]
 
     def update_local_dev(self, d_z, n_meas):
         self._check(self._lib().phd_update_local_dev(self.f._h, self._ptr(d_z), int(n_meas)), "phd_update_local_dev")
@@ -271,8 +281,11 @@ class GpuShard:
         self._filter_to_torch()
         pack = self.pack_bytes()
         n_send = max(sum(sc), 1)
-        send = self._wrap(buf.value, n_send * pack // 4).view(torch.uint8).view(n_send, pack)
-        return sc, rc, send, idx
+        cached = getattr(self, "_send", None)                 # the library's send buffer only moves when it grows
+        if cached is None or cached[0] != buf.value or cached[1] < n_send:
+            rows = max(n_send, self.f.n)
+            cached = self._send = (buf.value, rows, self._wrap(buf.value, rows * pack // 4).view(torch.uint8).view(rows, pack))
+        return sc, rc, cached[2], idx
 
     def resample_end(self, recv):
         self._torch_to_filter()
