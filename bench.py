@@ -111,11 +111,20 @@ def main():
     share = os.environ.get("PHD_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    # PHD_BENCH_ONE_RANK_RCCL=1 (with --gpus 1): the N > 1 step — local step, RCCL all-gather, global resample, RCCL
+    # all-to-all — on a ONE-rank RCCL group: what the collective path costs per step before any link is involved.
+    # A diagnostic (labelled in config), not the N = 1 measurement.
+    one_rank = world == 1 and os.environ.get("PHD_BENCH_ONE_RANK_RCCL") == "1"
+    multi = world > 1 or one_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         if share:
             dist.init_process_group("gloo")
+        elif one_rank:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -144,24 +153,34 @@ def main():
     torch.cuda.synchronize()
 
     f.set_frozen(True)  # steady state: no step commits, every iteration restarts from the same snapshot
-    if world == 1:
+    if not multi:
         def step():
             f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=True)
     else:
         shard = D.GpuShard(f, N * world)
         sf = D.ShardedFilter(shard, N * world, rank, world)
+        sf.collectives = True
+        if os.environ.get("PHD_BENCH_EXCHANGE") == "alltoall":
+            sf.gathered_limit = 0
+        gathered = sf.gathered()                    # small shards (this config up to 8 ranks): whole-shard all-gather
 
         def step():
-            # one launch for predict + update + prune + merge + raw weights, one RCCL all-gather, one launch for the
-            # global normalise + resample indices, one RCCL all-to-all for the migrating particles, commit
+            # one launch for predict + update + prune + merge + raw weights, then
             shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
-            allw = sf.gather_logweights()
-            sf.resample(u, all_raw_logw=allw)       # the bench forces the resample: no host round trip for nEff
+            if gathered:
+                # export -> ONE fixed-size RCCL all-gather of the shards (raw weights in the row headers) -> global
+                # normalise + resample indices + import of this shard's parents: nothing waits for the host
+                sf.resample_gathered(u, weights_in_rows=True, want_idx=False)
+            else:
+                # RCCL all-gather of the raw weights, one launch for the global normalise + resample indices (indices
+                # to the host for the plan), RCCL all-to-all of the migrating particles, commit
+                allw = sf.gather_logweights()
+                sf.resample(u, all_raw_logw=allw)   # the bench forces the resample: no host round trip for nEff
 
     def sync():
         f.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -188,7 +207,7 @@ def main():
     counts = [chunk] * len(marks) + [args.steps - chunk * len(marks)]
     per_step = sorted(a.elapsed_time(b) / c for a, b, c in zip(edges[:-1], edges[1:], counts) if c > 0)
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -208,34 +227,47 @@ def main():
     # N > 1: where a step's time goes ("report resample-with-migration time separately") — the phases
     # run back to back with a device synchronisation after each, so the parts add up to more than a pipelined step
     breakdown = None
-    if world > 1:
-        acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
+    if multi:
         k_bd = min(args.steps, 50)
 
         def tick():
             torch.cuda.synchronize()
             return time.perf_counter()
 
+        if gathered:
+            acc = {"local_step": 0.0, "export_shard": 0.0, "all_gather_rows": 0.0, "normalise+indices+import": 0.0}
+        else:
+            acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
         for _ in range(k_bd):
             t_a = tick()
             shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
             t_b = tick()
-            allw = sf.gather_logweights()
-            t_c = tick()
-            sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)
-            t_d = tick()
-            recv = sf._exchange(send[:sum(sc)], sc, rc, shard.pack_bytes())
-            t_e = tick()
-            shard.resample_end(recv)
-            t_f = tick()
-            for key, dt_ in zip(acc, (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)):
+            if gathered:
+                rows = shard.export_shard()
+                t_c = tick()
+                allrows = sf._gather_rows(rows)
+                t_d = tick()
+                shard.resample_gathered(allrows, u, world, rank, True, False)
+                t_e = tick()
+                ts_ = (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)
+            else:
+                allw = sf.gather_logweights()
+                t_c = tick()
+                sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)
+                t_d = tick()
+                recv = sf._exchange(send[:sum(sc)], sc, rc, shard.pack_bytes())
+                t_e = tick()
+                shard.resample_end(recv)
+                t_f = tick()
+                ts_ = (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)
+            for key, dt_ in zip(acc, ts_):
                 acc[key] += dt_
         breakdown = {key: 1e6 * v / k_bd for key, v in acc.items()}
         sync()
 
     # the same loop with the reference's trigger instead of a forced resample (nEff <= resample_threshold)
     unforced = None
-    if world == 1:
+    if not multi:
         k_un = min(args.steps, 200)
         for _ in range(5):
             f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
@@ -249,7 +281,7 @@ def main():
     # stage breakdown from the diagnostic instantiation of the update kernel: in-kernel s_memrealtime
     # stamps per workgroup (shares of the per-particle critical path; the stamped kernel is not the timed one)
     stages = None
-    if world == 1 and args.config != 5:
+    if not multi and args.config != 5:
         names = ["classify+ekf", "normalisers", "nondetect_emit", "detect_emit", "finalise+births", "sort", "merge_rounds",
                  "sort_by_seed", "segments", "moment_matching", "append"]
         f.debug(2)
@@ -264,7 +296,7 @@ def main():
 
     # in-run HBM ceiling: a device-to-device copy of 1 GiB on the same stream, read + write bytes
     copy_gbs = None
-    if world == 1:
+    if not multi:
         src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
         dst_t = torch.empty_like(src_t)
         dst_t.copy_(src_t)
@@ -284,7 +316,7 @@ def main():
             b_step += N * 2 * 4 * 256
             b_min += N * 2 * 4 * 256
         pair_ms = avg_ms[P._lib.K_UPDATE_MERGE]              # event pair around every launch (separate pass)
-        one_launch_per_step = world == 1 and cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0
+        one_launch_per_step = not multi and cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0
         # when the whole step is ONE launch of the dominant kernel (fused step), the events bracketing the timed
         # region give its average duration directly (launch-to-launch), free of the pair's marker packets
         ker_ms = gpu_region_ms / args.steps if one_launch_per_step else pair_ms
@@ -294,7 +326,7 @@ def main():
         # summary; rocprofv3 cannot run inside the bench) — null if this configuration was not profiled
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic_cfg%d.json" % args.config)
-        if world == 1 and os.path.exists(tf):
+        if not multi and os.path.exists(tf):
             try:
                 traffic = json.load(open(tf))["hbm_bytes_per_launch"]
             except Exception:
@@ -318,7 +350,9 @@ def main():
                        "particles_total": N * world, "gaussians_per_particle": G, "measurements_per_step": M,
                        "value_counts": "shard-steps (ranks x steps) per second",
                        "max_survivors": st["max_survivors"], "max_map": st["max_map"],
-                       "steps_per_s_unforced_resample": unforced, "multi_gpu_phase_us_rank0": breakdown},
+                       "steps_per_s_unforced_resample": unforced, "multi_gpu_phase_us_rank0": breakdown,
+                       "multi_gpu_exchange": (("gathered" if gathered else "alltoall") if multi else None),
+                       **({"one_rank_rccl_dry_run": True} if one_rank else {})},
             "stages_us_per_workgroup": stages,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -330,13 +364,13 @@ def main():
                          "other_kernels_avg_us": {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT],
                                                   "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}},
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if not multi and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.config, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     f.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

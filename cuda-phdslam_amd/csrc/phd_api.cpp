@@ -1231,6 +1231,19 @@ extern "C" int phd_finish_resample(phd_filter* f)
     return PHD_OK; // stream-ordered: no host synchronisation
 }
 
+static int ensure_send_buffer(phd_filter* f, size_t need)
+{
+    if (need > f->send_buf_bytes) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        if (f->send_buf) hipFree(f->send_buf);
+        f->send_buf = nullptr;
+        f->send_buf_bytes = 0;
+        HIPCHK(hipMalloc(&f->send_buf, need * 2));
+        f->send_buf_bytes = need * 2;
+    }
+    return PHD_OK;
+}
+
 // The exchange above in two calls (what the multi-GPU host runs per resampling step):
 //   begin: indices on the device (identical on every rank) -> download -> this rank's part of the plan
 //          (a pure function of the indices: slot j of rank q receives particle idx[q n + j], owned by rank
@@ -1288,15 +1301,8 @@ extern "C" int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_l
         for (int j = 0; j < n; ++j)                                 // what this rank needs from rank r, in slot order
             if (idx[off + j] / n == r) { f->plan_recv_slots.push_back(j); ++recv_counts[r]; }
     }
-    const size_t need = std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f);
-    if (need > f->send_buf_bytes) {
-        HIPCHK(hipStreamSynchronize(f->stream));
-        if (f->send_buf) hipFree(f->send_buf);
-        f->send_buf = nullptr;
-        f->send_buf_bytes = 0;
-        HIPCHK(hipMalloc(&f->send_buf, need * 2));
-        f->send_buf_bytes = need * 2;
-    }
+    rc = ensure_send_buffer(f, std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f));
+    if (rc) return rc;
     if (!f->plan_send.empty()) {
         rc = phd_export_particles_dev(f, f->plan_send.data(), (int)f->plan_send.size(), f->send_buf);
         if (rc) return rc;
@@ -1319,6 +1325,87 @@ extern "C" int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer)
     }
     f->plan_local_parent.clear();
     return phd_finish_resample(f);
+}
+
+// The same exchange for SMALL shards without a host round trip (the "gathered" exchange): every rank all-gathers every
+// rank's whole shard — rows of phd_particle_pack_bytes, the un-normalised log-weight in header word 7 — and then
+// normalises, draws the (identical) global indices and takes its slots' parents straight out of the gathered rows.
+// One fixed-size collective, the indices never leave the device, nothing waits for the host.  The traffic grows with
+// world * n * pack bytes per rank, so the host side picks this form only while that is small
+// (cuda-phdslam_amd/dist.py); the all-to-all form above moves only the particles that migrate.
+extern "C" int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_out)
+{
+    CHECK_F(f);
+    if (!d_rows) return fail(PHD_ERR_INVALID_ARG, "phd_export_shard_dev: null output");
+    const size_t pack = phd_particle_pack_bytes(f), need = (size_t)f->n * pack;
+    int rc = ensure_send_buffer(f, need);
+    if (rc) return rc;
+    HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur],
+                         f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], nullptr, f->send_buf, f->cap, pack,
+                         f->n, f->stream, f->logw_raw));
+    if (f->cphd)
+        HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, nullptr, f->parent[f->pcur], (float*)f->send_buf + 8 + 6 * f->cap,
+                                pack / 4, nullptr, f->cn_len, f->n, f->stream));
+    *d_rows = f->send_buf;
+    if (bytes_out) *bytes_out = need;
+    return PHD_OK;
+}
+
+// d_all_rows: world * n rows in rank order (the all-gather of every rank's phd_export_shard_dev).
+// weights_in_rows != 0: normalise the header weights and draw the indices in one launch (forced resample);
+// 0: the indices come from the vector phd_global_normalize left (the nEff-triggered resample of the SLAM loop).
+extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_rows, double uniform, int world, int rank,
+                                            int weights_in_rows, int32_t* idx_out)
+{
+    CHECK_F(f);
+    if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
+        return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_gathered: world/rank do not match the filter's shard");
+    if (!d_all_rows) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_gathered: null rows");
+    const int ng = f->n_global, n = f->n, off = rank * n;
+    const size_t pack = phd_particle_pack_bytes(f);
+    WeightArgs w;
+    memset(&w, 0, sizeof(w));
+    w.u0 = uniform;
+    if (weights_in_rows) {
+        w.logw_in = (const float*)d_all_rows + 7;
+        w.in_stride = (int)(pack / 4);
+        w.mode = WM_NORMALIZE | WM_RESAMPLE_FORCE;
+    } else {
+        w.logw_in = f->logw_scratch;
+        w.mode = WM_RESAMPLE_FORCE;
+    }
+    w.logw = f->logw_scratch;
+    w.n = ng;
+    w.n_new = ng;
+    w.uniforms = f->d_uniforms;
+    w.n_uniforms = 1;
+    w.cdf = f->cdf;
+    w.idx_out = f->idx;
+    w.neff_out = f->neff;
+    w.did_resample = f->did;
+    w.n_weight_norm = ng;
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights(w, f->stream));
+    t_end(f);
+    // copy_particles (src/slamtypes.h:313-333): slot j <- gathered row idx[off + j]; weights <- -log N and the map
+    // indirection back to identity in the same launch
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3;
+    HIPCHK(launch_import(f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], nullptr, d_all_rows, f->cap, pack, n,
+                         f->stream, f->idx + off, f->frozen ? nullptr : f->logw, (float)(-log((double)ng)),
+                         f->frozen ? nullptr : f->parent[f->pcur]));
+    if (f->cphd)
+        HIPCHK(launch_copy_rows((const float*)d_all_rows + 8 + 6 * f->cap, pack / 4, f->idx + off, nullptr, f->cn[f->cur ^ 1],
+                                f->cn_len, nullptr, f->cn_len, n, f->stream));
+    if (!f->frozen) { // bench protocol when frozen: the exchange ran, the snapshot stays
+        f->cur ^= 1;
+        f->pose_cur = (f->pose_cur + 1) % 3;
+        f->parent_dirty = false;
+    }
+    if (idx_out) {
+        HIPCHK(hipMemcpyAsync(idx_out, f->idx, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
+    return PHD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

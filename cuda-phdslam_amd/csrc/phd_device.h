@@ -32,7 +32,8 @@ enum { PHD_STATUS_MAP_OVERFLOW = 1u, PHD_STATUS_SURVIVOR_OVERFLOW = 2u };
 // Map slab layout in HBM: particle-major, then 6 SoA planes of `cap` floats:
 //   slab(p) = base + p*6*cap ; planes: 0 weight, 1 mean x, 2 mean y, 3 cov xx, 4 cov xy, 5 cov yy
 struct WeightArgs {
-    const float* logw_in;       // [n]
+    const float* logw_in;       // [n] (element i at logw_in[i * in_stride] when in_stride != 0)
+    int in_stride;              // floats between consecutive weights of logw_in (0: contiguous)
     float* logw;                // [n] working/out vector (== logw_in unless frozen)
     const float* dlogw;         // [n]
     float* raw_out;             // [n] optional: un-normalised accumulated weights
@@ -125,9 +126,11 @@ hipError_t launch_unpack_maps(const float* slabs, const int* parent, const int* 
 hipError_t launch_state(const phd_pose* poses, const float* logw, int n, float* pose_out, int* argmax_out,
                         hipStream_t st);
 hipError_t launch_export(const float* slabs, const int* counts, const int* parent, const phd_pose* poses,
-                         const int* which, void* buf, int cap, size_t stride, int n, hipStream_t st);
+                         const int* which, void* buf, int cap, size_t stride, int n, hipStream_t st,
+                         const float* raw = nullptr);
 hipError_t launch_import(float* slabs, int* counts, phd_pose* poses, const int* which, const void* buf, int cap,
-                         size_t stride, int n, hipStream_t st);
+                         size_t stride, int n, hipStream_t st, const int* rowsel = nullptr, float* logw_fill = nullptr,
+                         float nlw = 0.f, int* parent_reset = nullptr);
 hipError_t launch_gather_maps(const float* src, const int* counts_src, const int* parent, const int* sel, float* dst,
                               int* counts_dst, const phd_pose* pose_src, phd_pose* pose_dst, int cap, int n,
                               hipStream_t st);

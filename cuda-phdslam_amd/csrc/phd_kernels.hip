@@ -2251,8 +2251,9 @@ __global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
     float* logw = A.logw;       // [n] working / output vector (== logw_in unless the filter is frozen)
     // 1. accumulate the increments of the last update (src/phdfilter.cu:3741-3744)
     if ((A.mode & W_ACCUMULATE) || A.logw_in != logw) {
+        const size_t ls = A.in_stride ? (size_t)A.in_stride : 1;
         for (int i = tid; i < n; i += PHD_WT) {
-            float w = A.logw_in[i];
+            float w = A.logw_in[i * ls];
             if (A.mode & W_ACCUMULATE) w += A.dlogw[i];
             logw[i] = w;
             if (A.raw_out) A.raw_out[i] = w;
@@ -2417,7 +2418,7 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
         const int i = tid + r * BT;
         w[r] = -FLT_MAX;
         if (i < n) {
-            w[r] = A.logw_in[i];
+            w[r] = A.logw_in[A.in_stride ? (size_t)i * A.in_stride : (size_t)i];
             if (A.mode & W_ACCUMULATE) w[r] += ld_f32<HANDOFF>(&A.dlogw[i]);
             if (A.raw_out) A.raw_out[i] = w[r];
         }
@@ -2634,30 +2635,41 @@ __global__ __launch_bounds__(PHD_WT) void phd_state_kernel(const phd_pose* __res
 }
 
 // gather/scatter of whole particles for peer migration: [pose (6 f32) | count (1 i32) | pad | 6*cap f32]
+// [7] carries the particle's un-normalised log-weight when `raw` is given (whole-shard export of the gathered exchange)
 __global__ void phd_export_kernel(const float* __restrict__ slabs, const int* __restrict__ counts,
                                   const int* __restrict__ parent, const phd_pose* __restrict__ poses,
-                                  const int* __restrict__ which, unsigned char* __restrict__ buf, int cap, size_t stride)
+                                  const int* __restrict__ which, unsigned char* __restrict__ buf, int cap, size_t stride,
+                                  const float* __restrict__ raw)
 {
     const int k = blockIdx.x;
-    const int p = which[k];
+    const int p = which ? which[k] : k;
     const int src = parent ? parent[p] : p;
     float* o = (float*)(buf + (size_t)k * stride);
     const int n = counts[src];
     if (threadIdx.x < 6) o[threadIdx.x] = ((const float*)&poses[p])[threadIdx.x];
     if (threadIdx.x == 6) ((int*)o)[6] = n;
+    if (threadIdx.x == 7) o[7] = raw ? raw[p] : 0.f;
     const float* s = slabs + (size_t)src * 6 * cap;
     for (int i = threadIdx.x; i < 6 * cap; i += blockDim.x) o[8 + i] = ((i % cap) < n) ? s[i] : 0.f;
 }
 
+// which == NULL: slot k; rowsel != NULL: slot k takes row rowsel[k] of the buffer (the gathered exchange: every rank
+// holds all rows, rowsel = this shard's part of the global parent indices, on the device); logw_fill/parent_reset: the
+// tail of copy_particles (weights <- -log N, src/slamtypes.h:327; map indirection back to identity) in the same launch
 __global__ void phd_import_kernel(float* __restrict__ slabs, int* __restrict__ counts, phd_pose* __restrict__ poses,
                                   const int* __restrict__ which, const unsigned char* __restrict__ buf, int cap,
-                                  size_t stride)
+                                  size_t stride, const int* __restrict__ rowsel, float* __restrict__ logw_fill, float nlw,
+                                  int* __restrict__ parent_reset)
 {
     const int k = blockIdx.x;
-    const int p = which[k];
-    const float* o = (const float*)(buf + (size_t)k * stride);
+    const int p = which ? which[k] : k;
+    const float* o = (const float*)(buf + (size_t)(rowsel ? rowsel[k] : k) * stride);
     if (threadIdx.x < 6) ((float*)&poses[p])[threadIdx.x] = o[threadIdx.x];
     if (threadIdx.x == 6) counts[p] = ((const int*)o)[6];
+    if (threadIdx.x == 7) {
+        if (logw_fill) logw_fill[p] = nlw;
+        if (parent_reset) parent_reset[p] = p;
+    }
     float* s = slabs + (size_t)p * 6 * cap;
     for (int i = threadIdx.x; i < 6 * cap; i += blockDim.x) s[i] = o[8 + i];
 }
@@ -2814,20 +2826,21 @@ hipError_t launch_state(const phd_pose* poses, const float* logw, int n, float* 
 }
 
 hipError_t launch_export(const float* slabs, const int* counts, const int* parent, const phd_pose* poses,
-                         const int* which, void* buf, int cap, size_t stride, int n, hipStream_t st)
+                         const int* which, void* buf, int cap, size_t stride, int n, hipStream_t st, const float* raw)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(phd_export_kernel, dim3(n), dim3(256), 0, st, slabs, counts, parent, poses, which,
-                       (unsigned char*)buf, cap, stride);
+                       (unsigned char*)buf, cap, stride, raw);
     return hipGetLastError();
 }
 
 hipError_t launch_import(float* slabs, int* counts, phd_pose* poses, const int* which, const void* buf, int cap,
-                         size_t stride, int n, hipStream_t st)
+                         size_t stride, int n, hipStream_t st, const int* rowsel, float* logw_fill, float nlw,
+                         int* parent_reset)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(phd_import_kernel, dim3(n), dim3(256), 0, st, slabs, counts, poses, which,
-                       (const unsigned char*)buf, cap, stride);
+                       (const unsigned char*)buf, cap, stride, rowsel, logw_fill, nlw, parent_reset);
     return hipGetLastError();
 }
 

@@ -7,6 +7,9 @@ Per step and rank:
     identical normalise / nEff / resample-index routine on every rank (bit-identical results)
     particle migration for parents that live on another rank   (all_to_all of packed particles,
                                                                 point-to-point over xGMI)
+Small shards (all ranks' packed particles together <= ShardedFilter.gathered_limit bytes) use the "gathered" exchange
+instead: ONE fixed-size all-gather of every rank's whole shard (the raw weight rides in the row header), then each rank
+normalises, draws the indices and fills its slots from the gathered rows on the device — no host round trip at all.
 
 The exchange logic is written against a small backend interface so that the same code runs on the
 gfx950 filter (GpuShard) and — in the world_size-2 gloo tests — on a numpy stand-in.
@@ -72,10 +75,15 @@ class ShardedFilter:
         self.world = world
         self.group = group
         self.offset, self.n = shard_range(n_global, world, rank)
+        # a one-rank group needs no collective; tests set this on a one-rank RCCL group to run the collective code
+        # paths (buffers, split sizes, empty exchanges) on a single GPU
+        self.collectives = world > 1
+        # all ranks' packed particles up to this many bytes: whole-shard all-gather; above: all-to-all of the migrants
+        self.gathered_limit = 32 << 20
 
     def gather_logweights(self):
         raw = self.b.raw_logweights()                       # tensor [n] on the backend's device
-        if self.world == 1:
+        if not self.collectives:
             return raw.clone()
         if dist.get_backend(self.group) == "gloo" and raw.is_cuda:
             # test transport (several ranks sharing one GPU): stage through host memory
@@ -123,11 +131,38 @@ class ShardedFilter:
                                input_split_sizes=send_counts, group=self.group)
         return in_buf
 
+    def gathered(self):
+        """True when the resampling exchange is the whole-shard all-gather (the same answer on every rank)"""
+        return (self.collectives and hasattr(self.b, "export_shard")
+                and self.n_global * self.b.pack_bytes() <= self.gathered_limit)
+
+    def _gather_rows(self, rows):
+        """[n, pack] rows of this rank -> [n_global, pack] rows of all ranks, rank order"""
+        if dist.get_backend(self.group) == "gloo":
+            # test transport (CPU stand-in, or several ranks sharing one GPU): through host memory
+            host = torch.empty((self.n_global, rows.shape[1]), dtype=torch.uint8)
+            dist.all_gather_into_tensor(host.view(-1), rows.cpu().contiguous().view(-1), group=self.group)
+            return host.to(rows.device)
+        allrows = getattr(self, "_allrows", None)              # allocated once; stream-ordered reuse as for _allw
+        if allrows is None or allrows.shape[1] != rows.shape[1] or allrows.device != rows.device:
+            allrows = self._allrows = torch.empty((self.n_global, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+        dist.all_gather_into_tensor(allrows.view(-1), rows.reshape(-1), group=self.group)
+        return allrows
+
+    def resample_gathered(self, uniform, weights_in_rows=True, want_idx=False):
+        """whole-shard all-gather form of resample(): export -> ONE collective -> normalise + indices + import on the
+        device.  weights_in_rows: normalise the raw weights carried by the rows (forced resample straight after the
+        local step: no separate weight gather, no normalize()); False: indices from what normalize() left."""
+        rows = self.b.export_shard()
+        return self.b.resample_gathered(self._gather_rows(rows), uniform, self.world, self.rank, weights_in_rows, want_idx)
+
     def resample(self, uniform, all_raw_logw=None):
         """global systematic resample + migration.  Returns the global parent indices.
         all_raw_logw: the gathered UN-normalised weights — normalisation and indices then come from one launch
         (forced resample; skip normalize())"""
-        if self.world > 1 and hasattr(self.b, "resample_begin"):
+        if self.gathered():
+            return self.resample_gathered(uniform, all_raw_logw is not None, want_idx=True)
+        if self.collectives and hasattr(self.b, "resample_begin"):
             # library path: one call plans (in C++) and exports, one collective, one call imports and commits
             send_counts, recv_counts, send, idx = self.b.resample_begin(uniform, self.world, self.rank, all_raw_logw)
             recv = self._exchange(send[:sum(send_counts)], send_counts, recv_counts, self.b.pack_bytes())
@@ -135,7 +170,7 @@ class ShardedFilter:
             return idx
         idx = self.b.global_resample_indices(uniform)       # numpy [n_global], identical on all ranks
         local_parent, send, recv_slots = plan_migration(idx, self.n_global, self.world, self.rank)
-        if self.world > 1:
+        if self.collectives:
             send_counts = [len(s) for s in send]
             recv_counts = [len(s) for s in recv_slots]
             order = np.concatenate(send) if sum(send_counts) else np.zeros(0, np.int32)
@@ -156,7 +191,7 @@ def _expected_map(self, min_distance):
     (ragged: padded to the longest) in rank order = global particle order, and each rank reduces
     the same global mixture — identical results everywhere, no rank is special."""
     planes = self.b.expected_map_concat()                   # tensor [6, total_r]
-    if self.world > 1:
+    if self.collectives:
         gloo = dist.get_backend(self.group) == "gloo"
         dev = planes.device
         t = torch.tensor([planes.shape[1]], dtype=torch.int64, device="cpu" if gloo else dev)
@@ -286,6 +321,26 @@ class GpuShard:
             rows = max(n_send, self.f.n)
             cached = self._send = (buf.value, rows, self._wrap(buf.value, rows * pack // 4).view(torch.uint8).view(rows, pack))
         return sc, rc, cached[2], idx
+
+    def export_shard(self):
+        C = self._C
+        p, nb = C.c_void_p(), C.c_size_t()
+        self._check(self._lib().phd_export_shard_dev(self.f._h, C.byref(p), C.byref(nb)), "phd_export_shard_dev")
+        cached = getattr(self, "_rows", None)
+        if cached is None or cached[0] != p.value or cached[1] != nb.value:
+            pack = self.pack_bytes()
+            cached = self._rows = (p.value, nb.value, self._wrap(p.value, nb.value // 4).view(torch.uint8).view(nb.value // pack, pack))
+        self._filter_to_torch()
+        return cached[2]
+
+    def resample_gathered(self, allrows, uniform, world, rank, weights_in_rows, want_idx):
+        idx = np.zeros(self.n_global, np.int32) if want_idx else None
+        self._torch_to_filter()
+        self._check(self._lib().phd_global_resample_gathered(self.f._h, self._ptr(allrows.data_ptr()), float(uniform), int(world),
+                                                             int(rank), int(bool(weights_in_rows)),
+                                                             self._ptr(idx) if want_idx else None),
+                    "phd_global_resample_gathered")
+        return idx
 
     def resample_end(self, recv):
         self._torch_to_filter()

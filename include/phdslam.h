@@ -297,6 +297,16 @@ int phd_finish_resample(phd_filter* f); /* weights <- -log(global_particles) */
 int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_logw, double uniform, int world, int rank,
                               int32_t* send_counts, int32_t* recv_counts, void** d_send_buffer, int32_t* idx_out);
 int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer);
+/* The same exchange for small shards with no host round trip ("gathered" exchange): phd_export_shard_dev packs the
+ * whole shard (n rows of phd_particle_pack_bytes; header word 7 = the particle's un-normalised log-weight) into the
+ * library's send buffer; the caller all-gathers the shards in rank order (one fixed-size RCCL all-gather);
+ * phd_global_resample_gathered normalises (weights_in_rows != 0: from the rows; 0: the vector phd_global_normalize
+ * left), draws the identical global indices on every rank and fills this shard's slots straight from the gathered
+ * rows.  Everything is stream-ordered; idx_out (optional, host) forces a synchronisation.  Traffic is
+ * world * n * pack bytes per rank: for small shards only — phd_global_resample_begin/_end move just the migrants. */
+int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_out);
+int phd_global_resample_gathered(phd_filter* f, const void* d_all_rows, double uniform, int world, int rank,
+                                 int weights_in_rows, int32_t* idx_out);
 
 /* ------------------------------------------------------------------------------------
  * Bench / steady-state protocol and instrumentation

@@ -72,6 +72,23 @@ class NumpyShard:
         self.maps, self.poses = self._next
         self.logw = np.full(len(self.poses), -np.log(self.n_global), np.float32)
 
+    # the whole-shard ("gathered") exchange: rows of every local particle, the raw weight in the header
+    def export_shard(self):
+        rows = self.export_particles(range(len(self.poses))).numpy().copy()
+        rows.view(np.float32)[:, 9] = self.raw                 # last payload word is free (maps hold < 8 values)
+        return torch.from_numpy(rows)
+
+    def resample_gathered(self, allrows, uniform, world, rank, weights_in_rows, want_idx):
+        b = allrows.numpy()
+        n = len(self.poses)
+        if weights_in_rows:
+            self._all = O.normalize_weights(b.view(np.float32)[:, 9].copy())
+        idx = O.resample(self._all, uniform)
+        self._next = ([None] * n, np.zeros(n, np.float32))
+        self.import_particles(range(n), torch.from_numpy(b[idx[rank * n:(rank + 1) * n]]))
+        self.finish_resample()
+        return idx if want_idx else None
+
 
 def _global_set(n_global, seed):
     rng = np.random.default_rng(seed)
@@ -81,7 +98,7 @@ def _global_set(n_global, seed):
     return ids, maps, raw
 
 
-def _worker(rank, world, port, n_global, seed, uniform, out_dir):
+def _worker(rank, world, port, n_global, seed, uniform, out_dir, exchange):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -89,10 +106,16 @@ def _worker(rank, world, port, n_global, seed, uniform, out_dir):
     off, n = D.shard_range(n_global, world, rank)
     shard = NumpyShard(ids[off:off + n], maps[off:off + n], raw[off:off + n], n_global)
     sf = D.ShardedFilter(shard, n_global, rank, world)
+    if exchange == "alltoall":
+        sf.gathered_limit = 0
+    assert sf.gathered() == (exchange != "alltoall")
     allw = sf.gather_logweights()
     assert np.array_equal(allw.numpy(), raw)                       # all-gather reassembles the global vector
     neff = sf.normalize(allw)
-    idx = sf.resample(uniform)
+    if exchange == "gathered_rows":
+        idx = sf.resample_gathered(uniform, weights_in_rows=True, want_idx=True)   # the bench's forced-resample step
+    else:
+        idx = sf.resample(uniform)                                 # "gathered": indices from what normalize() left
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ids=shard.poses, idx=idx, neff=neff, logw=shard.logw,
              sizes=np.array([len(m) for m in shard.maps]), flat=np.concatenate(shard.maps + [np.zeros(0, np.float32)]))
     dist.barrier()
@@ -107,10 +130,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_global,seed", [(2, 64, 1), (2, 256, 2), (4, 128, 3)])
-def test_global_resample_and_migration(tmp_path, world, n_global, seed):
+@pytest.mark.parametrize("world,n_global,seed,exchange", [(2, 64, 1, "alltoall"), (2, 256, 2, "alltoall"), (4, 128, 3, "alltoall"),
+                                                          (2, 64, 1, "gathered"), (4, 128, 3, "gathered_rows")])
+def test_global_resample_and_migration(tmp_path, world, n_global, seed, exchange):
     uniform = 0.37
-    mp.spawn(_worker, args=(world, _free_port(), n_global, seed, uniform, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_global, seed, uniform, str(tmp_path), exchange), nprocs=world, join=True)
     ids, maps, raw = _global_set(n_global, seed)
     ref_lw = O.normalize_weights(raw)
     ref_idx = O.resample(ref_lw, uniform)

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, N, G, M, seed, u, fast):
+def _worker(rank, world, port, out_dir, N, G, M, seed, u, fast, exchange):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,12 +35,18 @@ def _worker(rank, world, port, out_dir, N, G, M, seed, u, fast):
     torch.cuda.synchronize()
     shard = D.GpuShard(f, N)
     sf = D.ShardedFilter(shard, N, rank, world)
+    if exchange == "alltoall":
+        sf.gathered_limit = 0                                 # large-shard form: all-to-all of the migrating particles
+    assert sf.gathered() == (exchange == "gathered")
     if fast:
         # the bench's step: one launch for predict + update + raw weights, normalise + indices in one launch
         shard.step_local_dev((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
-        allw = sf.gather_logweights()
         neff, lw_norm, eap = 0.0, np.zeros(n, np.float32), np.zeros(0, P.GAUSSIAN)
-        idx = sf.resample(u, all_raw_logw=allw)
+        if exchange == "gathered":
+            idx = sf.resample_gathered(u, weights_in_rows=True, want_idx=True)   # the weights ride in the rows
+        else:
+            allw = sf.gather_logweights()
+            idx = sf.resample(u, all_raw_logw=allw)
     else:
         f.predict_dev((2.0, 0.05), d_noise.data_ptr())
         shard.update_local_dev(d_z.data_ptr(), M)
@@ -59,14 +65,15 @@ def _worker(rank, world, port, out_dir, N, G, M, seed, u, fast):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["gathered", "alltoall"])
 @pytest.mark.parametrize("fast", [False, True])
-def test_two_ranks_equal_one_filter(tmp_path, fast):
+def test_two_ranks_equal_one_filter(tmp_path, fast, exchange):
     import torch.multiprocessing as mp
     P = importlib.import_module("cuda-phdslam_amd")
     S = importlib.import_module("cuda-phdslam_amd.synthetic")
     N, G, M, seed, u, world = 64, 24, 10, 77, 0.61, 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), N, G, M, seed, u, fast), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), N, G, M, seed, u, fast, exchange), nprocs=world, join=True)
     # the same filter on one rank
     w = S.make_workload(N, G, M, seed=seed)
     with P.PhdFilter(P.default_config(n_particles=N), n_particles=N, map_capacity=4 * G, max_measurements=M) as f:
