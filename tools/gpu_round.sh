@@ -13,6 +13,11 @@ python bench.py --config 3 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out
 cat gpurun_out/bench_cfg3_$tag.json
 python bench.py --config 5 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out/bench_cfg5_$tag.json 2> gpurun_out/bench_cfg5_$tag.err
 cat gpurun_out/bench_cfg5_$tag.json
+# the N > 1 step on a one-rank RCCL group (what the multi-rank path costs before any link): both exchange forms
+for ex in gathered alltoall; do
+  PHD_BENCH_EXCHANGE=$ex PHD_BENCH_ONE_RANK_RCCL=1 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 2> /dev/null | grep metric > gpurun_out/bench_cfg2_onerank_${ex}_$tag.json
+  cat gpurun_out/bench_cfg2_onerank_${ex}_$tag.json | cut -c1-160
+done
 python tools/phase_profile.py 2 3 > gpurun_out/phase_$tag.log 2>&1
 (python tools/e2e_run.py 256; python tools/e2e_run.py 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/e2e_$tag.log
 cat gpurun_out/e2e_$tag.log
@@ -26,3 +31,5 @@ done
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_traffic.sh 2 $tag
 bash tools/pmc_traffic.sh 3 $tag
+bash tools/pmc_sq.sh 3 $tag > gpurun_out/sq_counters_$tag.txt 2>&1
+bash tools/pmc_sq.sh 2 $tag >> gpurun_out/sq_counters_$tag.txt 2>&1
