@@ -165,13 +165,15 @@ def main():
         gathered = sf.gathered()                    # small shards (this config up to 8 ranks): whole-shard all-gather
 
         def step():
-            # one launch for predict + update + prune + merge + raw weights, then
-            shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
             if gathered:
-                # export -> ONE fixed-size RCCL all-gather of the shards (raw weights in the row headers) -> global
-                # normalise + resample indices + import of this shard's parents: nothing waits for the host
-                sf.resample_gathered(u, weights_in_rows=True, want_idx=False)
+                # one launch for predict + update + prune + merge, written straight into the export rows (raw weights
+                # in the row headers) -> ONE fixed-size RCCL all-gather of the shards -> global normalise + resample
+                # indices + import of this shard's parents: nothing waits for the host
+                rows = shard.step_local_rows(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+                sf.resample_gathered(u, weights_in_rows=True, want_idx=False, rows=rows)
             else:
+                # one launch for predict + update + prune + merge + raw weights, then
+                shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
                 # RCCL all-gather of the raw weights, one launch for the global normalise + resample indices (indices
                 # to the host for the plan), RCCL all-to-all of the migrating particles, commit
                 allw = sf.gather_logweights()
@@ -235,22 +237,22 @@ def main():
             return time.perf_counter()
 
         if gathered:
-            acc = {"local_step": 0.0, "export_shard": 0.0, "all_gather_rows": 0.0, "normalise+indices+import": 0.0}
+            acc = {"local_step_into_rows": 0.0, "all_gather_rows": 0.0, "normalise+indices+import": 0.0}
         else:
             acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
         for _ in range(k_bd):
             t_a = tick()
-            shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
-            t_b = tick()
             if gathered:
-                rows = shard.export_shard()
-                t_c = tick()
+                rows = shard.step_local_rows(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+                t_b = tick()
                 allrows = sf._gather_rows(rows)
-                t_d = tick()
+                t_c = tick()
                 shard.resample_gathered(allrows, u, world, rank, True, False)
-                t_e = tick()
-                ts_ = (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)
+                t_d = tick()
+                ts_ = (t_b - t_a, t_c - t_b, t_d - t_c)
             else:
+                shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+                t_b = tick()
                 allw = sf.gather_logweights()
                 t_c = tick()
                 sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)

@@ -125,6 +125,8 @@ struct phd_filter {
     std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots;
     void* send_buf = nullptr;
     size_t send_buf_bytes = 0;
+    bool rows_out = false;     // this launch writes its outputs into the export rows (phd_step_local_rows_dev)
+    bool rows_pending = false; // ... and the step still has to be completed by phd_global_resample_gathered
     bool want_raw = false; // the update kernel also writes raw = logw + dlogw (multi-GPU step: no weights launch before the all-gather)
     GmWorkspace* gm = nullptr; // expected-map / gm_reduce workspace, created on first use
     int gm_rounds = 0;
@@ -315,10 +317,17 @@ extern "C" int phd_destroy(phd_filter* f)
     return PHD_OK;
 }
 
-#define CHECK_F(f)                                                       \
+#define CHECK_F0(f)                                                      \
     do {                                                                 \
         if (!(f)) return fail(PHD_ERR_INVALID_ARG, "null filter handle"); \
         HIPCHK(hipSetDevice((f)->device));                               \
+    } while (0)
+// every entry point but the ones that complete or only observe a phd_step_local_rows_dev step
+#define CHECK_F(f)                                                       \
+    do {                                                                 \
+        CHECK_F0(f);                                                     \
+        if ((f)->rows_pending)                                           \
+            return fail(PHD_ERR_INVALID_ARG, "phd_step_local_rows_dev is pending: complete the step with phd_global_resample_gathered"); \
     } while (0)
 
 extern "C" int phd_set_config(phd_filter* f, const phd_slam_config* cfg)
@@ -346,7 +355,7 @@ extern "C" void* phd_stream(phd_filter* f) { return f ? (void*)f->stream : nullp
 
 extern "C" int phd_sync(phd_filter* f)
 {
-    CHECK_F(f);
+    CHECK_F0(f);
     HIPCHK(hipStreamSynchronize(f->stream));
     return PHD_OK;
 }
@@ -383,21 +392,21 @@ static void t_collect(phd_filter* f)
 
 extern "C" int phd_timing_enable(phd_filter* f, int enable)
 {
-    CHECK_F(f);
+    CHECK_F0(f);
     if (!enable) t_collect(f);
     f->timing = enable != 0;
     return PHD_OK;
 }
 extern "C" int phd_timing_reset(phd_filter* f)
 {
-    CHECK_F(f);
+    CHECK_F0(f);
     t_collect(f);
     for (int k = 0; k < PHD_K_COUNT; ++k) { f->t_ms[k] = 0; f->t_n[k] = 0; }
     return PHD_OK;
 }
 extern "C" int phd_timing_read(phd_filter* f, double* ms_total, int64_t* launches)
 {
-    CHECK_F(f);
+    CHECK_F0(f);
     t_collect(f);
     for (int k = 0; k < PHD_K_COUNT; ++k) {
         if (ms_total) ms_total[k] = f->t_ms[k];
@@ -656,6 +665,10 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     a.count_in = f->counts[f->cur];
     a.map_out = f->maps[f->cur ^ 1];
     a.count_out = f->counts[f->cur ^ 1];
+    if (f->rows_out) { // the outputs land in the export rows (phd_step_local_rows_dev)
+        a.map_out = (float*)f->send_buf + 8;
+        a.out_stride = (unsigned)(phd_particle_pack_bytes(f) / 4);
+    }
     a.parent = f->parent[f->pcur];
     a.parent_reset = f->frozen ? nullptr : f->parent[f->pcur];
     a.pose = f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur];
@@ -697,6 +710,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         a.cphd = 1;
         a.cn_in = f->cn[f->cur];
         a.cn_out = f->cn[f->cur ^ 1];
+        if (f->rows_out) a.cn_out = (float*)f->send_buf + 8 + 6 * f->cap;
         a.cn_len = f->cn_len;
         a.lfact = f->d_lfact;
         a.lfact_len = f->lfact_len;
@@ -1351,13 +1365,44 @@ extern "C" int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_
     return PHD_OK;
 }
 
+// phd_step_local_dev + phd_export_shard_dev in ONE launch: the update kernel writes each particle's merged map, predicted
+// pose, count, raw log-weight (and CPHD cardinality row) straight into its export row.  The updated maps then exist
+// ONLY in the rows: the step must be completed by phd_global_resample_gathered (which rebuilds every slot from the
+// gathered rows); until then every other call on a live (not frozen) filter is refused.
+extern "C" int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
+                                       const phd_measurement* d_z, int n_meas, void** d_rows, size_t* bytes_out)
+{
+    CHECK_F(f);
+    if (!d_rows) return fail(PHD_ERR_INVALID_ARG, "phd_step_local_rows_dev: null output");
+    const int M = std::min(n_meas, f->MM);
+    if (M <= 0 || f->n != f->n_base) { // no measurements / particle shotgun: the staged form
+        int rc = phd_step_local_dev(f, u, d_noise, d_z, n_meas);
+        if (rc) return rc;
+        return phd_export_shard_dev(f, d_rows, bytes_out);
+    }
+    const size_t need = (size_t)f->n * phd_particle_pack_bytes(f);
+    int rc = ensure_send_buffer(f, need);
+    if (rc) return rc;
+    FusedPredict fp = {u, d_noise};
+    f->want_raw = true;
+    f->rows_out = true;
+    rc = do_update_merge(f, d_z, M, &fp);
+    f->want_raw = false;
+    f->rows_out = false;
+    if (rc) return rc;
+    f->rows_pending = !f->frozen;
+    *d_rows = f->send_buf;
+    if (bytes_out) *bytes_out = need;
+    return PHD_OK;
+}
+
 // d_all_rows: world * n rows in rank order (the all-gather of every rank's phd_export_shard_dev).
 // weights_in_rows != 0: normalise the header weights and draw the indices in one launch (forced resample);
 // 0: the indices come from the vector phd_global_normalize left (the nEff-triggered resample of the SLAM loop).
 extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_rows, double uniform, int world, int rank,
                                             int weights_in_rows, int32_t* idx_out)
 {
-    CHECK_F(f);
+    CHECK_F0(f);
     if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
         return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_gathered: world/rank do not match the filter's shard");
     if (!d_all_rows) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_gathered: null rows");
@@ -1396,6 +1441,7 @@ extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_row
     if (f->cphd)
         HIPCHK(launch_copy_rows((const float*)d_all_rows + 8 + 6 * f->cap, pack / 4, f->idx + off, nullptr, f->cn[f->cur ^ 1],
                                 f->cn_len, nullptr, f->cn_len, n, f->stream));
+    f->rows_pending = false;
     if (!f->frozen) { // bench protocol when frozen: the exchange ran, the snapshot stays
         f->cur ^= 1;
         f->pose_cur = (f->pose_cur + 1) % 3;
@@ -1477,7 +1523,7 @@ extern "C" int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out)
 
 extern "C" int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out)
 {
-    CHECK_F(f);
+    CHECK_F0(f);
     uint32_t st = 0;
     int ms = 0, mm = 0;
     HIPCHK(hipMemcpyAsync(&st, f->status, 4, hipMemcpyDeviceToHost, f->stream));

@@ -62,6 +62,10 @@ struct UpdateArgs {
     const int* count_in;
     float* map_out;
     int* count_out;
+    // rows mode (multi-GPU whole-shard exchange), out_stride != 0: the outputs of particle p land directly in its export
+    // row of out_stride floats — slab at map_out + p * out_stride, header [pose | count | raw log-weight] in the 8 floats
+    // before it, CPHD cardinality row at cn_out + p * out_stride.  0: slabs of 6 * cap floats, cn rows of cn_len.
+    unsigned out_stride;
     const int* parent;          // map indirection left by the last resample
     int* parent_reset;          // == parent unless frozen (NULL): parent[p] <- p once slab p is rewritten
     const phd_pose* pose;       // [n_particles]

@@ -1774,7 +1774,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const int cap = A.cap, S_cap = A.S_cap, M = A.M;
     const int src = A.parent[p];
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
-    float* __restrict__ out = A.map_out + (size_t)p * 6 * cap;
+    const unsigned rows_stride = FUSEW ? 0u : A.out_stride; // rows mode belongs to the multi-GPU step (never the fused tail)
+    float* __restrict__ out = A.map_out + (size_t)p * (rows_stride ? rows_stride : (size_t)6 * cap);
     const int n_map = A.count_in[src];
     phd_pose pose = A.pose[p];
     if (A.do_predict) {
@@ -1951,7 +1952,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
         cphd_block(L, Q, cfg, M, A.MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
-                   A.cn_out + (size_t)p * A.cn_len, A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid);
+                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid);
         const float r1 = Q.scal[CQ_R1];
         // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
         for (int m0 = 0; m0 < M; m0 += PHD_T) {
@@ -2111,6 +2112,15 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             else A.parent_reset[p] = p;
         }
         A.count_out[p] = k_out + n_app;
+        if (rows_stride) { // the export row's header (phd_export_kernel's layout)
+            // pose and raw weight: re-read what this thread stored earlier rather than keep them live through the merge
+            float* h = out - 8;
+            const float* ps = (const float*)(A.do_predict ? &A.pose_out[p] : &A.pose[p]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) h[k] = ps[k];
+            ((int*)h)[6] = k_out + n_app;
+            h[7] = A.raw_out[p];
+        }
         if (status) atomicOr(A.status, status);
         atomicMax(A.max_surv, L.ctr[CTR_NSURV]);
         atomicMax(A.max_map, k_out + n_out0);

@@ -149,11 +149,13 @@ class ShardedFilter:
         dist.all_gather_into_tensor(allrows.view(-1), rows.reshape(-1), group=self.group)
         return allrows
 
-    def resample_gathered(self, uniform, weights_in_rows=True, want_idx=False):
+    def resample_gathered(self, uniform, weights_in_rows=True, want_idx=False, rows=None):
         """whole-shard all-gather form of resample(): export -> ONE collective -> normalise + indices + import on the
         device.  weights_in_rows: normalise the raw weights carried by the rows (forced resample straight after the
-        local step: no separate weight gather, no normalize()); False: indices from what normalize() left."""
-        rows = self.b.export_shard()
+        local step: no separate weight gather, no normalize()); False: indices from what normalize() left.
+        rows: what the backend's step_local_rows() returned (the local step already wrote the export rows)."""
+        if rows is None:
+            rows = self.b.export_shard()
         return self.b.resample_gathered(self._gather_rows(rows), uniform, self.world, self.rank, weights_in_rows, want_idx)
 
     def resample(self, uniform, all_raw_logw=None):
@@ -322,14 +324,26 @@ class GpuShard:
             cached = self._send = (buf.value, rows, self._wrap(buf.value, rows * pack // 4).view(torch.uint8).view(rows, pack))
         return sc, rc, cached[2], idx
 
+    def step_local_rows(self, control, d_noise, d_z, n_meas):
+        """local step whose outputs land directly in the export rows (one launch); complete it with resample_gathered"""
+        from .filter import _ctrl
+        C = self._C
+        p, nb = C.c_void_p(), C.c_size_t()
+        self._check(self._lib().phd_step_local_rows_dev(self.f._h, _ctrl(control), self._ptr(d_noise), self._ptr(d_z), int(n_meas),
+                                                        C.byref(p), C.byref(nb)), "phd_step_local_rows_dev")
+        return self._rows_tensor(p.value, nb.value)
+
     def export_shard(self):
         C = self._C
         p, nb = C.c_void_p(), C.c_size_t()
         self._check(self._lib().phd_export_shard_dev(self.f._h, C.byref(p), C.byref(nb)), "phd_export_shard_dev")
-        cached = getattr(self, "_rows", None)
-        if cached is None or cached[0] != p.value or cached[1] != nb.value:
+        return self._rows_tensor(p.value, nb.value)
+
+    def _rows_tensor(self, address, n_bytes):
+        cached = getattr(self, "_rows", None)                # the library's row buffer only moves when it grows
+        if cached is None or cached[0] != address or cached[1] != n_bytes:
             pack = self.pack_bytes()
-            cached = self._rows = (p.value, nb.value, self._wrap(p.value, nb.value // 4).view(torch.uint8).view(nb.value // pack, pack))
+            cached = self._rows = (address, n_bytes, self._wrap(address, n_bytes // 4).view(torch.uint8).view(n_bytes // pack, pack))
         self._filter_to_torch()
         return cached[2]
 

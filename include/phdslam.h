@@ -305,6 +305,12 @@ int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer);
  * rows.  Everything is stream-ordered; idx_out (optional, host) forces a synchronisation.  Traffic is
  * world * n * pack bytes per rank: for small shards only — phd_global_resample_begin/_end move just the migrants. */
 int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_out);
+/* phd_step_local_dev + phd_export_shard_dev in ONE launch: the update kernel writes every particle's merged map, predicted
+ * pose, count and raw log-weight straight into its export row.  The updated maps then exist only in the rows, so the step
+ * MUST be completed by phd_global_resample_gathered; until then a live (not frozen) filter refuses every other call
+ * except phd_sync / phd_device_status / phd_timing_* / phd_destroy. */
+int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
+                            const phd_measurement* d_z, int n_meas, void** d_rows, size_t* bytes_out);
 int phd_global_resample_gathered(phd_filter* f, const void* d_all_rows, double uniform, int world, int rank,
                                  int weights_in_rows, int32_t* idx_out);
 

@@ -40,11 +40,15 @@ def _worker(rank, world, port, out_dir, N, G, M, seed, u, fast, exchange):
     assert sf.gathered() == (exchange == "gathered")
     if fast:
         # the bench's step: one launch for predict + update + raw weights, normalise + indices in one launch
-        shard.step_local_dev((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
         neff, lw_norm, eap = 0.0, np.zeros(n, np.float32), np.zeros(0, P.GAUSSIAN)
         if exchange == "gathered":
-            idx = sf.resample_gathered(u, weights_in_rows=True, want_idx=True)   # the weights ride in the rows
+            # the local step writes the export rows itself (maps, poses, counts, raw weights): one launch, one collective
+            rows = shard.step_local_rows((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
+            with pytest.raises(P.PhdError):
+                f.get_maps()                                   # the updated maps exist only in the rows until the step completes
+            idx = sf.resample_gathered(u, weights_in_rows=True, want_idx=True, rows=rows)
         else:
+            shard.step_local_dev((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
             allw = sf.gather_logweights()
             idx = sf.resample(u, all_raw_logw=allw)
     else:

@@ -44,12 +44,18 @@ def _worker(rank, port, out_dir):
         if mode == "rccl":
             sf.gathered_limit = 0                            # all-to-all form
         for k in range(3):                                   # several steps: the cached buffers are reused
-            shard.step_local_dev((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
             if mode == "rccl_gathered":
-                # export -> all_gather_into_tensor of the whole shard -> normalise + indices + import, no host sync
+                # local step into the export rows (k odd: step, then a separate export) -> all_gather_into_tensor of the
+                # whole shard -> normalise + indices + import, no host sync
                 assert sf.gathered()
-                idx = sf.resample_gathered(u, weights_in_rows=True, want_idx=(k == 2))
+                rows = None
+                if k % 2 == 0:
+                    rows = shard.step_local_rows((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
+                else:
+                    shard.step_local_dev((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
+                idx = sf.resample_gathered(u, weights_in_rows=True, want_idx=(k == 2), rows=rows)
                 continue
+            shard.step_local_dev((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
             allw = sf.gather_logweights()
             if mode == "rccl":
                 assert allw.is_cuda and allw.data_ptr() == sf._allw.data_ptr()
