@@ -449,7 +449,7 @@ size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).tot
 int update_fuse_max_particles() { return PHD_T * 2; } // weights_body<PHD_T, 2> of the fused step
 
 enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */,
-       CTR_NNEAR = 30 };
+       CTR_NPAIR = 24 /* merge_small: candidate pairs listed for the exact closeness test */, CTR_NNEAR = 30 };
 
 // append one survivor; slot allocation is wave-aggregated (one LDS atomic per wave per call site)
 __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
@@ -826,10 +826,10 @@ __device__ __forceinline__ bool is_close(float smx, float smy, float sxx, float 
 // No second sort, no segment pass, no list compaction: 6 barriers instead of ~25.
 // ------------------------------------------------------------------------------------------
 template <bool HELLINGER, bool STAMPS>
-__device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig& cfg, float* __restrict__ out_slab, int cap,
-                                            int tid, u64* st, int n_update)
+__device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, const DevConfig& cfg, float* __restrict__ out_slab,
+                                            int cap, int tid, u64* st, int n_update)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const float T = cfg.minSeparation;
     const float Tpre = (T > 0.f) ? T * 1.01f : -1.f;
     // ---- rank by counting; P2 slots, PHD_T / P2 helper threads per survivor share the scan of the keys
@@ -837,6 +837,10 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
     while (P2 < S) P2 <<= 1;
     const int nh = PHD_T / P2;
     const int i = tid & (P2 - 1), h = tid / P2;
+    // the survivor planes are dead once the sorted staging has read them: the last three (yy, tr, u: >= 3 KB) hold the
+    // filter's packed copy of the sorted means and radii
+    lds_f32 fX2 = L.yy;                        // [128] (mx_l, mx_l+1, my_l, my_l+1)
+    lds_f32 fZ2 = L.yy + 2 * PHD_SMALL_S;      // [256] 0.505 T tr_l
     LDS_T(u64)* skey = L.srow;                 // [256] 64-bit keys (the row area is free until the ranks are known)
     lds_u32 scnt = (lds_u32)(L.srow + PHD_SMALL_S);
     u32 mh = 0, ml = 0;
@@ -869,10 +873,16 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
         // column in the filter, two per operand in the exact test and the moment matching
         L.sA[rank] = (v4f){rmx, rmy, 0.5f * Tpre * tr, rw};
         L.sB[rank] = (v4f){rxx, rxy, ryy, 0.f};
+        // the filter's copy, two columns per entry so that its arithmetic is packed (v_pk_*): (mx, mx', my, my'), (z, z')
+        fX2[(rank >> 1) * 4 + (rank & 1)] = rmx;
+        fX2[(rank >> 1) * 4 + 2 + (rank & 1)] = rmy;
+        fZ2[rank] = 0.5f * Tpre * tr;
     }
     __syncthreads();
     STAMP(6);
     u64 tq0 = 0, tq1 = 0, tq2 = 0;
+    lds_u32 plist = (lds_u32)L.w;                // candidate pairs (k << 16 | l): the first five survivor planes
+    const int pcap = 5 * S_cap;
     // ---- closeness rows: work units (block of 64 positions kb, 16 columns of a column block lc <= kb), dealt
     //      round-robin to the waves; a unit fills one 16-bit quarter of the row word srow[k][lc]
     {
@@ -893,32 +903,87 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S, const DevConfig
             if (lbase >= S) { srow16[(k * 4 + lc) * 4 + q] = 0; continue; }   // uniform: no such columns
             const bool kvalid = k < S;
             const int kk = kvalid ? k : S - 1;
-            const v4f ka = L.sA[kk], kbv = L.sB[kk];
-            const float kmx = ka.x, kmy = ka.y, kat = ka.z, kxx = kbv.x, kxy = kbv.y, kyy = kbv.z;
+            const v4f ka = L.sA[kk];
+            const float kmx = ka.x, kmy = ka.y, kat = ka.z;
             // cheap conservative filter over the unit's 16 columns, branch-free: d^2 < 0.505 T (tr_l + tr_k)
             // (d >= 2|dm|^2/(tr Pa + tr Pb) for SPD covariances, 1 % guard band; +inf trace = "always a candidate").
             // The column data are LDS broadcast reads (same address in every lane), all 16 in flight.
             // Columns >= S hold stale data of earlier steps: the test l < k (< S) masks them.
             u32 cand = 0;
+            const LDS_T(v4f)* cX = (const LDS_T(v4f)*)fX2 + (lbase >> 1);
+            const LDS_T(v2f)* cZ = (const LDS_T(v2f)*)fZ2 + (lbase >> 1);
+            const v2f kx2 = (v2f){kmx, kmx}, ky2 = (v2f){kmy, kmy}, kz2 = (v2f){kat, kat};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int l = lbase + j;
-                const v4f ca = L.sA[l];
-                const float dx = ca.x - kmx, dy = ca.y - kmy;
-                const bool near = HELLINGER || !(dx * dx + dy * dy >= ca.z + kat);
-                cand |= (near && l < k) ? (1u << j) : 0u;
+            for (int jp = 0; jp < 8; ++jp) {
+                const v4f a = cX[jp];
+                const v2f z = cZ[jp];
+                const v2f dx = (v2f){a.x, a.y} - kx2, dy = (v2f){a.z, a.w} - ky2;
+                const v2f d2 = dx * dx + dy * dy, thr = z + kz2;
+                const bool near0 = HELLINGER || !(d2.x >= thr.x), near1 = HELLINGER || !(d2.y >= thr.y);
+                cand |= (near0 ? (1u << (2 * jp)) : 0u) | (near1 ? (2u << (2 * jp)) : 0u);
             }
-            if (!kvalid) cand = 0;
-            // ... then the exact decision on the marked columns only (a handful per position)
-            u32 bits = 0;
-            while (cand) {
-                const int j = __builtin_ctz(cand);
-                cand &= cand - 1;
-                const int l = lbase + j;
-                const v4f la = L.sA[l], lb = L.sB[l];
-                if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, kmx, kmy, kxx, kxy, kyy, T)) bits |= 1u << j;
+            // only earlier positions count (l < k), and only rows of real positions
+            const int nlt = k - lbase;
+            cand &= (!kvalid || nlt <= 0) ? 0u : (nlt >= 16 ? 0xFFFFu : ((1u << nlt) - 1u));
+            // The marked pairs are few (a hundred or two per particle) and unevenly spread over the positions, so the
+            // exact decision does not run here, one divergent loop per lane: the row keeps the candidate bits and the
+            // pairs go to a list (wave-aggregated slot allocation) that the whole workgroup tests one pair per
+            // thread below.  The list lives in the survivor planes, dead since the sorted staging.
+            srow16[(k * 4 + lc) * 4 + q] = (u16)cand;
+            const int np = __popc(cand);
+            const int incl = (int)wave_incl_scan((u32)np);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (tot) {
+                int base = 0;
+                if (lane == 63) base = atomicAdd((int*)&L.ctr[CTR_NPAIR], tot);
+                int pos = __builtin_amdgcn_readlane(base, 63) + incl - np;
+                while (cand) {
+                    const int j = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    if (pos < pcap) plist[pos] = ((u32)k << 16) | (u32)(lbase + j);
+                    ++pos;
+                }
             }
-            srow16[(k * 4 + lc) * 4 + q] = (u16)bits;
+        }
+    }
+    __syncthreads();
+    {
+        const int n_pairs = L.ctr[CTR_NPAIR];
+        if (n_pairs <= pcap) {
+            // exact decision, one listed pair per thread: a candidate that fails loses its bit
+            for (int t = tid; t < n_pairs; t += PHD_T) {
+                const u32 pr = plist[t];
+                const int k = (int)(pr >> 16), l = (int)(pr & 0xFFFFu);
+                const v4f ka = L.sA[k], kbv = L.sB[k], la = L.sA[l], lb = L.sB[l];
+                if (!is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, ka.x, ka.y, kbv.x, kbv.y, kbv.z, T))
+                    atomicAnd((u64*)&L.srow[k * 4 + (l >> 6)], ~(1ull << (l & 63)));
+            }
+        } else {
+            // more candidates than the list holds (dense clutter of overlapping Gaussians, or the Hellinger metric, which
+            // has no cheap filter): the exact decision per position on its marked columns
+            LDS_T(u16)* srow16 = (LDS_T(u16)*)L.srow;
+            const int nblk = (S + 63) >> 6;
+            const int n_units = 4 * (nblk * (nblk + 1) / 2);
+            for (int unit = wave; unit < n_units; unit += PHD_NW) {
+                const int q = unit & 3;
+                int kb = 0, lc = unit >> 2;
+                while (lc > kb) { lc -= kb + 1; ++kb; }
+                const int lbase = 64 * lc + 16 * q;
+                const int k = 64 * kb + lane;
+                if (lbase >= S) continue;
+                const int kk = k < S ? k : S - 1;
+                const v4f ka = L.sA[kk], kbv = L.sB[kk];
+                u32 cand = srow16[(k * 4 + lc) * 4 + q];
+                u32 bits = 0;
+                while (cand) {
+                    const int j = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    const int l = lbase + j;
+                    const v4f la = L.sA[l], lb = L.sB[l];
+                    if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, ka.x, ka.y, kbv.x, kbv.y, kbv.z, T)) bits |= 1u << j;
+                }
+                srow16[(k * 4 + lc) * 4 + q] = (u16)bits;
+            }
         }
     }
     __syncthreads();
@@ -1062,14 +1127,14 @@ template <bool HELLINGER, bool STAMPS>
 __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv, const DevConfig& cfg, float* __restrict__ out_slab,
                              int cap, int tid, u64* st, int n_update, bool packed)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const float T = cfg.minSeparation;
     // guard band of the trace filter; T <= 0: "2 d2 >= -(..)" always holds -> far, like the exact test
     const float Tpre = (T > 0.f) ? T * 1.01f : -1.f;
     const int S = n_surv;
     if (tid == 0) { L.ctr[CTR_KOUT] = 0; L.ctr[CTR_NHEAD] = 0; }
     if (S == 0) { __syncthreads(); return; }
-    if (S <= PHD_SMALL_S) { merge_small<HELLINGER, STAMPS>(L, S, cfg, out_slab, cap, tid, st, n_update); return; }
+    if (S <= PHD_SMALL_S) { merge_small<HELLINGER, STAMPS>(L, S_cap, S, cfg, out_slab, cap, tid, st, n_update); return; }
 
     // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
     int n_pad = 2;
@@ -1657,7 +1722,7 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
                                         int tid)
 {
 #pragma clang fp contract(off)
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const int Nmax = cn_len - 1;
     const float lam = cfg.clutterRate;
     const float llam = safe_log(lam), lkap = safe_log(cfg.clutterDensity);
@@ -1768,7 +1833,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(A.S_cap, A.cap, A.MM).total, A.cn_len, A.MM) : CphdLds();
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const int p = blockIdx.x;
     const DevConfig& cfg = A.cfg;
     const int cap = A.cap, S_cap = A.S_cap, M = A.M;
@@ -2204,7 +2269,7 @@ __device__ __forceinline__ u64 cdf_quantise(double p, double scale) { return (u6
 template <int BT>
 __device__ __forceinline__ u64 block_scan_u64(u64* q, int m, u64 carry, u64* s_wtot, int tid)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const int per = (m + BT - 1) / BT;
     const int lo = tid * per, hi = (lo + per < m) ? lo + per : m;
     u64 local = 0;
