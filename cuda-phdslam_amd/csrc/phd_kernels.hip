@@ -832,11 +832,10 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const float T = cfg.minSeparation;
     const float Tpre = (T > 0.f) ? T * 1.01f : -1.f;
-    // ---- rank by counting; P2 slots, PHD_T / P2 helper threads per survivor share the scan of the keys
-    int P2 = 64;
-    while (P2 < S) P2 <<= 1;
-    const int nh = PHD_T / P2;
-    const int i = tid & (P2 - 1), h = tid / P2;
+    // ---- rank by counting; nh = PHD_T / S (at most 8) threads per survivor share the scan of the keys: thread
+    //      tid serves survivor tid mod S, so that nearly every lane of the workgroup has work whatever S is
+    const int nh = (PHD_T / S) < 8 ? (PHD_T / S) : 8;   // S <= 256: at least 2
+    const int h = tid / S, i = tid - h * S;
     // the survivor planes are dead once the sorted staging has read them: the last three (yy, tr, u: >= 3 KB) hold the
     // filter's packed copy of the sorted means and radii
     lds_f32 fX2 = L.yy;                        // [128] (mx_l, mx_l+1, my_l, my_l+1)
@@ -845,7 +844,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     lds_u32 scnt = (lds_u32)(L.srow + PHD_SMALL_S);
     u32 mh = 0, ml = 0;
     float rw = 0, rmx = 0, rmy = 0, rxx = 0, rxy = 0, ryy = 0;
-    if (h == 0 && i < S) {
+    if (h == 0) {
         const int u0 = L.u[i];
         mh = orderable(L.w[i]);
         ml = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
@@ -854,18 +853,17 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
         rw = L.w[i]; rmx = L.mx[i]; rmy = L.my[i]; rxx = L.xx[i]; rxy = L.xy[i]; ryy = L.yy[i];
     }
     __syncthreads();
-    if (i < S) {
+    if (h < nh) {
         const u64 mine = skey[i];
         const int per = (S + nh - 1) / nh;
         const int j0 = h * per, j1 = (j0 + per < S) ? j0 + per : S;
         int cnt = 0;
 #pragma unroll 8
         for (int j = j0; j < j1; ++j) cnt += (skey[j] > mine) ? 1 : 0; // keys are unique: (weight, slab index)
-        if (nh > 1) atomicAdd((u32*)&scnt[i], (u32)cnt);
-        else scnt[i] = (u32)cnt;
+        atomicAdd((u32*)&scnt[i], (u32)cnt);
     }
     __syncthreads();
-    if (h == 0 && i < S) {
+    if (h == 0) {
         const int rank = (int)scnt[i];
         const bool spd = (rxx > 0.f) && (ryy > 0.f) && (rxx * ryy - rxy * rxy > 0.f);
         const float tr = spd ? (rxx + ryy) : INFINITY;
