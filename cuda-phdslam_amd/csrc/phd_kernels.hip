@@ -1234,6 +1234,16 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         //      COLS candidate-seed bits per (survivor, wave), stored as one field of the survivor's u64
         {
             const u32 myseeds = (u32)(seeds >> (PHD_COLS * wave)) & ((1u << PHD_COLS) - 1u);
+            // the wave's candidates are the same for the whole sweep: read them once and keep them in scalar registers
+            // (the sweep is bound by LDS return bandwidth — a broadcast read still returns a full wave of data)
+            float smx[PHD_COLS], smy[PHD_COLS], str[PHD_COLS];
+#pragma unroll
+            for (int c = 0; c < PHD_COLS; ++c) {
+                const int l = PHD_COLS * wave + c;
+                smx[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wmx[l])));
+                smy[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wmy[l])));
+                str[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wtr[l])));
+            }
             for (int e0 = 0; e0 < nrest; e0 += 64) {
                 const int e = e0 + lane;
                 u32 mbits = 0;
@@ -1243,17 +1253,16 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 #pragma unroll
                     for (int g = 0; g < PHD_COLS / 4; ++g) {
                         if (!((myseeds >> (4 * g)) & 0xFu)) continue; // uniform
-                        float smx[4], smy[4], str[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int l = PHD_COLS * wave + 4 * g + q;
-                            smx[q] = wmx[l]; smy[q] = wmy[l]; str[q] = wtr[l];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float dx = smx[q] - emx, dy = smy[q] - emy;
-                            const bool near = HELLINGER ? (etr > -INFINITY) : !(2.f * (dx * dx + dy * dy) >= Tpre * (str[q] + etr));
-                            if (near) mbits |= (1u << (4 * g + q));
+                        for (int q = 0; q < 4; q += 2) { // two candidates per step: packed arithmetic
+                            const int c = 4 * g + q;
+                            const v2f dx = (v2f){smx[c], smx[c + 1]} - (v2f){emx, emx};
+                            const v2f dy = (v2f){smy[c], smy[c + 1]} - (v2f){emy, emy};
+                            const v2f lhs = (v2f){2.f, 2.f} * (dx * dx + dy * dy);
+                            const v2f rhs = (v2f){Tpre, Tpre} * ((v2f){str[c], str[c + 1]} + (v2f){etr, etr});
+                            const bool near0 = HELLINGER ? (etr > -INFINITY) : !(lhs.x >= rhs.x);
+                            const bool near1 = HELLINGER ? (etr > -INFINITY) : !(lhs.y >= rhs.y);
+                            mbits |= (near0 ? (1u << c) : 0u) | (near1 ? (2u << c) : 0u);
                         }
                     }
                     mbits &= myseeds;
