@@ -450,6 +450,7 @@ int update_fuse_max_particles() { return PHD_T * 2; } // weights_body<PHD_T, 2> 
 
 enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */,
        CTR_NPAIR = 24 /* merge_small: candidate pairs listed for the exact closeness test */, CTR_NNEAR = 30 };
+#define PHD_CAND_SEG (1920 / PHD_NW) // u16 entries per wave in the (part, win) arrays, free until the merge
 
 // append one survivor; slot allocation is wave-aggregated (one LDS atomic per wave per call site)
 __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
@@ -1988,6 +1989,15 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const int lm = lane & (Mp - 1);
     const int js = lane / Mp;
 
+    // Pass 2 keeps a detection term iff exp(lw - log Z_m) >= minFeatureWeight, and log Z_m >= log(clutter + birth
+    // weight) whatever the map: a term with lw below log(minFeatureWeight) + log(clutter + birth) (1e-3 of slack for the
+    // rounding of either side) cannot survive.  Pass 1 has lw in a register, so it lists the few terms that can
+    // (about 1 in 10) and pass 2 visits the list, one term per thread, instead of every (feature, measurement)
+    // pair again.  PHD only (the CPHD weights carry a factor known after the ESFs); a full list falls back.
+    lds_u16 clist = (lds_u16)L.part;
+    const bool sparse2 = !CPHD && cfg.minFeatureWeight > 0.f && (n_in * M <= 0xFFFF);
+    const float c0m = safe_log(cfg.minFeatureWeight) + safe_log(cfg.clutterDensity + cfg.birthWeight) - 1e-3f;
+    int ncw = 0; // terms listed by this wave
     // ---- pass 1: normalisers ----------------------------------------------------------------------
     for (int mt = 0; mt < m_tiles; ++mt) {
         const int m = mt * 64 + lm;
@@ -2005,10 +2015,19 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const float lw = fc.y - 0.5f * dist;
             const float e = __expf(lw);                                                               // :2205
             acc += (mvalid && j < n_in) ? e : 0.f;
+            if (sparse2) {
+                // every wave fills its own segment of the list: positions from a ballot, no atomics in the loop
+                const bool cnd = mvalid && (j < n_in) && !(lw < c0m);   // NaN stays a candidate, as in the dense test
+                const u64 bal = __ballot(cnd);
+                const int pos = ncw + __popcll(bal & lanemask_lt());
+                if (cnd && pos < PHD_CAND_SEG) clist[wave * PHD_CAND_SEG + pos] = (u16)(m * n_in + j);
+                ncw += __popcll(bal);
+            }
         }
         for (int off = Mp; off < 64; off <<= 1) acc += xor_lane(acc, off);
         if (js == 0 && m < M) L.zpart[wave * A.MM + m] = acc;
     }
+    if (sparse2 && lane == 0) L.ctr[CTR_TMP + wave] = ncw; // the per-wave slots are free between the classification and the merge
     __syncthreads();
     float lz_local = 0.f;
     if (CPHD) {
@@ -2096,6 +2115,47 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // ---- pass 2: final weights; prune before store --------------------------------------------------
     STAMP(3);
     // detection terms
+    int n_cand = 0, seg_max = 0;
+    if (sparse2) {
+#pragma unroll
+        for (int wv = 0; wv < PHD_NW; ++wv) {
+            const int c = L.ctr[CTR_TMP + wv];
+            n_cand += c;
+            seg_max = c > seg_max ? c : seg_max;
+        }
+    }
+    if (sparse2 && seg_max <= PHD_CAND_SEG) {
+        const float rcp_nin = 1.0f / (float)(n_in > 0 ? n_in : 1);
+        for (int t0 = 0; t0 < n_cand; t0 += PHD_T) {
+            const int t = t0 + tid;
+            const bool tv = t < n_cand;
+            // entry t of the concatenated segments
+            int sw = 0, so = tv ? t : 0;
+#pragma unroll
+            for (int wv = 0; wv < PHD_NW - 1; ++wv) {
+                const int c = L.ctr[CTR_TMP + wv];
+                const bool next = (sw == wv) && (so >= c);
+                so = next ? so - c : so;
+                sw = next ? wv + 1 : sw;
+            }
+            const int idx = tv ? clist[sw * PHD_CAND_SEG + so] : 0;
+            const int m = (int)(((float)idx + 0.5f) * rcp_nin);      // idx = m * n_in + j < 2^16: exact
+            const int j = idx - m * n_in;
+            const v4f fa = L.f_a[j];
+            const v2f fc = L.f_c[j];
+            const float i0 = L.z_r[m] - fa.x;
+            const float i1 = wrap_angle(L.z_b[m] - fa.y);
+            const float dist = i0 * i0 * fa.z + i0 * i1 * fa.w + i1 * i1 * fc.x;
+            const float lw = fc.y - 0.5f * dist;
+            const float w = __expf(lw - L.logZ[m]);                                                   // :2242-2243 (listed terms have a valid label)
+            const bool keep = tv && !(w < cfg.minFeatureWeight);                                      // :2314
+            const int slot = alloc_slots(keep, L.ctr);
+            if (keep) {
+                if (slot < S_cap) { L.w[slot] = w; L.u[slot] = n_in + m * n_in + j; }
+                else L.ctr[CTR_OVERFLOW] = 1;
+            }
+        }
+    } else
     for (int mt = 0; mt < m_tiles; ++mt) {
         const int m = mt * 64 + lm;
         const bool mvalid = (m < M);

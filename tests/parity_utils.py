@@ -61,7 +61,9 @@ def assert_maps_close(got, ref, w_rtol=5e-4, w_atol=2e-7, m_atol=2e-4, c_rtol=2e
 def prune_margin(slab_weights, min_w):
     """min relative distance of an update-component weight to the prune threshold"""
     w = np.asarray(slab_weights, np.float64)
-    return float(np.min(np.abs(w - min_w) / min_w)) if len(w) else np.inf
+    if not len(w) or min_w <= 0:                # threshold 0 prunes nothing: no decision can flip
+        return np.inf
+    return float(np.min(np.abs(w - min_w) / min_w))
 
 
 def oracle_full_update(pose, gmap, z, ocfg):

@@ -114,6 +114,21 @@ def test_update_small(seed, N, G, M):
     check_update_against_oracle(P.default_config(), w, w["z"][0])
 
 
+@pytest.mark.parametrize("thr,G,M", [(0.0, 12, 6), (1e-30, 24, 33), (1e-12, 64, 64), (1e-3, 64, 32), (0.2, 30, 20)])
+def test_update_prune_threshold_paths(thr, G, M):
+    """min_weight picks how pass 2 finds the detection terms that survive the prune: 0 keeps every term (dense pass);
+    tiny thresholds make (nearly) every term a candidate, so the candidate list of pass 1 overflows and the dense
+    pass runs; the usual thresholds take the list; a large one prunes nearly everything.  Same survivors as the
+    oracle in every case."""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(3, G, M, seed=90 + M)
+    cfg = P.default_config(minFeatureWeight=thr)
+    cap = min(G * (M + 2) + M + 64, 4000) if thr < 1e-20 else 4 * G + 2 * M
+    st = check_update_against_oracle(cfg, w, w["z"][0], cap=cap, mm=max(M, 8), min_structural=0.0)
+    if thr == 0.0:
+        assert st["max_survivors"] > 3 * M                  # every (in-range feature, measurement) term survived
+
+
 def test_update_clustered_merge_stress():
     """config-3 style landmarks (clusters of 8 at 0.2 m): heavy merging"""
     P, S = pkg(), synthetic()
