@@ -124,7 +124,11 @@ def test_update_prune_threshold_paths(thr, G, M):
     w = S.make_workload(3, G, M, seed=90 + M)
     cfg = P.default_config(minFeatureWeight=thr)
     cap = min(G * (M + 2) + M + 64, 4000) if thr < 1e-20 else 4 * G + 2 * M
-    st = check_update_against_oracle(cfg, w, w["z"][0], cap=cap, mm=max(M, 8), min_structural=0.0)
+    # thresholds below ~1e-37 keep terms whose weight is a denormal on the host and zero on the device (v_exp_f32 flushes):
+    # the survivor sets still agree within the absolute weight tolerance and the merge is bit-exact on the device's own
+    # survivors, but the oracle's merge of ITS survivors can stop one cluster later (W == 0 rule, src/phdfilter.cu:2821)
+    st = check_update_against_oracle(cfg, w, w["z"][0], cap=cap, mm=max(M, 8), min_structural=0.0,
+                                     structural_maps=thr > 1e-20)
     if thr == 0.0:
         assert st["max_survivors"] > 3 * M                  # every (in-range feature, measurement) term survived
 
