@@ -1545,11 +1545,10 @@ __device__ __forceinline__ float clamp_log(float x) { return x < -1e30f ? -1e30f
 // configuration of BASELINE.json — the tile loops and their guards fold away, which halves the instruction count
 // of this single-wave, latency-bound section
 template <int tiles>
-__device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __restrict__ T_scratch, int M, int lane, float llam,
-                                                float lam)
+__device__ __forceinline__ void cphd_esf_backward(const CphdLds& Q, float2* __restrict__ T_scratch, int M, int lane, float llam,
+                                                  float lam)
 {
 #pragma clang fp contract(off)
-    const float LOG0F = -FLT_MAX;
     const int XF_ZERO_K = -(1 << 28);
     float tm[4];
     int tk[4];
@@ -1569,8 +1568,11 @@ __device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __rest
             T_scratch[(size_t)(M - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
         }
     }
+    // one tile: the roots sit in a register (lane m holds xi_m) and reach the recursion through v_readlane — an LDS
+    // read per step would put its latency on the critical path of this single-wave chain
+    const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;
     for (int m = M - 1; m >= 1; --m) {
-        const float x = Q.lxi[m];
+        const float x = (tiles == 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m)) : Q.lxi[m];
         float nm[4];
         int nk[4];
 #pragma unroll
@@ -1599,32 +1601,49 @@ __device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __rest
             }
         }
     }
-    __threadfence(); // the rows are read back by other lanes of this wave
-    // forward: P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
+    __threadfence(); // the rows are read back by the other waves of this workgroup (after its barrier)
+}
+
+// The forward sweep.  The recursion P_{m+1} = P_m (1 + xi_m x) is a short dependent chain per step; what is long is the
+// dot product D_m = <P_m, T_{m+1}> (two wave reductions and a log) — and nothing depends on it.  So EVERY wave of the
+// workgroup runs the (cheap) recursion redundantly and takes the dot products of the steps m = wave (mod PHD_NW) only:
+// eight dot products in flight instead of one, no data exchanged between the waves.
+template <int tiles>
+__device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2* __restrict__ T_scratch, int M, int lane, int wave,
+                                                 float llam, float lam)
+{
+#pragma clang fp contract(off)
+    const float LOG0F = -FLT_MAX;
+    const int XF_ZERO_K = -(1 << 28);
+    // P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
     float pm[4] = {0.f, 0.f, 0.f, 0.f};
     int pk[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
-    // the rows come back from L2 / HBM: keep PF of them in flight ahead of the step that uses them
+    // this wave's rows come back from L2 / HBM: keep PF of them in flight ahead of the step that uses them
     constexpr int PF = 4;
     float2 rbuf[PF][4], r0buf[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        const float2* row = T_scratch + (size_t)u * M;
+        const int mu = wave + PHD_NW * u;                 // this wave's u-th step
+        const float2* row = T_scratch + (size_t)mu * M;
         r0buf[u] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int c = 0; c < 4; ++c) rbuf[u][c] = make_float2(0.f, 0.f);
-        if (u < M) {
+        if (mu < M) {
             r0buf[u] = row[0];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 1 + 64 * c <= u) rbuf[u][c] = row[lane + 1 + 64 * c];
+                if (c < tiles && lane + 1 + 64 * c <= mu) rbuf[u][c] = row[lane + 1 + 64 * c];
         }
     }
-    for (int m0 = 0; m0 < M; m0 += PF) {
+    const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;   // as in the backward sweep
+    for (int m0 = 0; m0 < M; m0 += PF * PHD_NW) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        const int m = m0 + u;
+    for (int r = 0; r < PHD_NW; ++r) {
+        const int m = m0 + PHD_NW * u + r;
         if (m < M) {
-        const float x = Q.lxi[m];
+        const float x = (tiles == 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m)) : Q.lxi[m];
+        if (r == wave) {
         // D_m = T_{m+1}[0] + sum_{a=1..m} P_m[a] T_{m+1}[a]
         float qm[5];
         int qk[5];
@@ -1646,12 +1665,12 @@ __device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __rest
             qk[4] = (lane == 0) ? __float_as_int(t0.y) : 2 * XF_ZERO_K;
             kmax = max(kmax, qk[4]);
         }
-        if (m + PF < M) { // refill this slot with the row PF steps ahead
-            const float2* row = T_scratch + (size_t)(m + PF) * M;
+        if (m + PF * PHD_NW < M) { // refill this slot with the row of this wave's step PF turns ahead
+            const float2* row = T_scratch + (size_t)(m + PF * PHD_NW) * M;
             r0buf[u] = row[0];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 1 + 64 * c <= m + PF) rbuf[u][c] = row[lane + 1 + 64 * c];
+                if (c < tiles && lane + 1 + 64 * c <= m + PF * PHD_NW) rbuf[u][c] = row[lane + 1 + 64 * c];
         }
         kmax = wave_max_i(kmax);
         float s = 0.f;
@@ -1663,6 +1682,7 @@ __device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __rest
             const float dm = frexpf(s, &dk);
             Q.lD[m] = dm > 0.f ? logf(dm) + (float)(kmax + dk) * 0.69314718f : LOG0F;   // log <Y1[Z \ m], p>
         }
+        } // this wave's step
         // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
         float um[4];
         int uk[4];
@@ -1692,6 +1712,8 @@ __device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __rest
         } // m < M
     }
     }
+    }
+    if (wave != 0) return;
     // full set: e_j = P_M[j]; <Y0,p> and <Y1,p>
     float ev[4];
 #pragma unroll
@@ -1727,9 +1749,12 @@ __device__ __forceinline__ void cphd_esf_sweeps(const CphdLds& Q, float2* __rest
 __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const DevConfig& cfg, int M, int MM, int cn_len,
                                         const float* __restrict__ lfact_g, int lfact_len, const float* __restrict__ cn_prior,
                                         float* __restrict__ cn_out, float2* __restrict__ T_scratch, float w_all, float pdw,
-                                        int tid)
+                                        int tid, u64* cq)
 {
 #pragma clang fp contract(off)
+    // cq (diagnostic instantiation, thread 0): time of [staging .. n-sums, backward sweep, forward sweep, rest]
+#define CQSTAMP(k) do { if (cq && tid == 0) cq[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    CQSTAMP(0);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const int Nmax = cn_len - 1;
     const float lam = cfg.clutterRate;
@@ -1795,13 +1820,20 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // carries P in registers and takes one dot product per measurement.  Values span hundreds of decades, so
     // each is a float mantissa with its own integer exponent (m 2^k): align with v_ldexp, renormalise with
     // v_frexp — exact operations around one correctly rounded multiply and add (the oracle does the same).
+    const int tiles = (M + 63) >> 6;
+    CQSTAMP(1);
     if (wave == 0) {
-        const int tiles = (M + 63) >> 6;
-        if (tiles == 1) cphd_esf_sweeps<1>(Q, T_scratch, M, lane, llam, lam);
-        else if (tiles == 2) cphd_esf_sweeps<2>(Q, T_scratch, M, lane, llam, lam);
-        else cphd_esf_sweeps<4>(Q, T_scratch, M, lane, llam, lam);
+        if (tiles == 1) cphd_esf_backward<1>(Q, T_scratch, M, lane, llam, lam);
+        else if (tiles == 2) cphd_esf_backward<2>(Q, T_scratch, M, lane, llam, lam);
+        else cphd_esf_backward<4>(Q, T_scratch, M, lane, llam, lam);
     }
     __syncthreads();
+    CQSTAMP(2);
+    if (tiles == 1) cphd_esf_forward<1>(Q, T_scratch, M, lane, wave, llam, lam);
+    else if (tiles == 2) cphd_esf_forward<2>(Q, T_scratch, M, lane, wave, llam, lam);
+    else cphd_esf_forward<4>(Q, T_scratch, M, lane, wave, llam, lam);
+    __syncthreads();
+    CQSTAMP(3);
     const float lY0 = Q.scal[CQ_LY0];
     for (int m = tid; m < M; m += PHD_T) L.logZ[m] = -((llam - lkap) + Q.lD[m] - lY0);      // .bak:1434-1437
     if (tid == 0) Q.scal[CQ_R1] = expf(Q.scal[CQ_LY1] - lY0);                               // .bak:1452-1455
@@ -1823,6 +1855,8 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
         cn_out[n] = Q.cnp[n] + (safe_log(s) + mx) - lY0;
     }
     __syncthreads();
+    CQSTAMP(4);
+#undef CQSTAMP
 }
 
 // (defined further down) the weights / nEff / resample routine, run by the last workgroup of a fused step
@@ -1872,6 +1906,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         }
     }
     u64* st = STAMPS ? (A.stamps + (size_t)p * 16) : nullptr;
+    u64 cq[5] = {0, 0, 0, 0, 0};
     if (STAMPS && tid == 0) { st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0; }
     STAMP(0);
 
@@ -2043,7 +2078,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
         cphd_block(L, Q, cfg, M, A.MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
-                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid);
+                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid,
+                   STAMPS ? cq : nullptr);
         const float r1 = Q.scal[CQ_R1];
         // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
         for (int m0 = 0; m0 < M; m0 += PHD_T) {
@@ -2258,6 +2294,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         atomicMax(A.max_map, k_out + n_out0);
     }
     STAMP(11);
+    if (STAMPS && CPHD && tid == 0) { // the CPHD block's parts replace the merge-round statistics
+        st[12] = cq[1] - cq[0]; st[13] = cq[2] - cq[1]; st[14] = cq[3] - cq[2]; st[15] = cq[4] - cq[3];
+    }
     if (FUSEW) {
         // ---- fused tail: the workgroup that finishes last runs the weights / nEff / resample routine.
         // Hand-off (cdna guide, Guideline 16): lane 0 of every workgroup made its hand-off stores
@@ -2875,11 +2914,12 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
         // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
-        const void* fns[4] = {(const void*)phd_update_merge_kernel<false, false, false>,
+        const void* fns[5] = {(const void*)phd_update_merge_kernel<false, false, false>,
                               (const void*)phd_update_merge_kernel<true, false, false>,
                               (const void*)phd_update_merge_kernel<false, true, false>,
-                              (const void*)phd_update_merge_kernel<false, false, true>};
-        for (int k = 0; k < 4; ++k) {
+                              (const void*)phd_update_merge_kernel<false, false, true>,
+                              (const void*)phd_update_merge_kernel<true, false, true>};
+        for (int k = 0; k < 5; ++k) {
             hipFuncAttributes fa;
             hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
             if (e != hipSuccess) return e;
@@ -2888,7 +2928,8 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         }
         attr_set = true;
     }
-    if (a.cphd) hipLaunchKernelGGL((phd_update_merge_kernel<false, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    if (a.cphd && a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else if (a.cphd) hipLaunchKernelGGL((phd_update_merge_kernel<false, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else hipLaunchKernelGGL((phd_update_merge_kernel<false, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
