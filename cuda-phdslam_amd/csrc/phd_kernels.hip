@@ -1746,6 +1746,37 @@ __device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2*
         if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
 }
 
+template <int CH>
+__device__ __forceinline__ void cphd_nsums(const CphdLds& Q, int M, int Nmax, int lane, int wave, float lWq, float lW1)
+{
+#pragma clang fp contract(off)
+    const float LOG0F = -FLT_MAX;
+    for (int j = wave; j <= M + 1; j += PHD_NW) {
+        float tv[CH];
+        float mx = LOG0F;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int n = j + lane + 64 * c;
+            tv[c] = LOG0F;
+            if (n <= Nmax) {
+                tv[c] = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
+                mx = fmaxf(mx, tv[c]);
+            }
+        }
+        mx = wave_max_f(mx);
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (j + lane + 64 * c <= Nmax) sacc += __expf(tv[c] - mx);
+        sacc = wave_sum(sacc);
+        if (lane == 0) {
+            const float v = (j <= Nmax) ? safe_log(sacc) + mx : LOG0F;
+            if (j <= M) Q.I0[j] = v;
+            if (j >= 1) Q.I1[j - 1] = v;
+        }
+    }
+}
+
 __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const DevConfig& cfg, int M, int MM, int cn_len,
                                         const float* __restrict__ lfact_g, int lfact_len, const float* __restrict__ cn_prior,
                                         float* __restrict__ cn_out, float2* __restrict__ T_scratch, float w_all, float pdw,
@@ -1786,30 +1817,10 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // I_u[j] = log sum_n p(n) P(n,j+u) Wq^(n-j-u) / W1^n.  Since P(n,j+1) Wq^(n-j-1) is the u = 0 term of j+1,
     // I_1[j] = I_0[j+1] (the same floating-point expression): one family J[j] = I_0[j], j = 0..M+1.
     // Wave per j, lanes over n; the terms stay in registers between the max and the sum pass (n <= 1023).
-    for (int j = wave; j <= M + 1; j += PHD_NW) {
-        float tv[16];
-        float mx = LOG0F;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int n = j + lane + 64 * c;
-            tv[c] = LOG0F;
-            if (n <= Nmax) {
-                tv[c] = Q.cnp[n] + (Q.lfact[n] - Q.lfact[n - j]) + (float)(n - j) * lWq - (float)n * lW1;
-                mx = fmaxf(mx, tv[c]);
-            }
-        }
-        mx = wave_max_f(mx);
-        float sacc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (j + lane + 64 * c <= Nmax) sacc += __expf(tv[c] - mx);
-        sacc = wave_sum(sacc);
-        if (lane == 0) {
-            const float v = (j <= Nmax) ? safe_log(sacc) + mx : LOG0F;
-            if (j <= M) Q.I0[j] = v;
-            if (j >= 1) Q.I1[j - 1] = v;
-        }
-    }
+    // (the chunk count is a compile-time constant per cardinality length: max_cardinality 255 needs 4 of the 16)
+    if (cn_len <= 256) cphd_nsums<4>(Q, M, Nmax, lane, wave, lWq, lW1);
+    else if (cn_len <= 512) cphd_nsums<8>(Q, M, Nmax, lane, wave, lWq, lW1);
+    else cphd_nsums<16>(Q, M, Nmax, lane, wave, lWq, lW1);
     __syncthreads();
     // ESFs (.bak:1224-1272).  The .bak runs one full recursion per left-out measurement (O(M^3)); here
     //   e(Xi \ m) = P_m (*) S_{m+1}   (ESFs of the roots before and after m), so
@@ -2028,10 +2039,15 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // weight) whatever the map: a term with lw below log(minFeatureWeight) + log(clutter + birth) (1e-3 of slack for the
     // rounding of either side) cannot survive.  Pass 1 has lw in a register, so it lists the few terms that can
     // (about 1 in 10) and pass 2 visits the list, one term per thread, instead of every (feature, measurement)
-    // pair again.  PHD only (the CPHD weights carry a factor known after the ESFs); a full list falls back.
+    // pair again.  A full list falls back to the dense pass.
+    // CPHD: the weight is e_jm (lambda/kappa) <Y1[Z\m],p> / <Y0[Z],p>.  With e_j(Z) = e_j(Z\m) + xi_m e_{j-1}(Z\m) >=
+    // xi_m e_{j-1}(Z\m) and the coefficient identity c1_j = c0_{j+1} (I_1[j] = I_0[j+1], cphd_block), <Y0[Z],p> >=
+    // xi_m <Y1[Z\m],p>, xi_m = (lambda/kappa)(S_m + birth weight): the factor is at most 1/(S_m + birth) <= 1/birth,
+    // so lw >= log(minFeatureWeight) + log(birth) is necessary there (5e-2 of slack for the rounding of the ESF chain).
     lds_u16 clist = (lds_u16)L.part;
-    const bool sparse2 = !CPHD && cfg.minFeatureWeight > 0.f && (n_in * M <= 0xFFFF);
-    const float c0m = safe_log(cfg.minFeatureWeight) + safe_log(cfg.clutterDensity + cfg.birthWeight) - 1e-3f;
+    const bool sparse2 = cfg.minFeatureWeight > 0.f && (n_in * M <= 0xFFFF);
+    const float c0m = CPHD ? safe_log(cfg.minFeatureWeight) + safe_log(cfg.birthWeight) - 5e-2f
+                           : safe_log(cfg.minFeatureWeight) + safe_log(cfg.clutterDensity + cfg.birthWeight) - 1e-3f;
     int ncw = 0; // terms listed by this wave
     // ---- pass 1: normalisers ----------------------------------------------------------------------
     for (int mt = 0; mt < m_tiles; ++mt) {
