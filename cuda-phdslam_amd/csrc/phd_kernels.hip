@@ -547,56 +547,6 @@ __device__ __forceinline__ void reg_sort_desc64(u32 (&khi)[E], u32 (&klo)[E], u3
     }
 }
 
-template <int E>
-__device__ __forceinline__ void reg_sort_asc32(u32 (&key)[E], int n, int tid, lds_u32 x)
-{
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= E * 64) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = tid * E + e;
-                    if (i < n) x[i] = key[e];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = tid * E + e;
-                    if (i < n) {
-                        const u32 oth = x[i ^ j];
-                        const bool want_min = (((i & k) == 0) == ((i & j) == 0));
-                        if (want_min ? (oth < key[e]) : (oth > key[e])) key[e] = oth;
-                    }
-                }
-                __syncthreads();
-            } else if (j >= E) {
-                const int lm = j / E;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = tid * E + e;
-                    const u32 oth = __shfl_xor(key[e], lm);
-                    const bool want_min = (((i & k) == 0) == ((i & j) == 0));
-                    key[e] = want_min ? min(key[e], oth) : max(key[e], oth);
-                }
-            } else {
-#pragma unroll
-                for (int jj = E / 2; jj > 0; jj >>= 1) {
-                    if (j == jj) {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            if ((e & jj) == 0) {
-                                const int i = tid * E + e;
-                                const u32 a = key[e], b = key[e | jj];
-                                const bool asc = ((i & k) == 0);
-                                if (asc ? (a > b) : (a < b)) { key[e] = b; key[e | jj] = a; }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
 
 // keys-only variant of reg_sort_desc64 (the payload rides in the low 16 bits of the key)
 template <int E>
@@ -739,41 +689,6 @@ __device__ __forceinline__ void rank_sort_survivors(const Lds& L, int S, int tid
         const bool spd = (rxx > 0.f) && (ryy > 0.f) && (rxx * ryy - rxy * rxy > 0.f);
         L.tr[rank] = spd ? (rxx + ryy) : INFINITY;
         L.u[rank] = -1;
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void rank_sort_assignments(const Lds& L, int S, int tid)
-{
-    u32 mine = 0;
-    if (tid < S) { mine = ((u32)L.u[tid] << 16) | (u32)tid; L.pay[tid] = mine; }
-    __syncthreads();
-    if (tid < S) {
-        int rank = 0;
-#pragma unroll 8
-        for (int j = 0; j < S; ++j) rank += (L.pay[j] < mine) ? 1 : 0;
-        L.key2[rank] = mine;
-    }
-    __syncthreads();
-}
-
-// sort 2 of the merge: (seed position, own position) ascending -> clusters become contiguous,
-// members in (weight desc) order, seed first
-template <int E>
-__device__ __forceinline__ void sort_assignments(const Lds& L, int S, int n_pad, int tid)
-{
-    u32 key[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = tid * E + e;
-        key[e] = (i < S) ? (((u32)L.u[i] << 16) | (u32)i) : 0xFFFFFFFFu;
-    }
-    reg_sort_asc32<E>(key, n_pad, tid, L.key2);
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = tid * E + e;
-        if (i < n_pad) L.key2[i] = key[e];
     }
     __syncthreads();
 }
@@ -1322,33 +1237,86 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     }
 
     STAMP(7);
-    // ---- sort 2: group by seed, members in sorted-position order ---------------------------------
-    if (n_pad <= PHD_T) rank_sort_assignments(L, S, tid);
-    else if (n_pad <= 2 * PHD_T) sort_assignments<2>(L, S, n_pad, tid);
-    else if (n_pad <= 4 * PHD_T) sort_assignments<4>(L, S, n_pad, tid);
-    else sort_assignments<8>(L, S, n_pad, tid);
-    STAMP(8);
-    // cluster heads -> seg[]
+    // ---- group by seed, members in sorted-position order --------------------------------------------
+    // A counting sort instead of a second bitonic sort (a tenth of its instructions): members per seed (LDS atomics)
+    // -> one packed scan gives each seed its segment start (low half) and its cluster index (high half: seeds
+    // before it) -> members dropped into their seed's segment in arrival order -> every member finds its place by
+    // counting the smaller positions in its own segment (clusters are small), which makes the order — and so the
+    // summation order of the moment matching — deterministic.
     {
-        int running = 0;
-        for (int i0 = 0; i0 < S; i0 += PHD_T) {
-            const int i = i0 + tid;
-            bool head = false;
-            if (i < S) head = (i == 0) || ((L.key2[i] >> 16) != (L.key2[i - 1] >> 16));
-            const u64 bal = __ballot(head);
-            if (lane == 0) L.ctr[CTR_TMP + wave] = __popcll(bal);
+        lds_u32 cursor = L.khi;                 // per seed: members placed so far (then key2, the grouped list)
+        lds_u32 members = L.klo;                // segments in arrival order (then seg, the cluster starts)
+        lds_u32 cnt = L.pay;                    // per seed: member count -> packed exclusive prefix
+        for (int i = tid; i < S; i += PHD_T) { cnt[i] = 0u; cursor[i] = 0u; }
+        __syncthreads();
+        for (int i = tid; i < S; i += PHD_T) atomicAdd((u32*)&cnt[assign[i]], 1u);
+        __syncthreads();
+        const int per = (S + PHD_T - 1) / PHD_T; // <= 4 (S <= 2048)
+        u32 total;
+        {
+            const int lo = tid * per;
+            u32 v[4], local = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sd = lo + e;
+                v[e] = (e < per && sd < S) ? (cnt[sd] | ((assign[sd] == sd) ? 0x10000u : 0u)) : 0u;
+                local += v[e];
+            }
+            const u32 incl = wave_incl_scan(local);
+            if (lane == 63) L.ctr[CTR_TMP + wave] = (int)incl;
             __syncthreads();
-            int off = running;
-            for (int w = 0; w < wave; ++w) off += L.ctr[CTR_TMP + w];
-            int total = 0;
-            for (int w = 0; w < PHD_NW; ++w) total += L.ctr[CTR_TMP + w];
-            if (head) L.seg[off + __popcll(bal & lanemask_lt())] = i;
-            running += total;
-            __syncthreads();
+            u32 woff = 0u;
+            total = 0u;
+#pragma unroll
+            for (int w = 0; w < PHD_NW; ++w) {
+                const u32 c = (u32)L.ctr[CTR_TMP + w];
+                if (w < wave) woff += c;
+                total += c;
+            }
+            u32 run = woff + incl - local;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sd = lo + e;
+                if (e < per && sd < S) { cnt[sd] = run; run += v[e]; }
+            }
         }
-        if (tid == 0) { L.seg[running] = S; L.ctr[CTR_NHEAD] = running; L.ctr[CTR_KOUT] = 0x7FFFFFFF; }
+        __syncthreads();
+        int sreg[4], pos[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + e * PHD_T;
+            sreg[e] = 0;
+            if (i < S) {
+                const int sd = assign[i];
+                sreg[e] = sd;
+                members[(cnt[sd] & 0xFFFFu) + atomicAdd((u32*)&cursor[sd], 1u)] = (u32)i;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + e * PHD_T;
+            pos[e] = 0;
+            if (i < S) {
+                const int b = (int)(cnt[sreg[e]] & 0xFFFFu), k = (int)cursor[sreg[e]];
+                int r = 0;
+                for (int t = 0; t < k; ++t) r += ((int)members[b + t] < i) ? 1 : 0;
+                pos[e] = b + r;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + e * PHD_T;
+            if (i < S) {
+                L.key2[pos[e]] = ((u32)sreg[e] << 16) | (u32)i;                    // key2 aliases cursor
+                if (sreg[e] == i) L.seg[cnt[i] >> 16] = (int)(cnt[i] & 0xFFFFu);   // seg aliases members
+            }
+        }
+        if (tid == 0) { L.seg[total >> 16] = S; L.ctr[CTR_NHEAD] = (int)(total >> 16); L.ctr[CTR_KOUT] = 0x7FFFFFFF; }
         __syncthreads();
     }
+    STAMP(8);
     const int n_clusters = L.ctr[CTR_NHEAD];
     STAMP(9);
 
