@@ -183,6 +183,18 @@ __device__ __forceinline__ float wave_sum(float v)
     v += xor_lane_c<4>(v); v += xor_lane_c<2>(v); v += xor_lane_c<1>(v);
     return v;
 }
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    v = fmaxf(v, xor_lane_c<32>(v)); v = fmaxf(v, xor_lane_c<16>(v)); v = fmaxf(v, xor_lane_c<8>(v));
+    v = fmaxf(v, xor_lane_c<4>(v)); v = fmaxf(v, xor_lane_c<2>(v)); v = fmaxf(v, xor_lane_c<1>(v));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = max(v, (int)xor_lane_c<32>((u32)v)); v = max(v, (int)xor_lane_c<16>((u32)v)); v = max(v, (int)xor_lane_c<8>((u32)v));
+    v = max(v, (int)xor_lane_c<4>((u32)v)); v = max(v, (int)xor_lane_c<2>((u32)v)); v = max(v, (int)xor_lane_c<1>((u32)v));
+    return v;
+}
 
 // block-wide sum with a fixed reduction tree (deterministic); scratch: PHD_NW floats
 __device__ __forceinline__ float block_sum(float v, LDS_T(float)* scratch, int tid)
@@ -693,6 +705,137 @@ __device__ __forceinline__ void rank_sort_survivors(const Lds& L, int S, int tid
     __syncthreads();
 }
 
+// sort 1 for the large mixtures without a sorting network: the weight keys are nearly uniform in their (orderable) bit
+// pattern — a log scale — so a counting sort on the leading bits leaves buckets of a few survivors each, and a
+// survivor's rank is its bucket's start plus the number of larger keys in its own bucket.  A quarter of the
+// instructions of the register bitonic sort.  Returns false (uniformly, before anything the network needs is
+// touched) when a bucket is crowded — many equal weights — and the network is the better tool.
+__device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S_cap, int tid, int lane, int wave, int n_update)
+{
+    lds_u32 cntc = L.pay;             // per bucket: count -> (placed << 16) | start
+    lds_u32 members = (lds_u32)L.u;   // bucket segments in arrival order (the slab indices live in the keys by then)
+    const int NB = S_cap;             // buckets: a power of two >= 512
+    u32 mh[4], ml[4];
+    int bk[4];
+    float rw[4], rmx[4], rmy[4], rxx[4], rxy[4], ryy[4];
+    u32 kmn = 0xFFFFFFFFu, kmx = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        mh[e] = 0u; ml[e] = 0u; bk[e] = 0;
+        rw[e] = rmx[e] = rmy[e] = rxx[e] = rxy[e] = ryy[e] = 0.f;
+        if (i < S) {
+            const int u0 = L.u[i];
+            mh[e] = orderable(L.w[i]);
+            ml[e] = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
+            L.khi[i] = mh[e]; L.klo[i] = ml[e];
+            kmn = mh[e] < kmn ? mh[e] : kmn;
+            kmx = mh[e] > kmx ? mh[e] : kmx;
+            rw[e] = L.w[i]; rmx[e] = L.mx[i]; rmy[e] = L.my[i]; rxx[e] = L.xx[i]; rxy[e] = L.xy[i]; ryy[e] = L.yy[i];
+        }
+    }
+    for (int b = tid; b < NB; b += PHD_T) cntc[b] = 0u;
+    // workgroup range of the weight keys
+    {
+        u32 o;
+        o = xor_lane_c<32>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<32>(kmx); kmx = o > kmx ? o : kmx;
+        o = xor_lane_c<16>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<16>(kmx); kmx = o > kmx ? o : kmx;
+        o = xor_lane_c<8>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<8>(kmx); kmx = o > kmx ? o : kmx;
+        o = xor_lane_c<4>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<4>(kmx); kmx = o > kmx ? o : kmx;
+        o = xor_lane_c<2>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<2>(kmx); kmx = o > kmx ? o : kmx;
+        o = xor_lane_c<1>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<1>(kmx); kmx = o > kmx ? o : kmx;
+    }
+    if (lane == 0) { L.ctr[CTR_TMP + wave] = (int)kmn; L.ctr[CTR_TMP + PHD_NW + wave] = (int)kmx; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < PHD_NW; ++w) {
+        const u32 a = (u32)L.ctr[CTR_TMP + w], b = (u32)L.ctr[CTR_TMP + PHD_NW + w];
+        kmn = a < kmn ? a : kmn;
+        kmx = b > kmx ? b : kmx;
+    }
+    const u32 range = kmx - kmn;
+    const int bits = range ? 32 - __clz((int)range) : 0, lognb = 31 - __clz(NB);
+    const int shift = bits > lognb ? bits - lognb : 0;          // (range >> shift) < NB; bucket 0 holds the largest weights
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        if (i < S) { bk[e] = (int)((kmx - mh[e]) >> shift); atomicAdd((u32*)&cntc[bk[e]], 1u); }
+    }
+    __syncthreads();
+    // exclusive scan over the buckets (thread t owns buckets [t per, (t + 1) per)), and the largest bucket
+    {
+        const int per = NB / PHD_T;                               // 1, 2 or 4
+        const int lo = tid * per;
+        u32 v[4], local = 0u, lmax = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (e < per) ? cntc[lo + e] : 0u;
+            local += v[e];
+            lmax = v[e] > lmax ? v[e] : lmax;
+        }
+        const u32 incl = wave_incl_scan(local);
+        lmax = (u32)wave_max_i((int)lmax);
+        if (lane == 63) L.ctr[CTR_TMP + wave] = (int)incl;
+        if (lane == 0) L.ctr[CTR_TMP + PHD_NW + wave] = (int)lmax;
+        __syncthreads();
+        u32 woff = 0u, bmax = 0u;
+#pragma unroll
+        for (int w = 0; w < PHD_NW; ++w) {
+            const u32 c = (u32)L.ctr[CTR_TMP + w], m = (u32)L.ctr[CTR_TMP + PHD_NW + w];
+            if (w < wave) woff += c;
+            bmax = m > bmax ? m : bmax;
+        }
+        if (bmax > 128u) { __syncthreads(); return false; }       // uniform
+        u32 run = woff + incl - local;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < per) { cntc[lo + e] = run; run += v[e]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        if (i < S) {
+            const u32 old = atomicAdd((u32*)&cntc[bk[e]], 0x10000u);
+            members[(old & 0xFFFFu) + (old >> 16)] = (u32)i;
+        }
+    }
+    __syncthreads();
+    int rank[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        rank[e] = 0;
+        if (i < S) {
+            const u32 c = cntc[bk[e]];
+            const int base = (int)(c & 0xFFFFu), k = (int)(c >> 16);
+            const u64 mine = ((u64)mh[e] << 32) | ml[e];
+            int r = 0;
+            for (int t = 0; t < k; ++t) {
+                const int m = (int)members[base + t];
+                const u64 o = ((u64)L.khi[m] << 32) | L.klo[m];
+                r += (o > mine) ? 1 : 0;                           // keys are unique: (weight, slab index)
+            }
+            rank[e] = base + r;
+        }
+    }
+    __syncthreads(); // every read of the old order (and of the member lists, which sit in u) precedes the writes below
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        if (i < S) {
+            const int k = rank[e];
+            L.w[k] = rw[e]; L.mx[k] = rmx[e]; L.my[k] = rmy[e];
+            L.xx[k] = rxx[e]; L.xy[k] = rxy[e]; L.yy[k] = ryy[e];
+            const bool spd = (rxx[e] > 0.f) && (ryy[e] > 0.f) && (rxx[e] * ryy[e] - rxy[e] * rxy[e] > 0.f);
+            L.tr[k] = spd ? (rxx[e] + ryy[e]) : INFINITY;
+            L.u[k] = -1; // unassigned
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 // Is survivor e within the merge distance of seed s?  (d(s,e) < T, src/phdfilter.cu:2802-2806)
 //
 // Mahalanobis: the decision is taken WITHOUT the four divisions of the reference formula whenever it
@@ -1053,7 +1196,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
     int n_pad = 2;
     while (n_pad < S) n_pad <<= 1;
-    if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid, n_update);
+    if (bucket_sort_survivors(L, S, S_cap, tid, lane, wave, n_update)) { /* counting sort did it */ }
+    else if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid, n_update);
     else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid, n_update, packed);
     else if (n_pad <= 4 * PHD_T) sort_survivors<4>(L, S, n_pad, tid, n_update, packed);
     else sort_survivors<8>(L, S, n_pad, tid, n_update, packed);
@@ -1488,18 +1632,6 @@ __device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
     return Q;
 }
 
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    v = fmaxf(v, xor_lane_c<32>(v)); v = fmaxf(v, xor_lane_c<16>(v)); v = fmaxf(v, xor_lane_c<8>(v));
-    v = fmaxf(v, xor_lane_c<4>(v)); v = fmaxf(v, xor_lane_c<2>(v)); v = fmaxf(v, xor_lane_c<1>(v));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-    v = max(v, (int)xor_lane_c<32>((u32)v)); v = max(v, (int)xor_lane_c<16>((u32)v)); v = max(v, (int)xor_lane_c<8>((u32)v));
-    v = max(v, (int)xor_lane_c<4>((u32)v)); v = max(v, (int)xor_lane_c<2>((u32)v)); v = max(v, (int)xor_lane_c<1>((u32)v));
-    return v;
-}
 
 __device__ __forceinline__ float lse2f(float a, float b)
 {

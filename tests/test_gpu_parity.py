@@ -133,6 +133,17 @@ def test_update_prune_threshold_paths(thr, G, M):
         assert st["max_survivors"] > 3 * M                  # every (in-range feature, measurement) term survived
 
 
+def test_update_equal_weights_fall_back_to_the_sorting_network():
+    """several hundred survivors with the SAME weight (a fresh map of equal-weight features, nothing detected): the counting
+    sort of the merge would put them all in one bucket, so the kernel falls back to the register sorting network; the
+    order is then decided by the slab-index tie-break alone"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(2, 400, 4, seed=57)
+    w["maps"]["weight"][:] = np.float32(0.4)
+    st = check_update_against_oracle(P.default_config(), w, w["z"][0], cap=1024, min_structural=0.0)
+    assert st["max_survivors"] > 256
+
+
 def test_update_clustered_merge_stress():
     """config-3 style landmarks (clusters of 8 at 0.2 m): heavy merging"""
     P, S = pkg(), synthetic()
