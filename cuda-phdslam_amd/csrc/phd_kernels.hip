@@ -717,13 +717,11 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
     const int NB = S_cap;             // buckets: a power of two >= 512
     u32 mh[4], ml[4];
     int bk[4];
-    float rw[4], rmx[4], rmy[4], rxx[4], rxy[4], ryy[4];
     u32 kmn = 0xFFFFFFFFu, kmx = 0u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = tid + e * PHD_T;
         mh[e] = 0u; ml[e] = 0u; bk[e] = 0;
-        rw[e] = rmx[e] = rmy[e] = rxx[e] = rxy[e] = ryy[e] = 0.f;
         if (i < S) {
             const int u0 = L.u[i];
             mh[e] = orderable(L.w[i]);
@@ -731,7 +729,6 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
             L.khi[i] = mh[e]; L.klo[i] = ml[e];
             kmn = mh[e] < kmn ? mh[e] : kmn;
             kmx = mh[e] > kmx ? mh[e] : kmx;
-            rw[e] = L.w[i]; rmx[e] = L.mx[i]; rmy[e] = L.my[i]; rxx[e] = L.xx[i]; rxy[e] = L.xy[i]; ryy[e] = L.yy[i];
         }
     }
     for (int b = tid; b < NB; b += PHD_T) cntc[b] = 0u;
@@ -818,6 +815,14 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
             }
             rank[e] = base + r;
         }
+    }
+    // the planes are staged through registers only now (short live ranges: the kernel sits at its register budget)
+    float rw[4], rmx[4], rmy[4], rxx[4], rxy[4], ryy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        rw[e] = rmx[e] = rmy[e] = rxx[e] = rxy[e] = ryy[e] = 0.f;
+        if (i < S) { rw[e] = L.w[i]; rmx[e] = L.mx[i]; rmy[e] = L.my[i]; rxx[e] = L.xx[i]; rxy[e] = L.xy[i]; ryy[e] = L.yy[i]; }
     }
     __syncthreads(); // every read of the old order (and of the member lists, which sit in u) precedes the writes below
 #pragma unroll
