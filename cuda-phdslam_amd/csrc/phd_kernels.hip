@@ -1307,7 +1307,9 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 const int l = PHD_COLS * wave + c;
                 smx[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wmx[l])));
                 smy[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wmy[l])));
-                str[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wtr[l])));
+                // the filter's right-hand side Tpre (tr_l + tr_e) / 2 is split into a per-candidate and a per-survivor half
+                // (it is a conservative bound with a 1 % guard band: the rounding of the split is immaterial)
+                str[c] = 0.5f * Tpre * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wtr[l])));
             }
             for (int e0 = 0; e0 < nrest; e0 += 64) {
                 const int e = e0 + lane;
@@ -1315,6 +1317,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 if (myseeds) {
                     float emx = 0, emy = 0, etr = -INFINITY; // -inf trace: the filter rejects
                     if (e < nrest) { const int i = cur[64 + e]; emx = L.mx[i]; emy = L.my[i]; etr = L.tr[i]; }
+                    const float eth = 0.5f * Tpre * etr;
 #pragma unroll
                     for (int g = 0; g < PHD_COLS / 4; ++g) {
                         if (!((myseeds >> (4 * g)) & 0xFu)) continue; // uniform
@@ -1323,8 +1326,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                             const int c = 4 * g + q;
                             const v2f dx = (v2f){smx[c], smx[c + 1]} - (v2f){emx, emx};
                             const v2f dy = (v2f){smy[c], smy[c + 1]} - (v2f){emy, emy};
-                            const v2f lhs = (v2f){2.f, 2.f} * (dx * dx + dy * dy);
-                            const v2f rhs = (v2f){Tpre, Tpre} * ((v2f){str[c], str[c + 1]} + (v2f){etr, etr});
+                            const v2f lhs = dx * dx + dy * dy;
+                            const v2f rhs = (v2f){str[c], str[c + 1]} + (v2f){eth, eth};
                             const bool near0 = HELLINGER ? (etr > -INFINITY) : !(lhs.x >= rhs.x);
                             const bool near1 = HELLINGER ? (etr > -INFINITY) : !(lhs.y >= rhs.y);
                             mbits |= (near0 ? (1u << c) : 0u) | (near1 ? (2u << c) : 0u);
