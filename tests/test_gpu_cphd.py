@@ -135,7 +135,7 @@ def test_cphd_cardinalities_follow_the_particles():
         assert np.array_equal(f.cardinalities(), cn3) and len(m3) == N and len(maps_before) == N
 
 
-def _worker(rank, world, port, out_dir, N, G, M, seed, u):
+def _worker(rank, world, port, out_dir, N, G, M, seed, u, exchange):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -158,23 +158,31 @@ def _worker(rank, world, port, out_dir, N, G, M, seed, u):
     torch.cuda.synchronize()
     shard = D.GpuShard(f, N)
     sf = D.ShardedFilter(shard, N, rank, world)
-    f.predict_dev((2.0, 0.05), d_noise.data_ptr())
-    shard.update_local_dev(d_z.data_ptr(), M)
-    sf.normalize(sf.gather_logweights())
-    idx = sf.resample(u)
+    if exchange == "alltoall":
+        sf.gathered_limit = 0
+    if exchange == "rows":
+        # the local step writes maps, poses, counts, raw weights AND the cardinality rows straight into the export rows
+        rows = shard.step_local_rows((2.0, 0.05), d_noise.data_ptr(), d_z.data_ptr(), M)
+        idx = sf.resample_gathered(u, weights_in_rows=True, want_idx=True, rows=rows)
+    else:
+        f.predict_dev((2.0, 0.05), d_noise.data_ptr())
+        shard.update_local_dev(d_z.data_ptr(), M)
+        sf.normalize(sf.gather_logweights())
+        idx = sf.resample(u)                                  # "gathered": separate export, indices from normalize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, cn=f.cardinalities(), lw=f.get_particles()[1])
     f.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_cphd_two_ranks_equal_one_filter(tmp_path):
-    """the cardinality rows migrate with the particles (export / import behind the slab)"""
+@pytest.mark.parametrize("exchange", ["alltoall", "gathered", "rows"])
+def test_cphd_two_ranks_equal_one_filter(tmp_path, exchange):
+    """the cardinality rows migrate with the particles (export / import behind the slab), in every form of the exchange"""
     import torch.multiprocessing as mp
     P, S = pkg(), synthetic()
     N, G, M, seed, u, world = 48, 16, 8, 31, 0.27, 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), N, G, M, seed, u), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), N, G, M, seed, u, exchange), nprocs=world, join=True)
     w = S.make_workload(N, G, M, seed=seed)
     with P.PhdFilter(P.default_config(n_particles=N, filterType=1, maxCardinality=63), n_particles=N, map_capacity=4 * G,
                      max_measurements=M) as f:
