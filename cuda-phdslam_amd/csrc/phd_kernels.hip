@@ -945,31 +945,35 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     u64 tq0 = 0, tq1 = 0, tq2 = 0;
     lds_u32 plist = (lds_u32)L.w;                // candidate pairs (k << 16 | l): the first five survivor planes
     const int pcap = 5 * S_cap;
-    // ---- closeness rows: work units (block of 64 positions kb, 16 columns of a column block lc <= kb), dealt
-    //      round-robin to the waves; a unit fills one 16-bit quarter of the row word srow[k][lc]
+    // ---- closeness rows.  Work units are HALF waves: 32 consecutive positions (half-block hb) x 16 columns (column unit
+    //      cu, columns 16 cu .. 16 cu + 15, only units with a column below the half-block's last row), two units per
+    //      wave iteration, dealt round-robin to the waves; a unit fills the 16-bit quarter cu of its rows' words.
+    //      (With 64-position units a 148-survivor mixture paid for 24 units of which 44 % was real work; now 15.)
+    const int ncu = (S + 15) >> 4, nhb = (S + 31) >> 5;
+    int n_half = 0;
+    for (int hb = 0; hb < nhb; ++hb) n_half += (2 * hb + 2 < ncu) ? 2 * hb + 2 : ncu;
     {
         static_assert(PHD_SMALL_S == 256, "merge_small uses four 64-bit words per row");
-        // (the rows are not cleared: every quarter a later phase reads — words lc <= kb of the rows k < S — is written
+        // (the rows are not cleared: every quarter a later phase reads — words lc <= k / 64 of the rows k < S — is written
         //  below; the member masks are cleared here, they are first touched two barriers later)
         for (int t = tid; t < PHD_SMALL_S * 4; t += PHD_T) L.scol[t] = 0ull;
         if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
         LDS_T(u16)* srow16 = (LDS_T(u16)*)L.srow;
-        const int nblk = (S + 63) >> 6;
-        const int n_units = 4 * (nblk * (nblk + 1) / 2);
-        for (int unit = wave; unit < n_units; unit += PHD_NW) {
-            const int q = unit & 3;
-            int kb = 0, lc = unit >> 2;
-            while (lc > kb) { lc -= kb + 1; ++kb; }            // item -> (kb, lc), lc <= kb
-            const int lbase = 64 * lc + 16 * q;
-            const int k = 64 * kb + lane;
-            if (lbase >= S) { srow16[(k * 4 + lc) * 4 + q] = 0; continue; }   // uniform: no such columns
-            const bool kvalid = k < S;
-            const int kk = kvalid ? k : S - 1;
+        for (int u0 = 2 * wave; u0 < n_half; u0 += 2 * PHD_NW) {
+            const int h = u0 + (lane >> 5);
+            const bool hvalid = h < n_half;
+            int hb = 0, cu = hvalid ? h : 0;
+            for (;;) { const int c = (2 * hb + 2 < ncu) ? 2 * hb + 2 : ncu; if (cu < c) break; cu -= c; ++hb; }
+            const int cnt_hb = (2 * hb + 2 < ncu) ? 2 * hb + 2 : ncu;
+            const int lbase = 16 * cu;
+            const int k = 32 * hb + (lane & 31);
+            const bool kvalid = hvalid && k < S;
+            const int kk = (k < S) ? k : S - 1;
             const v4f ka = L.sA[kk];
             const float kmx = ka.x, kmy = ka.y, kat = ka.z;
             // cheap conservative filter over the unit's 16 columns, branch-free: d^2 < 0.505 T (tr_l + tr_k)
             // (d >= 2|dm|^2/(tr Pa + tr Pb) for SPD covariances, 1 % guard band; +inf trace = "always a candidate").
-            // The column data are LDS broadcast reads (same address in every lane), all 16 in flight.
+            // The column data are LDS broadcast reads (one address per half wave), all in flight.
             // Columns >= S hold stale data of earlier steps: the test l < k (< S) masks them.
             u32 cand = 0;
             const LDS_T(v4f)* cX = (const LDS_T(v4f)*)fX2 + (lbase >> 1);
@@ -991,7 +995,16 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
             // exact decision does not run here, one divergent loop per lane: the row keeps the candidate bits and the
             // pairs go to a list (wave-aggregated slot allocation) that the whole workgroup tests one pair per
             // thread below.  The list lives in the survivor planes, dead since the sorted staging.
-            srow16[(k * 4 + lc) * 4 + q] = (u16)cand;
+            if (hvalid) {
+                srow16[k * 16 + cu] = (u16)cand;
+                // the unit on the first quarter of the rows' own word also zeroes the quarters of that word no unit covers
+                const int q0 = 4 * (hb >> 1);
+                if (cu == q0) {
+#pragma unroll
+                    for (int q = 1; q < 4; ++q)
+                        if (q0 + q >= cnt_hb) srow16[k * 16 + q0 + q] = 0;
+                }
+            }
             const int np = __popc(cand);
             const int incl = (int)wave_incl_scan((u32)np);
             const int tot = __builtin_amdgcn_readlane(incl, 63);
@@ -1024,18 +1037,16 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
             // more candidates than the list holds (dense clutter of overlapping Gaussians, or the Hellinger metric, which
             // has no cheap filter): the exact decision per position on its marked columns
             LDS_T(u16)* srow16 = (LDS_T(u16)*)L.srow;
-            const int nblk = (S + 63) >> 6;
-            const int n_units = 4 * (nblk * (nblk + 1) / 2);
-            for (int unit = wave; unit < n_units; unit += PHD_NW) {
-                const int q = unit & 3;
-                int kb = 0, lc = unit >> 2;
-                while (lc > kb) { lc -= kb + 1; ++kb; }
-                const int lbase = 64 * lc + 16 * q;
-                const int k = 64 * kb + lane;
-                if (lbase >= S) continue;
+            for (int u0 = 2 * wave; u0 < n_half; u0 += 2 * PHD_NW) {
+                const int h = u0 + (lane >> 5);
+                if (h >= n_half) continue;
+                int hb = 0, cu = h;
+                for (;;) { const int c = (2 * hb + 2 < ncu) ? 2 * hb + 2 : ncu; if (cu < c) break; cu -= c; ++hb; }
+                const int lbase = 16 * cu;
+                const int k = 32 * hb + (lane & 31);
                 const int kk = k < S ? k : S - 1;
                 const v4f ka = L.sA[kk], kbv = L.sB[kk];
-                u32 cand = srow16[(k * 4 + lc) * 4 + q];
+                u32 cand = srow16[k * 16 + cu];
                 u32 bits = 0;
                 while (cand) {
                     const int j = __builtin_ctz(cand);
@@ -1044,7 +1055,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
                     const v4f la = L.sA[l], lb = L.sB[l];
                     if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, ka.x, ka.y, kbv.x, kbv.y, kbv.z, T)) bits |= 1u << j;
                 }
-                srow16[(k * 4 + lc) * 4 + q] = (u16)bits;
+                srow16[k * 16 + cu] = (u16)bits;
             }
         }
     }
