@@ -1727,11 +1727,15 @@ __device__ __forceinline__ void cphd_esf_backward(const CphdLds& Q, float2* __re
 // dot product D_m = <P_m, T_{m+1}> (two wave reductions and a log) — and nothing depends on it.  So EVERY wave of the
 // workgroup runs the (cheap) recursion redundantly and takes the dot products of the steps m = wave (mod PHD_NW) only:
 // eight dot products in flight instead of one, no data exchanged between the waves.
+#ifndef PHD_FW
+#define PHD_FW 4
+#endif
 template <int tiles>
 __device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2* __restrict__ T_scratch, int M, int lane, int wave,
                                                  float llam, float lam)
 {
 #pragma clang fp contract(off)
+    if (wave >= PHD_FW) return;   // the recursion is redundant work: only this many waves take part
     const float LOG0F = -FLT_MAX;
     const int XF_ZERO_K = -(1 << 28);
     // P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
@@ -1742,7 +1746,7 @@ __device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2*
     float2 rbuf[PF][4], r0buf[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        const int mu = wave + PHD_NW * u;                 // this wave's u-th step
+        const int mu = wave + PHD_FW * u;                 // this wave's u-th step
         const float2* row = T_scratch + (size_t)mu * M;
         r0buf[u] = make_float2(0.f, 0.f);
 #pragma unroll
@@ -1755,11 +1759,11 @@ __device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2*
         }
     }
     const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;   // as in the backward sweep
-    for (int m0 = 0; m0 < M; m0 += PF * PHD_NW) {
+    for (int m0 = 0; m0 < M; m0 += PF * PHD_FW) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-    for (int r = 0; r < PHD_NW; ++r) {
-        const int m = m0 + PHD_NW * u + r;
+    for (int r = 0; r < PHD_FW; ++r) {
+        const int m = m0 + PHD_FW * u + r;
         if (m < M) {
         const float x = (tiles == 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m)) : Q.lxi[m];
         if (r == wave) {
@@ -1784,12 +1788,12 @@ __device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2*
             qk[4] = (lane == 0) ? __float_as_int(t0.y) : 2 * XF_ZERO_K;
             kmax = max(kmax, qk[4]);
         }
-        if (m + PF * PHD_NW < M) { // refill this slot with the row of this wave's step PF turns ahead
-            const float2* row = T_scratch + (size_t)(m + PF * PHD_NW) * M;
+        if (m + PF * PHD_FW < M) { // refill this slot with the row of this wave's step PF turns ahead
+            const float2* row = T_scratch + (size_t)(m + PF * PHD_FW) * M;
             r0buf[u] = row[0];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 1 + 64 * c <= m + PF * PHD_NW) rbuf[u][c] = row[lane + 1 + 64 * c];
+                if (c < tiles && lane + 1 + 64 * c <= m + PF * PHD_FW) rbuf[u][c] = row[lane + 1 + 64 * c];
         }
         kmax = wave_max_i(kmax);
         float s = 0.f;
