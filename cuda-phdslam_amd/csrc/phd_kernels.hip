@@ -1724,9 +1724,10 @@ __device__ __forceinline__ void cphd_esf_backward(const CphdLds& Q, float2* __re
 }
 
 // The forward sweep.  The recursion P_{m+1} = P_m (1 + xi_m x) is a short dependent chain per step; what is long is the
-// dot product D_m = <P_m, T_{m+1}> (two wave reductions and a log) — and nothing depends on it.  So EVERY wave of the
-// workgroup runs the (cheap) recursion redundantly and takes the dot products of the steps m = wave (mod PHD_NW) only:
-// eight dot products in flight instead of one, no data exchanged between the waves.
+// dot product D_m = <P_m, T_{m+1}> (two wave reductions and a log) — and nothing depends on it.  So PHD_FW waves of the
+// workgroup run the (cheap) recursion redundantly and each takes the dot products of the steps m = wave (mod PHD_FW) only:
+// PHD_FW dot products in flight instead of one, no data exchanged between the waves (eight waves are no faster than four:
+// the redundant recursion is issue capacity the other resident workgroup can use).
 #ifndef PHD_FW
 #define PHD_FW 4
 #endif
