@@ -1,0 +1,393 @@
+// phd_weights.h — particle weights: accumulate, logSumExp normalise, nEff, fixed-point CDF resample (one workgroup).
+// Part of the one translation unit phd_kernels.hip (device code, namespace phd); see that file for the overview.
+#pragma once
+#include "phd_defs.h"
+#include "phd_lane.h"
+#include "phd_math.h"
+#include "phd_lds.h"
+#include "phd_sort.h"
+#include "phd_merge.h"
+#include "phd_predict.h"
+#include "phd_cphd.h"
+
+namespace phd {
+
+// ------------------------------------------------------------------------------------------
+// particle weights: accumulate, logSumExp normalise, nEff, resample (one workgroup)
+// ------------------------------------------------------------------------------------------
+// portable exp for the resampling CDF: IEEE basic operations only (mul, fma, rint, ldexp), so
+// the double it returns is the same on every conforming CPU and GPU (see oracle/scphd_cpu.c).
+// -> det_exp() in phd_detexp.h (shared with phd_eap.hip)
+
+// ------------------------------------------------------------------------------------------
+// Fixed-point resampling CDF (definition and rationale: oracle/scphd_cpu.c, o_resample):
+//   sb = 62 - ceil(log2 N);  q_i = floor(min(det_exp(w_i), 1) * 2^sb);  Q_i = q_0 + ... + q_i (exact)
+//   the reference's "r_j > c_i"  <=>  Q_i < T_j = ceil(r_j * 2^sb)
+// Integer sums are associative: the parallel scan below, the oracle's sequential loop and every rank
+// of a multi-GPU run produce the same Q, hence the same indices.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cdf_scale_bits(int n)
+{
+    int b = 0;
+    while ((1ll << b) < n) ++b;
+    return 62 - b;
+}
+__device__ __forceinline__ u64 cdf_quantise(double p, double scale) { return (u64)floor((p > 1.0 ? 1.0 : p) * scale); }
+
+// in-place inclusive scan of q[0..m) (u64, LDS) by a workgroup of BT threads, plus `carry`; returns
+// the total (carry included).  Thread t owns the contiguous entries [t*per, (t+1)*per).
+template <int BT>
+__device__ __forceinline__ u64 block_scan_u64(u64* q, int m, u64 carry, u64* s_wtot, int tid)
+{
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
+    const int per = (m + BT - 1) / BT;
+    const int lo = tid * per, hi = (lo + per < m) ? lo + per : m;
+    u64 local = 0;
+    for (int e = lo; e < hi; ++e) local += q[e];
+    const u64 incl = wave_incl_scan(local);
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    u64 woff = carry, total = carry;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) {
+        const u64 c = s_wtot[w];
+        if (w < wave) woff += c;
+        total += c;
+    }
+    u64 run = woff + incl - local;
+    for (int e = lo; e < hi; ++e) { run += q[e]; q[e] = run; }
+    __syncthreads();
+    return total;
+}
+
+#define PHD_CDF_CHUNK 2048
+
+template <int PHD_WT>
+__device__ __forceinline__ float block_reduce_w(float v, float* sc, int tid, bool is_max)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float o = xor_lane(v, off);
+        v = is_max ? fmaxf(v, o) : (v + o);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) sc[tid >> 6] = v;
+    __syncthreads();
+    float r = sc[0];
+    for (int w = 1; w < PHD_WT / 64; ++w) r = is_max ? fmaxf(r, sc[w]) : (r + sc[w]);
+    return r;
+}
+
+// mode bits
+enum { W_ACCUMULATE = 1, W_NORMALIZE = 2, W_RESAMPLE_FORCE = 4, W_RESAMPLE_AUTO = 8, W_HAD_MEAS = 16, W_COMMIT = 32 };
+
+template <int PHD_WT>
+__global__ __launch_bounds__(PHD_WT) void phd_weights_kernel(WeightArgs A)
+{
+    __shared__ float sc[PHD_WT / 64];
+    __shared__ int s_flag;
+    __shared__ int s_argmax;
+    __shared__ double s_chunk[PHD_CDF_CHUNK];
+    __shared__ u64 s_wtot[PHD_WT / 64];
+    __shared__ double s_bestv[PHD_WT / 64];
+    __shared__ int s_besti[PHD_WT / 64];
+    const int tid = threadIdx.x;
+    const int n = A.n;          // weights in the vector being normalised (global count for multi-GPU)
+    float* logw = A.logw;       // [n] working / output vector (== logw_in unless the filter is frozen)
+    // 1. accumulate the increments of the last update (src/phdfilter.cu:3741-3744)
+    if ((A.mode & W_ACCUMULATE) || A.logw_in != logw) {
+        const size_t ls = A.in_stride ? (size_t)A.in_stride : 1;
+        for (int i = tid; i < n; i += PHD_WT) {
+            float w = A.logw_in[i * ls];
+            if (A.mode & W_ACCUMULATE) w += A.dlogw[i];
+            logw[i] = w;
+            if (A.raw_out) A.raw_out[i] = w;
+        }
+        __syncthreads();
+    }
+    // 2. logSumExp normalise (src/device_math.cuh:549-558, src/phdfilter.cu:3749-3754)
+    if (A.mode & W_NORMALIZE) {
+        float mx = -FLT_MAX;
+        for (int i = tid; i < n; i += PHD_WT) mx = fmaxf(mx, logw[i]);
+        mx = block_reduce_w<PHD_WT>(mx, sc, tid, true);
+        float s = 0.f;
+        for (int i = tid; i < n; i += PHD_WT) s += expf(logw[i] - mx);
+        s = block_reduce_w<PHD_WT>(s, sc, tid, false);
+        const float lse = safe_log(s) + mx;
+        for (int i = tid; i < n; i += PHD_WT) logw[i] -= lse;
+        __syncthreads();
+    }
+    // 3. nEff = 1 / sum exp(2w) / N (src/main.cpp:1281-1284)
+    float s2 = 0.f;
+    for (int i = tid; i < n; i += PHD_WT) s2 += expf(2 * logw[i]);
+    s2 = block_reduce_w<PHD_WT>(s2, sc, tid, false);
+    const float neff = (float)(1.0 / (double)s2 / (double)n);
+    if (tid == 0) {
+        A.neff_out[0] = neff;
+        int doit = 0;
+        if (A.mode & W_RESAMPLE_FORCE) doit = 1;
+        else if ((A.mode & W_RESAMPLE_AUTO) && (neff <= A.resample_thresh) && (A.mode & W_HAD_MEAS)) doit = 1; // :1286
+        s_flag = doit;
+        A.did_resample[0] = doit;
+    }
+    __syncthreads();
+    const int n_new = A.n_new;
+    if (!s_flag) {
+        for (int j = tid; j < ((A.mode & W_COMMIT) ? n : n_new); j += PHD_WT) {
+            A.idx_out[j] = j;                                                                          // :1292-1296
+            if (A.mode & W_COMMIT) {
+                A.pose_out[j] = A.pose_in[j];
+                A.parent_out[j] = A.parent_in[j];
+            }
+        }
+        return;
+    }
+    // 4. resample (src/main.cpp:453-501).  Thresholds: HEAD's expression r_j = j*interval + u_j*interval
+    //    (:468); with a single uniform (systematic, as src/phdfilter.cu.bak:3279-3327) u_j = u_0.
+    //    CDF in fixed point (see cdf_quantise): chunks of 2048 scanned in LDS, spilled to A.cdf (as u64).
+    u64* cdf = (u64*)A.cdf;   // [n] global scratch
+    u64* qch = (u64*)s_chunk;
+    const double interval = 1.0 / n_new;
+    const int sb = cdf_scale_bits(n);
+    const double scale = ldexp(1.0, sb);
+    double best = -1.0;
+    int besti = 0x7FFFFFFF;
+    u64 carry = 0;
+    for (int c0 = 0; c0 < n; c0 += PHD_CDF_CHUNK) {
+        const int m = (n - c0 < PHD_CDF_CHUNK) ? (n - c0) : PHD_CDF_CHUNK;
+        for (int i = tid; i < m; i += PHD_WT) {
+            const double e = det_exp(logw[c0 + i]);
+            qch[i] = cdf_quantise(e, scale);
+            if (e > best) { best = e; besti = c0 + i; } // strided ascending: keeps the lowest index per lane
+        }
+        __syncthreads();
+        carry = block_scan_u64<PHD_WT>(qch, m, carry, s_wtot, tid);
+        for (int i = tid; i < m; i += PHD_WT) cdf[c0 + i] = qch[i];
+        __syncthreads();
+    }
+    // arg-max of p (first maximum, strict '>'), used by the overflow guard (:475-494)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = xor_lane(best, off);
+            const int oi = xor_lane(besti, off);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if ((tid & 63) == 0) { s_bestv[tid >> 6] = best; s_besti[tid >> 6] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < PHD_WT / 64; ++w)
+                if (s_bestv[w] > best || (s_bestv[w] == best && s_besti[w] < besti)) { best = s_bestv[w]; besti = s_besti[w]; }
+            s_argmax = besti;
+        }
+        __syncthreads();
+    }
+    const u64 ctot = carry;
+    for (int j = tid; j < n_new; j += PHD_WT) {
+        const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
+        const double r = j * interval + u * interval;                                                  // :468
+        const u64 T = (u64)ceil(r * scale);
+        int idx;
+        if (T > ctot) {
+            idx = s_argmax;                                                                            // :475-494
+        } else {
+            // smallest i with Q_i >= T  ==  where the reference's "while (r > c) i++" stops
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] < T) lo = mid + 1; else hi = mid;
+            }
+            idx = lo;
+        }
+        A.idx_out[j] = idx;
+    }
+    if (A.mode & W_COMMIT) {
+        // copy_particles (src/slamtypes.h:313-333): gather poses, compose the map indirection,
+        // weights <- -log(N)
+        const float nlw = (float)(-log((double)A.n_weight_norm));
+        __syncthreads();
+        for (int j = tid; j < n_new; j += PHD_WT) {
+            const int s = A.idx_out[j];
+            A.pose_out[j] = A.pose_in[s];
+            A.parent_out[j] = A.parent_in[s];
+            logw[j] = nlw;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the same routine for n <= BT*R with the weights held in registers from load to commit: one
+// global read of (logw, dlogw), three block reductions, the sequential CDF in LDS, one global
+// write.  n <= PHD_CDF_CHUNK.  Results are a pure function of (inputs, BT): every rank of a
+// multi-GPU run launches the same instantiation on the same gathered vector.
+// ------------------------------------------------------------------------------------------
+// hand-off loads (fused step): data written by OTHER workgroups of the same launch is read with
+// agent-scope (sc1) loads, which bypass this CU's L1 (cdna guide, Guideline 16)
+template <bool HANDOFF>
+__device__ __forceinline__ float ld_f32(const float* p)
+{
+    return HANDOFF ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool HANDOFF>
+__device__ __forceinline__ int ld_i32(const int* p)
+{
+    return HANDOFF ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool HANDOFF>
+__device__ __forceinline__ phd_pose ld_pose(const phd_pose* p)
+{
+    if (!HANDOFF) return *p;
+    const float* f = (const float*)p;
+    phd_pose o;
+    o.px = ld_f32<true>(f + 0); o.py = ld_f32<true>(f + 1); o.ptheta = ld_f32<true>(f + 2);
+    o.vx = ld_f32<true>(f + 3); o.vy = ld_f32<true>(f + 4); o.vtheta = ld_f32<true>(f + 5);
+    return o;
+}
+
+template <int BT, int R, bool HANDOFF>
+__device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn)
+{
+    __shared__ float sc[BT / 64];
+    __shared__ int s_argmax;
+    __shared__ u64 s_wtot[BT / 64];
+    __shared__ double s_bestv[BT / 64];
+    __shared__ int s_besti[BT / 64];
+    const int tid = threadIdx.x;
+    const int n = A.n;
+#define WSTAMP(k) do { if (A.wstamps && tid == 0) A.wstamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    WSTAMP(0);
+    float w[R];
+    // 1. load + accumulate (src/phdfilter.cu:3741-3744)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * BT;
+        w[r] = -FLT_MAX;
+        if (i < n) {
+            w[r] = A.logw_in[A.in_stride ? (size_t)i * A.in_stride : (size_t)i];
+            if (A.mode & W_ACCUMULATE) w[r] += ld_f32<HANDOFF>(&A.dlogw[i]);
+            if (A.raw_out) A.raw_out[i] = w[r];
+        }
+    }
+    // 2. logSumExp normalise (src/device_math.cuh:549-558, src/phdfilter.cu:3749-3754)
+    if (A.mode & W_NORMALIZE) {
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int r = 0; r < R; ++r) mx = fmaxf(mx, w[r]);
+        mx = block_reduce_w<BT>(mx, sc, tid, true);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (tid + r * BT < n) s += expf(w[r] - mx);
+        s = block_reduce_w<BT>(s, sc, tid, false);
+        const float lse = safe_log(s) + mx;
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] -= lse;
+    }
+    WSTAMP(1);
+    // 3. nEff (src/main.cpp:1281-1284)
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (tid + r * BT < n) s2 += expf(2 * w[r]);
+    s2 = block_reduce_w<BT>(s2, sc, tid, false);
+    const float neff = (float)(1.0 / (double)s2 / (double)n);
+    int doit = 0;
+    if (A.mode & W_RESAMPLE_FORCE) doit = 1;
+    else if ((A.mode & W_RESAMPLE_AUTO) && (neff <= A.resample_thresh) && (A.mode & W_HAD_MEAS)) doit = 1; // :1286
+    if (tid == 0) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
+    const int n_new = A.n_new;
+    if (!doit) { // uniform: neff is the same in every thread
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * BT;
+            if (i < n) A.logw[i] = w[r];
+        }
+        for (int j = tid; j < ((A.mode & W_COMMIT) ? n : n_new); j += BT) {
+            A.idx_out[j] = j;                                                                          // :1292-1296
+            if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
+        }
+        return;
+    }
+    // 4. resample: p_i = det_exp(w_i) -> fixed-point CDF (see cdf_quantise) scanned in LDS by the
+    //    whole workgroup; thresholds r_j = j*interval + u*interval (src/main.cpp:468)
+    WSTAMP(2);
+    u64* Q = (u64*)s_dyn; // [n]
+    const int sb = cdf_scale_bits(n);
+    const double scale = ldexp(1.0, sb);
+    double best = -1.0;
+    int besti = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * BT;
+        if (i < n) {
+            const double e = det_exp(w[r]);
+            Q[i] = cdf_quantise(e, scale);
+            if (e > best) { best = e; besti = i; }
+        }
+    }
+    __syncthreads();
+    WSTAMP(3);
+    const u64 ctot = block_scan_u64<BT>(Q, n, 0ull, s_wtot, tid);
+    WSTAMP(4);
+    const double interval = 1.0 / n_new;
+    // the overflow guard (src/main.cpp:475-494) needs the arg-max of p only if the last threshold
+    // exceeds the total mass (weights that do not sum to one): thresholds increase with j
+    {
+        const int jl = n_new - 1;
+        const double ul = (A.n_uniforms == 1) ? A.u0 : A.uniforms[jl];
+        const bool overflow = (u64)ceil((jl * interval + ul * interval) * scale) > ctot;
+        if (overflow) { // uniform
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = xor_lane(best, off);
+                const int oi = xor_lane(besti, off);
+                if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+            }
+            if ((tid & 63) == 0) { s_bestv[tid >> 6] = best; s_besti[tid >> 6] = besti; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int wv = 1; wv < BT / 64; ++wv)
+                    if (s_bestv[wv] > best || (s_bestv[wv] == best && s_besti[wv] < besti)) { best = s_bestv[wv]; besti = s_besti[wv]; }
+                s_argmax = besti;
+            }
+            __syncthreads();
+        }
+    }
+    WSTAMP(5);
+    const float nlw = (float)(-log((double)A.n_weight_norm));
+    for (int j = tid; j < n_new; j += BT) {
+        const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
+        const double r = j * interval + u * interval;                                                  // :468
+        const u64 T = (u64)ceil(r * scale);
+        int idx;
+        if (T > ctot) {
+            idx = s_argmax;
+        } else {
+            int lo = 0, hi = n - 1;
+            while (lo < hi) { // smallest i with Q_i >= T
+                const int mid = (lo + hi) >> 1;
+                if (Q[mid] < T) lo = mid + 1; else hi = mid;
+            }
+            idx = lo;
+        }
+        A.idx_out[j] = idx;
+        if (A.mode & W_COMMIT) { // copy_particles (src/slamtypes.h:313-333)
+            A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[idx]);
+            A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[idx]);
+        }
+    }
+    // weights: -log(N) after a committed resample (slamtypes.h:327), else the normalised values
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * BT;
+        if (i < n) A.logw[i] = (A.mode & W_COMMIT) ? nlw : w[r];
+    }
+    WSTAMP(6);
+}
+
+template <int BT, int R>
+__global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_wdyn[];
+    weights_body<BT, R, false>(A, s_wdyn);
+}
+
+} // namespace phd
