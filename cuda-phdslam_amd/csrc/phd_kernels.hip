@@ -510,7 +510,17 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (last) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
         }
         __syncthreads();
-        if (*flag) weights_body<PHD_T, 2, true>(A.wa, lds_raw);
+        if (*flag) {
+            // up to 512 particles need four waves (the instantiation the staged calls launch, so both paths agree bit for
+            // bit there too); the other four leave first: the routine's barriers then wait for half as many waves
+            if (A.wa.n <= 256 && A.wa.n_new <= A.wa.n) {
+                if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread: same tree, same bits
+            } else if (A.wa.n <= 512 && A.wa.n_new <= A.wa.n) {
+                if (tid < 256) weights_body<256, 2, true>(A.wa, lds_raw);
+            } else {
+                weights_body<PHD_T, 2, true>(A.wa, lds_raw);
+            }
+        }
     }
 }
 
