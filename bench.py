@@ -88,8 +88,9 @@ def cpu_baseline(w, cfg_id, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    # defaults: 2000 timed steps of 24 us are 50 ms — long enough for the clocks to settle (400-step runs read ~2 % lower)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", type=int, default=2, help="workload: 2, 3 (BASELINE.json configs[1], [2]) or 5 (configs[4], CPHD)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()

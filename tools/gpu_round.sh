@@ -23,8 +23,8 @@ python tools/phase_profile.py 2 3 > gpurun_out/phase_$tag.log 2>&1
 cat gpurun_out/e2e_$tag.log
 cd /tmp && export TMPDIR=/tmp
 for cfg in 2 3 5; do
-  st=400; [ $cfg != 2 ] && st=50
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --steps $st --warmup 40 --cpu-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag.log 2>&1
+  st=2000; wu=200; [ $cfg != 2 ] && st=50 && wu=40
+  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --steps $st --warmup $wu --cpu-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag.log 2>&1
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_cfg${cfg}_$tag.csv && head -5 $f
 done
