@@ -16,6 +16,7 @@ namespace phd {
                             // when a CU holds a single particle; throughput-neutral at 4096 particles)
 #endif
 #define PHD_T (64 * PHD_NW)
+static_assert(PHD_NW == 8, "the kernels are written, tested and tuned for 8 waves per workgroup (4 measured slower and is not maintained)");
 #ifndef PHD_MIN_WAVES
 #define PHD_MIN_WAVES 4      // launch bound: waves per SIMD the register allocation must allow
 #endif
