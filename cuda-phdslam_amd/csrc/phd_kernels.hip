@@ -136,8 +136,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // ---- classification + per-feature EKF terms -----------------------------------------------
     float pdw_local = 0.f; // sum_j pd_j w_j (cardinality_predict, :2160)
     float wall_local = 0.f; // CPHD: <1, map>
+    int n_in = 0, n_out0 = 0; // every thread accumulates the same totals: no broadcast (and no extra barrier) afterwards
     {
-        int n_in = 0, n_out0 = 0;
         for (int i0 = 0; i0 < n_map; i0 += PHD_T) {
             const int i = i0 + tid;
             int cls = -1, nd_j = 0;
@@ -203,11 +203,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             n_in += tot_in; n_out0 += tot_out;
             __syncthreads();
         }
-        if (tid == 0) { L.ctr[CTR_NIN] = n_in; L.ctr[CTR_NOUT] = n_out0; }
     }
-    __syncthreads();
-    const int n_in = L.ctr[CTR_NIN];
-    const int n_out0 = L.ctr[CTR_NOUT];
     STAMP(1);
 
     // lane <-> measurement mapping
@@ -334,7 +330,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     }
     {
         float lz_sum, pdw;
-        block_sum2(lz_local, pdw_local, L.red, tid, lz_sum, pdw);
+        block_sum2(lz_local, pdw_local, L.red, tid, lz_sum, pdw, /*scratch_idle=*/true); // the only reduction of the PHD path
         // particle_weighting == 0 (:2260-2263): sum_m log Z_m - (sum_j pd_j w_j + M * birthWeight)
         if (tid == 0) {
             const float dl = lz_sum - (pdw + (float)M * cfg.birthWeight);
@@ -344,7 +340,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         }
     }
     } // !CPHD
-    __syncthreads();
+    // PHD: everything pass 2 reads (log Z_m, the candidate list and its counts) was published by the barriers above
+    if (CPHD) __syncthreads();
 
     STAMP(2);
     // ---- pass 2: final weights; prune before store --------------------------------------------------
@@ -453,8 +450,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             du[i] = L.u[i];
         }
         if (tid == 0) { A.dbg_n[p] = n_surv; A.dbg_nin[p] = n_in; }
+        __syncthreads(); // the merge permutes the planes the copy reads
     }
-    __syncthreads();
 
     // ---- merge ----------------------------------------------------------------------------------------
     const int n_update = n_in * (M + 1) + M;

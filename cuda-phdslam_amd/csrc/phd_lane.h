@@ -155,11 +155,13 @@ __device__ __forceinline__ float block_sum(float v, LDS_T(float)* scratch, int t
 
 // two block sums behind one pair of barriers (each value takes exactly block_sum's tree: same bits);
 // scratch: 2 * PHD_NW floats
-__device__ __forceinline__ void block_sum2(float a, float b, LDS_T(float)* scratch, int tid, float& ra, float& rb)
+// scratch_idle: nobody can still be reading the scratch from an earlier reduction (saves the leading barrier)
+__device__ __forceinline__ void block_sum2(float a, float b, LDS_T(float)* scratch, int tid, float& ra, float& rb,
+                                           bool scratch_idle = false)
 {
     a = wave_sum(a);
     b = wave_sum(b);
-    __syncthreads();
+    if (!scratch_idle) __syncthreads();
     if ((tid & 63) == 0) { scratch[tid >> 6] = a; scratch[PHD_NW + (tid >> 6)] = b; }
     __syncthreads();
     ra = scratch[0]; rb = scratch[PHD_NW];

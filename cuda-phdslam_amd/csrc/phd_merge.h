@@ -288,6 +288,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     STAMP(9);
     // ---- moment matching: the thread that owns a seed, members in ascending position
     const int n_clusters = __popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3);
+    if (tid == 0) atomicMin((int*)&L.ctr[CTR_KOUT], n_clusters);   // the count is min(clusters, first stop): settled by the barrier below
     if (is_seed) {
 #pragma clang fp contract(off)
         const int k = tid;
@@ -352,12 +353,6 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     }
     __syncthreads();
     STAMP(10);
-    if (tid == 0) {
-        int k = L.ctr[CTR_KOUT];
-        if (k > n_clusters) k = n_clusters;
-        L.ctr[CTR_KOUT] = k;
-    }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -653,6 +648,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 
     // ---- moment matching: one lane per cluster, sequential in (weight desc) order ----------------
     // (two trips over the lanes' clusters: first find where the reference's loop would stop)
+    if (tid == 0) atomicMin((int*)&L.ctr[CTR_KOUT], n_clusters);   // as in merge_small
     for (int c0 = 0; c0 < n_clusters; c0 += PHD_T) {
 #pragma clang fp contract(off)
         const int c = c0 + tid;
@@ -701,12 +697,6 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     }
     __syncthreads();
     STAMP(10);
-    if (tid == 0) {
-        int k = L.ctr[CTR_KOUT];
-        if (k > n_clusters) k = n_clusters;
-        L.ctr[CTR_KOUT] = k;
-    }
-    __syncthreads();
 }
 
 } // namespace phd
