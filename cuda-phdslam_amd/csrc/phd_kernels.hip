@@ -486,8 +486,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             h[7] = A.raw_out[p];
         }
         if (status) atomicOr(A.status, status);
-        atomicMax(A.max_surv, L.ctr[CTR_NSURV]);
-        atomicMax(A.max_map, k_out + n_out0);
+        // high-water marks (diagnostics): a plain look first — in steady state no workgroup raises them, and 2 x N
+        // same-address atomics per launch are not free
+        const int hs = L.ctr[CTR_NSURV], hm = k_out + n_out0;
+        if (hs > __hip_atomic_load(A.max_surv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(A.max_surv, hs);
+        if (hm > __hip_atomic_load(A.max_map, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(A.max_map, hm);
     }
     STAMP(11);
     if (STAMPS && CPHD && tid == 0) { // the CPHD block's parts replace the merge-round statistics
