@@ -1533,6 +1533,7 @@ extern "C" int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* m
     if (status_out) *status_out = st;
     if (max_survivors_out) *max_survivors_out = ms;
     if (max_map_out) *max_map_out = mm;
+    if (st & 4) return fail(PHD_ERR_HIP, "fused step: the weights workgroup timed out waiting for the particles' workgroups");
     if (st) return fail(PHD_ERR_CAPACITY, std::string("device capacity overflow:") + ((st & 1) ? " map_capacity" : "") +
                                               ((st & 2) ? " survivor_capacity" : ""));
     return PHD_OK;

@@ -27,7 +27,7 @@ struct DevConfig {
     int labeledMeasurements;
 };
 
-enum { PHD_STATUS_MAP_OVERFLOW = 1u, PHD_STATUS_SURVIVOR_OVERFLOW = 2u };
+enum { PHD_STATUS_MAP_OVERFLOW = 1u, PHD_STATUS_SURVIVOR_OVERFLOW = 2u, PHD_STATUS_TAIL_TIMEOUT = 4u };
 
 // Map slab layout in HBM: particle-major, then 6 SoA planes of `cap` floats:
 //   slab(p) = base + p*6*cap ; planes: 0 weight, 1 mean x, 2 mean y, 3 cov xx, 4 cov xy, 5 cov yy

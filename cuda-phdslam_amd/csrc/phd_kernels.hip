@@ -70,6 +70,36 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
+    if (FUSEW && blockIdx.x == gridDim.x - 1) {
+        // ---- fused step: the weights / nEff / resample routine has a workgroup of its own (the grid is N + 1).
+        // It needs the particles' log-weight increments, predicted poses and map indirection — all known once a
+        // particle's workgroup is past pass 1 — but not the merged maps (resampling moves indices, not maps).  So it
+        // runs WHILE the slower half of every particle's work, the merge, is still going on, and its 4 us vanish
+        // from the step.  Hand-off (cdna guide, Guideline 16): lane 0 of a particle's workgroup makes its hand-off
+        // stores agent-scope, drains them and adds one to the ticket counter; this workgroup polls the counter
+        // (agent scope, bounded) and then reads with sc1 loads.  Only this workgroup ever waits, and for workgroups
+        // that wait for nothing, so the order in which the dispatcher places them does not matter.
+        const unsigned n_wg = gridDim.x - 1;
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_wg) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 24)) { atomicOr(A.status, PHD_STATUS_TAIL_TIMEOUT); break; }   // ~seconds: never in practice
+            }
+            __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // ready for the next launch
+        }
+        __syncthreads();
+        // up to 512 particles need four waves (the instantiation the staged calls launch, so both paths agree bit for
+        // bit there too); the other four leave first: the routine's barriers then wait for half as many waves
+        if (A.wa.n <= 256 && A.wa.n_new <= A.wa.n) {
+            if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread: same tree, same bits
+        } else if (A.wa.n <= 512 && A.wa.n_new <= A.wa.n) {
+            if (tid < 256) weights_body<256, 2, true>(A.wa, lds_raw);
+        } else {
+            weights_body<PHD_T, 2, true>(A.wa, lds_raw);
+        }
+        return;
+    }
     const int p = blockIdx.x;
     const DevConfig& cfg = A.cfg;
     const int cap = A.cap, S_cap = A.S_cap, M = A.M;
@@ -80,24 +110,12 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const int n_map = A.count_in[src];
     phd_pose pose = A.pose[p];
     if (A.do_predict) {
-        // fused vehicle predict: every lane computes the same pose (no broadcast needed), lane 0 stores it
+        // fused vehicle predict: every lane computes the same pose (no broadcast needed); lane 0 stores it after the
+        // first barrier — a live filter predicts in place, and every lane must have read the prior pose by then
         float n_alpha, n_encoder;
         if (A.noise) { n_alpha = A.noise[p].n_alpha; n_encoder = A.noise[p].n_encoder; }
         else draw_noise(A.seed, A.counter, p, cfg, n_alpha, n_encoder);
         pose = predict_pose(pose, A.control, n_alpha, n_encoder, cfg);
-        if (tid == 0) {
-            if (FUSEW) { // handed to the last workgroup: agent-scope (sc1) stores
-                float* po = (float*)&A.pose_out[p];
-                __hip_atomic_store(po + 0, pose.px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 1, pose.py, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 2, pose.ptheta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 3, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 4, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 5, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                A.pose_out[p] = pose;
-            }
-        }
     }
     u64* st = STAMPS ? (A.stamps + (size_t)p * 16) : nullptr;
     u64 cq[5] = {0, 0, 0, 0, 0};
@@ -113,6 +131,24 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         L.zok[m] = (z.label == 0 || !cfg.labeledMeasurements) ? 1u : 0u; // :1913
     }
     __syncthreads();
+    // every thread holds the prior pose and src by now
+    if (tid == 0) {
+        if (A.do_predict) {
+            if (FUSEW) { // handed to the weights workgroup: agent-scope (sc1) stores
+                float* po = (float*)&A.pose_out[p];
+                __hip_atomic_store(po + 0, pose.px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 1, pose.py, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 2, pose.ptheta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 3, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 4, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 5, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                A.pose_out[p] = pose;
+            }
+        }
+        // (fused step) the output slab of particle p is its own again — a hand-off store
+        if (FUSEW && A.parent_reset) __hip_atomic_store(&A.parent_reset[p], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- birth geometry (host loop src/phdfilter.cu:3470-3506): depends only on the pose and the
     //      measurement, so the top lanes of the workgroup — idle while the low lanes classify the map —
@@ -334,8 +370,12 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         // particle_weighting == 0 (:2260-2263): sum_m log Z_m - (sum_j pd_j w_j + M * birthWeight)
         if (tid == 0) {
             const float dl = lz_sum - (pdw + (float)M * cfg.birthWeight);
-            if (FUSEW) __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else A.dlogw[p] = dl;
+            if (FUSEW) {
+                // the last of this particle's hand-off stores (pose: at the top; indirection: after the first barrier)
+                __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else A.dlogw[p] = dl;
             if (!FUSEW && A.raw_out) A.raw_out[p] = A.logw_in[p] + dl;                                // :3741-3744
         }
     }
@@ -471,10 +511,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         for (int pl = 1; pl < 6; ++pl) out[pl * cap + k_out + i] = in[pl * cap + s];
     }
     if (tid == 0) {
-        if (A.parent_reset) { // the output slab of particle p is its own again
-            if (FUSEW) __hip_atomic_store(&A.parent_reset[p], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else A.parent_reset[p] = p;
-        }
+        if (!FUSEW && A.parent_reset) A.parent_reset[p] = p; // the output slab of particle p is its own again
         A.count_out[p] = k_out + n_app;
         if (rows_stride) { // the export row's header (phd_export_kernel's layout)
             // pose and raw weight: re-read what this thread stored earlier rather than keep them live through the merge
@@ -495,32 +532,6 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     STAMP(11);
     if (STAMPS && CPHD && tid == 0) { // the CPHD block's parts replace the merge-round statistics
         st[12] = cq[1] - cq[0]; st[13] = cq[2] - cq[1]; st[14] = cq[3] - cq[2]; st[15] = cq[4] - cq[3];
-    }
-    if (FUSEW) {
-        // ---- fused tail: the workgroup that finishes last runs the weights / nEff / resample routine.
-        // Hand-off (cdna guide, Guideline 16): lane 0 of every workgroup made its hand-off stores
-        // (dlogw, predicted pose, parent reset) agent-scope, drains them, then takes a ticket with an
-        // agent-scope atomic; the workgroup whose ticket is the last one reads them with sc1 loads.
-        lds_i32 flag = L.ctr + CTR_TMP;
-        if (tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == gridDim.x - 1);
-            *flag = last;
-            if (last) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
-        }
-        __syncthreads();
-        if (*flag) {
-            // up to 512 particles need four waves (the instantiation the staged calls launch, so both paths agree bit for
-            // bit there too); the other four leave first: the routine's barriers then wait for half as many waves
-            if (A.wa.n <= 256 && A.wa.n_new <= A.wa.n) {
-                if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread: same tree, same bits
-            } else if (A.wa.n <= 512 && A.wa.n_new <= A.wa.n) {
-                if (tid < 256) weights_body<256, 2, true>(A.wa, lds_raw);
-            } else {
-                weights_body<PHD_T, 2, true>(A.wa, lds_raw);
-            }
-        }
     }
 }
 
@@ -761,7 +772,7 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     }
     if (a.cphd && a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else if (a.cphd) hipLaunchKernelGGL((phd_update_merge_kernel<false, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles + 1), dim3(PHD_T), lds_bytes, st, a); // + the weights workgroup
     else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else hipLaunchKernelGGL((phd_update_merge_kernel<false, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     return hipGetLastError();
