@@ -50,7 +50,7 @@ namespace phd {
 
 // host-visible sizes (declared in phd_device.h)
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total; }
-int update_fuse_max_particles() { return PHD_T * 2; } // weights_body<PHD_T, 2> of the fused step
+int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
 size_t cphd_lds_bytes(int cn_len, int MM)
 {
     u32 off[10];
@@ -95,8 +95,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread: same tree, same bits
         } else if (A.wa.n <= 512 && A.wa.n_new <= A.wa.n) {
             if (tid < 256) weights_body<256, 2, true>(A.wa, lds_raw);
-        } else {
+        } else if (A.wa.n <= 2 * PHD_T) {
             weights_body<PHD_T, 2, true>(A.wa, lds_raw);
+        } else {
+            weights_body<PHD_T, 8, true>(A.wa, lds_raw);                 // up to 4096: what launch_weights runs for these sizes
         }
         return;
     }
@@ -823,6 +825,7 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
     const size_t dyn = (size_t)a.n * 8; // the fixed-point CDF, one u64 per particle
     if (a.n <= 512 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, a);
     else if (a.n <= 2048 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 8>), dim3(1), dim3(256), dyn, st, a);
+    else if (a.n <= 4096 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, a);
     else if (a.n <= 16384 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, a);
     else if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(phd_weights_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
