@@ -795,7 +795,7 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
 // launch's fixed cost is a measurable share of the step.
 static bool can_fuse(const phd_filter* f)
 {
-    return f->fuse_enabled && !f->cphd && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
+    return f->fuse_enabled && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
            (size_t)f->n * 8 <= f->lds_bytes;
 }
 

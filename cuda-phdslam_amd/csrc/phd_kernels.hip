@@ -346,8 +346,14 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                                    in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i);
         }
         if (tid == 0) {
-            A.dlogw[p] = Q.scal[CQ_LY0];                                                             // .bak:2661-2667
-            if (A.raw_out) A.raw_out[p] = A.logw_in[p] + Q.scal[CQ_LY0];
+            if (FUSEW) { // as in the PHD branch below: the last hand-off store, then the ticket
+                __hip_atomic_store(&A.dlogw[p], Q.scal[CQ_LY0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                A.dlogw[p] = Q.scal[CQ_LY0];                                                         // .bak:2661-2667
+                if (A.raw_out) A.raw_out[p] = A.logw_in[p] + Q.scal[CQ_LY0];
+            }
         }
     } else {
     for (int m = tid; m < M; m += PHD_T) {
@@ -758,12 +764,13 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
         // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
-        const void* fns[5] = {(const void*)phd_update_merge_kernel<false, false, false>,
+        const void* fns[6] = {(const void*)phd_update_merge_kernel<false, false, false>,
                               (const void*)phd_update_merge_kernel<true, false, false>,
                               (const void*)phd_update_merge_kernel<false, true, false>,
                               (const void*)phd_update_merge_kernel<false, false, true>,
-                              (const void*)phd_update_merge_kernel<true, false, true>};
-        for (int k = 0; k < 5; ++k) {
+                              (const void*)phd_update_merge_kernel<true, false, true>,
+                              (const void*)phd_update_merge_kernel<false, true, true>};
+        for (int k = 0; k < 6; ++k) {
             hipFuncAttributes fa;
             hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
             if (e != hipSuccess) return e;
@@ -773,6 +780,7 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         attr_set = true;
     }
     if (a.cphd && a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    else if (a.cphd && a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, true>), dim3(n_particles + 1), dim3(PHD_T), lds_bytes, st, a);
     else if (a.cphd) hipLaunchKernelGGL((phd_update_merge_kernel<false, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles + 1), dim3(PHD_T), lds_bytes, st, a); // + the weights workgroup
     else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);

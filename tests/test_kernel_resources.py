@@ -26,7 +26,8 @@ def test_production_kernels_do_not_spill():
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", text, re.S):
         found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
     # <STAMPS, FUSEW, CPHD>: the staged / multi-GPU step, the fused single-GPU step, the CPHD variant
-    for tag in ("ILb0ELb0ELb0E", "ILb0ELb1ELb0E", "ILb0ELb0ELb1E"):
+    # ... and the fused CPHD step
+    for tag in ("ILb0ELb0ELb0E", "ILb0ELb1ELb0E", "ILb0ELb0ELb1E", "ILb0ELb1ELb1E"):
         names = [n for n in found if "phd_update_merge_kernel" + tag in n]
         assert len(names) == 1, (tag, sorted(found))
         vgprs, scratch = found[names[0]]
