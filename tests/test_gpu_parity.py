@@ -366,6 +366,39 @@ def test_step_sequence_matches_staged_calls_and_oracle():
     assert (sizes == r["sizes"]).mean() > 0.8
 
 
+@pytest.mark.parametrize("N", [1, 2, 65, 256, 257, 512, 513, 1024, 1025, 3000, 4096])
+def test_fused_step_equals_staged_calls_across_sizes(N):
+    """the single-launch step (update kernel + the weights workgroup that runs beside the merges) against the staged calls,
+    bit for bit, at particle counts on both sides of every instantiation boundary of the weights routine (256 / 512 /
+    1024 / 4096), over several steps with forced and nEff-triggered resampling"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(N, 6, 4, seed=600 + N % 97, n_meas_sets=4)
+    cfg = P.default_config()
+    import torch
+    dev = torch.device("cuda:0")
+    with make_filter(cfg, w, cap=32, mm=8) as a, make_filter(cfg, w, cap=32, mm=8) as b:
+        for k in range(4):
+            dz = torch.from_numpy(w["z"][k].view(np.uint8).copy()).to(dev)
+            dn = torch.from_numpy(w["noise"][k].copy()).to(dev)
+            torch.cuda.synchronize()
+            force = k % 2 == 0
+            a.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), len(w["z"][k]), w["uniform"][k], force_resample=force)
+            a.sync()
+            b.predict((2.0, 0.05), w["noise"][k])
+            b.update(w["z"][k])
+            if force:
+                b.resample(w["uniform"][k])
+            else:
+                b.resample_if_needed(w["uniform"][k], had_measurements=True)
+            pa, la = a.get_particles()
+            pb, lb = b.get_particles()
+            assert np.array_equal(pa, pb) and np.array_equal(la, lb), (N, k)
+            for x, y in zip(a.get_maps(), b.get_maps()):
+                assert np.array_equal(x, y)
+        a.status()
+        b.status()
+
+
 def test_frozen_steps_restart_from_the_same_snapshot():
     """the bench protocol: frozen steps do not commit, so every iteration does identical work"""
     P, S = pkg(), synthetic()
