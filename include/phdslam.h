@@ -348,7 +348,9 @@ int phd_debug_get_stamps(phd_filter* f, uint64_t* out);
 int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, int32_t* slab_index_out,
                             int capacity, int32_t* n_out);
 int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out);
-/* status word accumulated on the device: bit0 map overflow, bit1 survivor overflow */
+/* status word accumulated on the device: bit0 map overflow, bit1 survivor overflow (-> PHD_ERR_CAPACITY), bit2 the weights
+ * workgroup of a fused step gave up waiting for the particles' workgroups (-> PHD_ERR_HIP; a bounded spin of seconds, never
+ * seen in practice) */
 int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out);
 
 /* ------------------------------------------------------------------------------------
