@@ -13,7 +13,11 @@
 #include <string.h>
 #include <sys/time.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "phdfilter_compat.h"
@@ -101,6 +105,70 @@ int main(int argc, char** argv)
     const int kshot = config.nPredictParticles > 1 ? config.nPredictParticles : 1;
     const int n_max = config.n_particles * (kshot > 1 ? 5 * kshot : 1);
 
+    // The state log of a step (every particle's pose and weight as text: half the loop time at 256 particles, most of it at
+    // 4096) is formatted and written by a few writer threads (one file per step, so they are independent) while the filter
+    // runs the next steps; at most eight steps are in flight.  PHD_DRIVER_SYNC_LOG=1 writes in line, as the reference does.
+    struct LogJob {
+        int step, n_map, n_cur;
+        bool did;
+        phd_pose expected;
+        std::vector<phd_gaussian2d> map;
+        std::vector<float> logw, cn;
+        std::vector<phd_pose> poses;
+        std::vector<int32_t> ridx;
+    };
+    const bool cphd_log = config.filterType == 1;
+    const int max_card = config.maxCardinality;
+    auto write_job = [&](const LogJob& j) -> int {
+        if (log7) {
+            if (cphd_log)
+                return phd_write_state_log7_cphd(out_dir.c_str(), j.step, &j.expected, j.map.data(), j.n_map, j.logw.data(),
+                                                 j.poses.data(), j.ridx.data(), j.n_cur, kshot, j.cn.data(), (int)j.cn.size());
+            return phd_write_state_log7(out_dir.c_str(), j.step, &j.expected, j.map.data(), j.n_map, j.logw.data(), j.poses.data(),
+                                        j.ridx.data(), j.n_cur, max_card, kshot);
+        }
+        if (cphd_log)
+            return phd_write_state_log_cphd(out_dir.c_str(), j.step, &j.expected, j.map.data(), j.n_map, j.logw.data(),
+                                            j.poses.data(), j.n_cur, j.cn.data(), (int)j.cn.size());
+        return phd_write_state_log(out_dir.c_str(), j.step, &j.expected, j.map.data(), j.n_map, j.logw.data(), j.poses.data(),
+                                   j.n_cur, max_card);
+    };
+    const bool sync_log = getenv("PHD_DRIVER_SYNC_LOG") != nullptr;
+    std::mutex log_mu;
+    std::condition_variable log_cv;
+    std::deque<LogJob> log_q;
+    bool log_done = false;
+    int log_err = 0, log_inflight = 0;
+    std::vector<std::thread> log_threads;
+    if (!sync_log)
+        for (int t = 0; t < 4; ++t)
+            log_threads.emplace_back([&]() {
+                for (;;) {
+                    LogJob j;
+                    {
+                        std::unique_lock<std::mutex> lk(log_mu);
+                        log_cv.wait(lk, [&] { return log_done || !log_q.empty(); });
+                        if (log_q.empty()) return;
+                        j = std::move(log_q.front());
+                        log_q.pop_front();
+                        ++log_inflight;
+                    }
+                    const int rc = write_job(j);
+                    {
+                        std::lock_guard<std::mutex> lk(log_mu);
+                        --log_inflight;
+                        if (rc && !log_err) log_err = rc;
+                    }
+                    log_cv.notify_all();
+                }
+            });
+    auto finish_logs = [&]() {
+        if (sync_log) return;
+        { std::lock_guard<std::mutex> lk(log_mu); log_done = true; }
+        log_cv.notify_all();
+        for (auto& th : log_threads) if (th.joinable()) th.join();
+    };
+
     std::vector<phd_pose> poses(n_max);
     std::vector<float> logw(n_max);
     std::vector<int32_t> ridx(n_max);
@@ -112,9 +180,16 @@ int main(int argc, char** argv)
     size_t z_idx = 0, c_idx = 0;
     float last_time = 0, current_time = 0;
     phd_ackerman_control current_control = {0, 0};                                           // :1170-1172
+    // PHD_DRIVER_PROFILE=1: where the loop time goes (inputs + predict, update, state extraction, resample, log writing)
+    const bool prof = getenv("PHD_DRIVER_PROFILE") != nullptr;
+    double acc_t[5] = {0, 0, 0, 0, 0};
+    auto now = []() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; };
+    double tp = 0;
+#define PROF_MARK(k) do { if (prof) { const double t_ = now(); acc_t[k] += t_ - tp; tp = t_; } } while (0)
     for (int n = 0; n < nSteps; ++n) {
         timeval t0, t1;
         gettimeofday(&t0, nullptr);
+        if (prof) tp = now();
         // inputs of this step (:1187-1237)
         const phd_measurement* Z = nullptr;
         int M = 0;
@@ -176,7 +251,10 @@ int main(int argc, char** argv)
                 fclose(pf);
             }
         }
+        PROF_MARK(0);
         if (M > 0) CHK(phd_update(f, Z, M));                                                 // :1260-1272
+        if (prof) { phd_sync(f); }
+        PROF_MARK(1);
         // state extraction (:1274) and log
         n_cur = phd_n_particles(f);
         phd_pose expected;
@@ -214,27 +292,34 @@ int main(int argc, char** argv)
             cn_est.resize((size_t)phd_cardinality_length(f));
             CHK(phd_cardinality_estimate(f, cn_est.data(), nullptr));
         }
+        PROF_MARK(2);
         // nEff test and resampling (:1281-1297)
         int32_t did = 0;
         CHK(phd_resample_if_needed(f, randu01(), M > 0, &did, ridx.data()));
-        const bool cphd = config.filterType == 1;
-        if (log7) {
+        PROF_MARK(3);
+        {
             // weights and poses are those of the step (before resampling); a resample that shrinks a grown
             // (shotgun) particle set yields fewer parent indices than particles: the rest is marked -1
-            if (did) for (int i = phd_n_particles(f); i < n_cur; ++i) ridx[i] = -1;
-            if (cphd)
-                CHK(phd_write_state_log7_cphd(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(),
-                                              ridx.data(), n_cur, kshot, cn_est.data(), (int)cn_est.size()));
-            else
-                CHK(phd_write_state_log7(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(),
-                                         ridx.data(), n_cur, config.maxCardinality, kshot));
-        } else if (cphd) {
-            CHK(phd_write_state_log_cphd(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), n_cur,
-                                         cn_est.data(), (int)cn_est.size()));
-        } else {
-            CHK(phd_write_state_log(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), n_cur,
-                                    config.maxCardinality));
+            if (log7 && did) for (int i = phd_n_particles(f); i < n_cur; ++i) ridx[i] = -1;
+            LogJob j;
+            j.step = n; j.n_map = n_map; j.n_cur = n_cur; j.did = did != 0; j.expected = expected;
+            j.map.assign(map.begin(), map.begin() + n_map);
+            j.logw.assign(logw.begin(), logw.begin() + n_cur);
+            j.poses.assign(poses.begin(), poses.begin() + n_cur);
+            if (log7) j.ridx.assign(ridx.begin(), ridx.begin() + n_cur);
+            if (cphd_log) j.cn = cn_est;
+            if (sync_log) {
+                CHK(write_job(j));
+            } else {
+                std::unique_lock<std::mutex> lk(log_mu);
+                log_cv.wait(lk, [&] { return (int)log_q.size() + log_inflight < 8; });
+                if (log_err) { lk.unlock(); finish_logs(); die("state log"); }
+                log_q.push_back(std::move(j));
+                lk.unlock();
+                log_cv.notify_all();
+            }
         }
+        PROF_MARK(4);
         uint32_t st = 0;
         if (phd_device_status(f, &st, nullptr, nullptr) != PHD_OK) die("capacity check");
         gettimeofday(&t1, nullptr);
@@ -244,6 +329,11 @@ int main(int argc, char** argv)
         if (phd_neff(f, &ne) != PHD_OK) { printf("nan weights detected! exiting...\n"); break; }  // :1307-1311
         printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", n, nSteps, M, n_cur, n_map, did, elapsed);
     }
+    if (prof && nSteps > 0)
+        printf("loop profile (ms per step): inputs+predict %.3f, update %.3f, state extraction %.3f, resample %.3f, log writing %.3f\n",
+               acc_t[0] / nSteps, acc_t[1] / nSteps, acc_t[2] / nSteps, acc_t[3] / nSteps, acc_t[4] / nSteps);
+    finish_logs();
+    if (log_err) die("state log");
     phd_destroy(f);
     return 0;
 }

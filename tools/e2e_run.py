@@ -55,6 +55,9 @@ def main():
     if r.returncode:
         print(r.stdout[-2000:], r.stderr[-2000:])
         raise SystemExit(r.returncode)
+    for line in r.stdout.splitlines():
+        if line.startswith("loop profile"):               # PHD_DRIVER_PROFILE=1
+            print(line)
     t = np.loadtxt(os.path.join(out, "loopTime.log"))
     L = P._lib.lib()
     res = np.zeros(5, np.float64)
