@@ -118,6 +118,7 @@ SYMBOLS = {
     "phd_global_resample_begin": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "phd_step_local_dev": (_i, [_vp, Control, _vp, _vp, _i]),
     "phd_global_resample_end": (_i, [_vp, _vp]),
+    "phd_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "phd_export_shard_dev": (_i, [_vp, _vp, _vp]),
     "phd_step_local_rows_dev": (_i, [_vp, Control, _vp, _vp, _i, _vp, _vp]),
     "phd_global_resample_gathered": (_i, [_vp, _vp, _d, _i, _i, _i, _vp]),

@@ -259,8 +259,8 @@ int main(int argc, char** argv)
         n_cur = phd_n_particles(f);
         phd_pose expected;
         int32_t n_map = 0, who = 0;
-        CHK(phd_expected_pose(f, &expected));
-        CHK(phd_map_estimate(f, map.data(), (int)map.size(), &n_map, &who));
+        // weighted-mean pose, arg-max particle's map, all poses and weights: one call, one synchronisation
+        CHK(phd_state_snapshot(f, &expected, map.data(), (int)map.size(), &n_map, &who, poses.data(), logw.data()));
         if ((config.mapEstimate & 2) && n_cur > 1) {
             // expected-a-posteriori map (recoverSlamState, :363-379).  map_estimate = 2: it is the map of the log;
             // map_estimate = 3 (both): the MAP map stays in the log, the EAP map goes to expected_mapNNNNN.log
@@ -287,7 +287,6 @@ int main(int argc, char** argv)
                 n_map = n_eap;
             }
         }
-        CHK(phd_get_particles(f, poses.data(), logw.data()));
         if (config.filterType == 1) {                                                        // cn_estimate (:360)
             cn_est.resize((size_t)phd_cardinality_length(f));
             CHK(phd_cardinality_estimate(f, cn_est.data(), nullptr));

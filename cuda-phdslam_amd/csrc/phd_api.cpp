@@ -929,6 +929,35 @@ extern "C" int phd_map_estimate(phd_filter* f, phd_gaussian2d* out, int capacity
     return phd_get_map(f, am, out, capacity, n_out);
 }
 
+// recoverSlamState in one call and ONE host synchronisation (phd_expected_pose + phd_map_estimate + phd_get_particles make
+// three): the arg-max particle's map is unpacked by a kernel that takes the index from device memory
+extern "C" int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gaussian2d* map_out, int capacity, int32_t* n_map_out,
+                                  int32_t* particle_out, phd_pose* poses_out, float* log_weights_out)
+{
+    CHECK_F(f);
+    if (!expected_out || !map_out || !n_map_out) return fail(PHD_ERR_INVALID_ARG, "phd_state_snapshot: null output");
+    int rc = ensure_concat(f, (size_t)f->cap);
+    if (rc) return rc;
+    int am = -1, nm = 0;
+    HIPCHK(launch_state(f->pose[f->pose_cur], f->logw, f->n, f->state_pose, f->state_argmax, f->stream));
+    HIPCHK(launch_unpack_one(f->maps[f->cur], f->parent[f->pcur], f->counts[f->cur], f->state_argmax, f->d_concat, f->cap,
+                             f->d_tmp_int, f->stream));
+    HIPCHK(hipMemcpyAsync(expected_out, f->state_pose, sizeof(phd_pose), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(&am, f->state_argmax, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(&nm, f->d_tmp_int, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    const int ncopy = std::min(capacity, f->cap);
+    if (ncopy > 0)
+        HIPCHK(hipMemcpyAsync(map_out, f->d_concat, (size_t)ncopy * sizeof(phd_gaussian2d), hipMemcpyDeviceToHost, f->stream));
+    if (poses_out) HIPCHK(hipMemcpyAsync(poses_out, f->pose[f->pose_cur], f->n * sizeof(phd_pose), hipMemcpyDeviceToHost, f->stream));
+    if (log_weights_out) HIPCHK(hipMemcpyAsync(log_weights_out, f->logw, f->n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (am < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
+    *n_map_out = nm;
+    if (particle_out) *particle_out = am;
+    if (nm > capacity) return fail(PHD_ERR_CAPACITY, "phd_state_snapshot: map larger than the output buffer");
+    return PHD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // expected-a-posteriori map (config.mapEstimate & 2): computeExpectedMap, src/main.cpp:290-316,
 // with reduceGaussianMixture (src/gm_reduce.cpp:57-134) run on the device (phd_eap.hip)

@@ -127,6 +127,8 @@ hipError_t launch_pack_maps(const phd_gaussian2d* concat, const int* offsets, co
                             int n, hipStream_t st);
 hipError_t launch_unpack_maps(const float* slabs, const int* parent, const int* offsets, const int* counts,
                               phd_gaussian2d* concat, int cap, int n, hipStream_t st);
+hipError_t launch_unpack_one(const float* slabs, const int* parent, const int* counts, const int* which, phd_gaussian2d* out,
+                             int cap, int* n_out, hipStream_t st);
 hipError_t launch_state(const phd_pose* poses, const float* logw, int n, float* pose_out, int* argmax_out,
                         hipStream_t st);
 hipError_t launch_export(const float* slabs, const int* counts, const int* parent, const phd_pose* poses,

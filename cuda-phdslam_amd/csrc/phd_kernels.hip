@@ -854,6 +854,37 @@ hipError_t launch_unpack_maps(const float* slabs, const int* parent, const int* 
     return hipGetLastError();
 }
 
+// one particle's map, the particle index taken from device memory (the arg-max of phd_state_kernel): AoS out, count out
+__global__ void phd_unpack_one_kernel(const float* __restrict__ slabs, const int* __restrict__ parent,
+                                      const int* __restrict__ counts, const int* __restrict__ which,
+                                      phd_gaussian2d* __restrict__ out, int cap, int* __restrict__ n_out)
+{
+    const int p = which[0];
+    if (p < 0) { if (threadIdx.x == 0) n_out[0] = 0; return; }
+    const int src = parent ? parent[p] : p;
+    const int n = counts[src];
+    const float* s = slabs + (size_t)src * 6 * cap;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        phd_gaussian2d v;
+        v.weight = s[0 * cap + i];
+        v.mean[0] = s[1 * cap + i];
+        v.mean[1] = s[2 * cap + i];
+        v.cov[0] = s[3 * cap + i];
+        v.cov[1] = s[4 * cap + i];
+        v.cov[2] = s[4 * cap + i];
+        v.cov[3] = s[5 * cap + i];
+        out[i] = v;
+    }
+    if (threadIdx.x == 0) n_out[0] = n;
+}
+
+hipError_t launch_unpack_one(const float* slabs, const int* parent, const int* counts, const int* which, phd_gaussian2d* out,
+                             int cap, int* n_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(phd_unpack_one_kernel, dim3(1), dim3(256), 0, st, slabs, parent, counts, which, out, cap, n_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_state(const phd_pose* poses, const float* logw, int n, float* pose_out, int* argmax_out,
                         hipStream_t st)
 {

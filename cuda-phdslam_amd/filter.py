@@ -168,6 +168,18 @@ class PhdFilter:
         check(lib().phd_map_estimate(self._h, ptr(out), self.cap, C.byref(n), C.byref(who)), "phd_map_estimate")
         return out[:n.value].copy(), who.value
 
+    def state_snapshot(self):
+        """recoverSlamState in one call and one host synchronisation: (expected pose, arg-max particle's map, its index,
+        all poses, all log-weights) — expected_pose() + map_estimate() + get_particles() in a single round trip"""
+        e = np.zeros(1, POSE)
+        out = np.zeros(self.cap, GAUSSIAN)
+        n, who = C.c_int32(0), C.c_int32(0)
+        poses = np.zeros(self.n, POSE)
+        lw = np.zeros(self.n, np.float32)
+        check(lib().phd_state_snapshot(self._h, ptr(e), ptr(out), self.cap, C.byref(n), C.byref(who), ptr(poses), ptr(lw)),
+              "phd_state_snapshot")
+        return e[0], out[:n.value].copy(), who.value, poses, lw
+
     def expected_map(self, capacity=None):
         """EAP map (config map_estimate & 2): computeExpectedMap, src/main.cpp:290-316, on the device"""
         capacity = int(capacity or 4 * self.cap)

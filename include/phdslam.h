@@ -352,6 +352,11 @@ int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out);
  * workgroup of a fused step gave up waiting for the particles' workgroups (-> PHD_ERR_HIP; a bounded spin of seconds, never
  * seen in practice) */
 int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out);
+/* recoverSlamState (src/main.cpp:318-361) in one call and one host synchronisation: weighted-mean pose, the map of the
+ * arg-max particle (map_out[capacity], *n_map_out entries, *particle_out its index), and optionally every particle's pose and
+ * log-weight — what phd_expected_pose + phd_map_estimate + phd_get_particles return in three round trips */
+int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gaussian2d* map_out, int capacity, int32_t* n_map_out,
+                       int32_t* particle_out, phd_pose* poses_out, float* log_weights_out);
 
 /* ------------------------------------------------------------------------------------
  * Host-side boundary helpers (no device needed): config file, data files, log writer

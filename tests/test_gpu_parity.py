@@ -322,6 +322,27 @@ def test_state_estimate():
     assert np.array_equal(m, w["maps"][who])
 
 
+def test_state_snapshot_equals_the_three_calls():
+    """phd_state_snapshot (one synchronisation; the driver's state extraction) == expected_pose + map_estimate + get_particles,
+    also after an update and a resample (map indirection in place)"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(300, 12, 6, seed=44)
+    with make_filter(P.default_config(), w) as f:
+        for stage in range(3):
+            if stage == 1:
+                f.predict((2.0, 0.05), w["noise"][0])
+                f.update(w["z"][0])
+            if stage == 2:
+                f.resample(0.41)
+                f.update(w["z"][0])
+            e, m, who, poses, lw = f.state_snapshot()
+            e2 = f.expected_pose()
+            m2, who2 = f.map_estimate()
+            p2, l2 = f.get_particles()
+            assert e.tobytes() == e2.tobytes() and who == who2 and np.array_equal(m, m2)
+            assert np.array_equal(poses, p2) and np.array_equal(lw, l2)
+
+
 # ----------------------------------------------------------------------------------------------
 # whole steps
 # ----------------------------------------------------------------------------------------------
