@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — filter-update steps/sec of the GM-PHD-SLAM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3]
+    python bench.py --gpus N --steps K --warmup W
 
 One "step" = one full filter step on one batch of synthetic input, inputs resident in HBM:
 predict -> update (in-range split, births, EKF, PHD weights) -> prune -> merge -> weight
@@ -9,17 +9,32 @@ normalise -> nEff -> resample (forced every step).  Steady-state
 filter is frozen, so every timed iteration restarts from the same device-resident snapshot and
 does identical work.
 
-N = 1: BASELINE.json configs[1] (256 particles x 64 Gaussians x 32 measurements).
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank holds a
-256-particle shard of one 256*N-particle filter; per step one RCCL all-gather of the
-un-normalised log-weights, the identical global normalise/resample on every rank and the
-migration of particles whose parent lives on another rank.  `value` counts shard-steps: N ranks x
-K steps / time.
+N = 1: the headline is the LARGEST single-GPU configuration, BASELINE.json configs[2]
+(4096 particles x 256 Gaussians x 64 measurements); configs[1] (256 x 64 x 32) and configs[4] (the CPHD
+variant of 4096 x 256 x 64) ride along as `secondary` entries of the same JSON line (`--config 2|3|5`
+picks another headline, `--no-secondary` drops the riders).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fused update+prune+merge
-kernel, algorithmic bytes of SURVEY.md §8d per launch / its average duration from HIP events on
-the filter's stream) and `cpu_baseline` (the CPU oracle timed on the host cores on the same
-workload, rank 0 at N = 1 only).
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] — ONE filter of
+16384 particles x 256 x 64 sharded N ways (strong scaling: rank r owns particles [r n, (r+1) n), n = 16384 / N,
+of the same generated set; every rank sees the same measurement set, control and resampling uniform).  Per step:
+local predict + update + merge (no communication) -> RCCL all-gather of the raw log-weights -> identical global
+normalise / resample on every rank -> migration of the particles whose parent lives on another rank
+(all_to_all over xGMI).  `value` = filter steps/s (K / time, not multiplied by N).  The round-1 weak-scaling
+workload (256 x 64 x 32 per rank) is kept as a labelled secondary.
+
+Clock pre-roll: before the W counted warm-up steps the same step runs, un-counted, for >= 200 ms
+(`preroll_steps` in the output), so that a 25-step run reads the clocks a long run reads.
+
+Prints ONE JSON line (rank 0) with
+  `roofline`      the contract figure of SURVEY.md §8d: algorithmic bytes per launch of the dominant kernel / its
+                  average duration (HIP events on the filter's stream), against the 8 TB/s HBM peak.  The kernel
+                  never materialises the update components, so this is bookkeeping, not efficiency — `traffic`
+                  (PMC, with its source file and date) is what actually crosses the HBM interface;
+  `roofline_valu` what bounds the kernel in fact: VALU issue.  Issue fraction from the SQ counter pass kept under
+                  profiles/ (source and date labelled), algorithmic flops of §8d / kernel time against the
+                  157.3 TFLOP/s fp32 vector peak;
+  `cpu_baseline`  the CPU oracle timed on the host cores on a bounded sample of the same workload (rank 0, N = 1):
+                  CPU model, single-thread and best-thread rates.
 """
 import argparse
 import importlib
@@ -33,11 +48,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide: peak FP32 (vector)
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+PREROLL_MS = 200.0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(w, cfg_id, budget_s):
-    """the CPU oracle (a port of the reference algorithm: kind "port") on the host cores"""
+    """the CPU oracle (a port of the reference algorithm: kind "port") on the host cores: single thread and the best
+    thread count of 1..visible"""
     from oracle import oracle as O
     N, G, M = w["N"], w["G"], w["M"]
     cap = 2 * G
@@ -58,41 +87,432 @@ def cpu_baseline(w, cfg_id, budget_s):
         return O.step(w["poses"][:n], lw, maps, w["sizes"][:n], cap, 0.05, 2.0, w["noise"][0][:n], w["z"][0], ocfg,
                       w["uniform"][0], True, n_threads=threads)
 
+    def rate(threads, min_s, min_k):
+        one(threads)
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            one(threads)
+            k += 1
+            el = time.perf_counter() - t0
+            if k >= min_k and el >= min_s:
+                return k / el * (n / N), k, el   # a slice of n particles is n/N of a step
+
+    t_start = time.perf_counter()
+    single, k1, el1 = rate(1, 0.15 * budget_s, 1)
     # the visible core count can exceed what the container may actually use (CPU quota): pick the
     # thread count that is fastest on this host and report THAT as `cores`
-    best_t, best_rate = 1, 0.0
-    t = 1
+    best_t, best_rate = 1, single
+    t = 2
     while t <= avail:
-        one(t)
-        t0 = time.perf_counter()
-        one(t)
-        rate = 1.0 / (time.perf_counter() - t0)
-        if rate > best_rate:
-            best_t, best_rate = t, rate
+        r, _, _ = rate(t, 0.0, 1)
+        if r > best_rate:
+            best_t, best_rate = t, r
         t *= 2
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        one(best_t)
-        k += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or (k >= 5 and el > 0.5 * budget_s):
-            break
-    steps_per_s = k / el * (n / N)  # a slice of n particles is n/N of a step
-    return {"value": steps_per_s, "unit": "steps/s", "cores": best_t, "kind": "port",
+    left = max(0.2 * budget_s, budget_s - (time.perf_counter() - t_start))
+    best, kb, elb = rate(best_t, left, 3) if best_t > 1 else (single, k1, el1)
+    return {"value": best, "unit": "steps/s", "cores": best_t, "kind": "port",
+            "cpu_model": cpu_model(), "cores_visible": avail,
+            "single_thread_steps_per_s": single, "best_thread_steps_per_s": best,
             "sample": "%d steps of the oracle (oracle/scphd_cpu.c + cphd_cpu.c, -O3 -march=native, OpenMP over particles, %d threads "
-                      "— the fastest of 1..%d visible) on %d of the %d particles of config %d (%dx%dx%d), %.1f s"
-                      % (k, best_t, avail, n, N, cfg_id, N, G, M, el)}
+                      "— the fastest of 1..%d visible; single thread: %d steps in %.1f s) on %d of the %d particles of config %d "
+                      "(%dx%dx%d), %.1f s" % (kb, best_t, avail, k1, el1, n, N, cfg_id, N, G, M, elb)}
+
+
+def algorithmic_flops(N, G, M):
+    """SURVEY.md §8(d), secondary figure: sum_p [150 G + 45 G M + 30 M]"""
+    return N * (150.0 * G + 45.0 * G * M + 30.0 * M)
+
+
+def load_profile_json(name):
+    """a PMC summary kept under profiles/ (tools/pmc_*.sh wrote it on the GPU box): (dict, source label) or (None, None)"""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, None
+    label = "profiles/%s (build %s, recorded %s)" % (name, d.get("build", "?"), d.get("date", "?"))
+    return d, label
+
+
+def timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms, agree=None):
+    """pre-roll (un-counted, >= preroll_ms of the same step), W warm-up steps, then K timed steps bracketed by sync()
+    -> (elapsed s, gpu region ms, p10/p50/p90 ms per step from asynchronous chunk events, preroll steps).
+    agree(x): max of x over the ranks (N > 1: every rank must run the same number of pre-roll steps)"""
+    preroll = 0
+    if preroll_ms > 0:
+        # 25 steps timed, then as many more as the remaining pre-roll time needs (one decision, agreed by all ranks)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(25):
+            step()
+        sync()
+        dt = (time.perf_counter() - t0) * 1e3
+        if agree is not None:
+            dt = agree(dt)
+        more = int(min(100000, max(0.0, (preroll_ms - dt) / max(dt / 25, 1e-4))))
+        for _ in range(more):
+            step()
+        sync()
+        preroll = 25 + more
+    for _ in range(warmup):
+        step()
+    sync()
+    # HIP events on the stream the kernels run on (torch's current stream IS the filter's stream), bracketing
+    # the timed region: GPU time of the K steps without the per-launch event pairs of the separate pass
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    chunk = max(1, steps // 20)            # an (asynchronous) event every `chunk` steps: the spread of the step time
+    marks = []
+    t0 = time.perf_counter()
+    ev0.record(ts)
+    for k in range(steps):
+        step()
+        if (k + 1) % chunk == 0 and k + 1 < steps:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(ts)
+            marks.append(e)
+    ev1.record(ts)
+    sync()
+    elapsed = time.perf_counter() - t0
+    gpu_region_ms = ev0.elapsed_time(ev1)
+    edges = [ev0] + marks + [ev1]
+    counts = [chunk] * len(marks) + [steps - chunk * len(marks)]
+    per_step = sorted(a.elapsed_time(b) / c for a, b, c in zip(edges[:-1], edges[1:], counts) if c > 0)
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
+    return elapsed, gpu_region_ms, [pct(0.1), pct(0.5), pct(0.9)], preroll
+
+
+def make_filter(P, torch, cfg_id, n_local, G, M, n_global, offset, dev, local_rank):
+    cfg = P.default_config(n_particles=n_global)
+    if cfg_id == 5:                                           # BASELINE.json configs[4]: the CPHD variant
+        cfg.filterType = 1
+        cfg.maxCardinality = 255
+    # one stream for everything: the filter's kernels and (N > 1) the RCCL collectives torch enqueues
+    ts = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(ts)
+    f = P.PhdFilter(cfg, n_particles=n_local, map_capacity=2 * G, max_measurements=M, device=local_rank, stream=ts.cuda_stream,
+                    global_particles=n_global, global_offset=offset)
+    return f, ts
+
+
+def roofline_entries(P, S, cfg_id, N, G, M, ker_ms, pair_ms, gpu_ms_per_step, copy_gbs, other, with_traffic=True):
+    b_step = S.algorithmic_bytes(N, G, M)               # per launch of the update+merge kernel (one shard)
+    b_min = N * (28 * G + 28 * G + 32)                   # compulsory traffic (SURVEY.md §8d)
+    if cfg_id == 5:                                      # CPHD: + one cardinality row read and written per particle
+        b_step += N * 2 * 4 * 256
+        b_min += N * 2 * 4 * 256
+    ker_s = ker_ms * 1e-3
+    achieved = b_step / ker_s / 1e9 if ker_s > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh writes the summary on
+    # the GPU box; rocprofv3 cannot run inside the bench) — null if this configuration was not profiled.
+    # NOT measured in this run: the source file, build tag and date are printed beside it.
+    traffic, traffic_src = None, None
+    if with_traffic:
+        tj, traffic_src = load_profile_json("pmc_traffic_cfg%d.json" % cfg_id)
+        if tj:
+            traffic = tj.get("hbm_bytes_per_launch")
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "note": "contract figure (SURVEY.md 8d): ALGORITHMIC bytes / kernel time.  The fused kernel prunes before it "
+                    "stores, so the update components never reach HBM; the kernel is VALU-issue-bound, see roofline_valu",
+            "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
+            "kernel_avg_us_event_pairs": 1e3 * pair_ms, "gpu_region_ms_per_step": gpu_ms_per_step,
+            "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
+            "measured_hbm_gbs": (traffic / ker_s / 1e9) if (traffic and ker_s > 0) else None,
+            "device_copy_ceiling_gbs": copy_gbs,
+            "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
+            "other_kernels_avg_us": other}
+    flops = algorithmic_flops(N, G, M)
+    tfl = flops / ker_s / 1e12 if ker_s > 0 else 0.0
+    sq, sq_src = load_profile_json("pmc_sq_cfg%d.json" % cfg_id)
+    valu = {"bound": "valu-issue", "achieved": None, "peak": 1.0, "unit": "fraction of VALU issue cycles", "frac": None,
+            "source": sq_src, "algorithmic_flops_per_launch": flops, "algorithmic_tflops": tfl,
+            "frac_of_fp32_vector_peak": tfl / FP32_VECTOR_PEAK_TFLOPS,
+            "fp32_vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS}
+    if sq:
+        valu["achieved"] = valu["frac"] = sq.get("valu_issue_fraction")
+        valu["counters_per_launch"] = {k: sq[k] for k in sq if k.startswith("SQ_") or k.startswith("GRBM_")}
+        valu["kernel_avg_us_in_counter_pass"] = sq.get("kernel_avg_us")
+    return roof, valu
+
+
+def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank, preroll_ms=PREROLL_MS, extras=True):
+    """N = 1: one configuration, fused single-launch step.  -> result dict"""
+    c = S.CONFIGS[cfg_id]
+    N, G, M = c["N"], c["G"], c["M"]
+    w = S.make_workload(N, G, M, seed=0x5EED0000 + cfg_id, clustered=c["clustered"])
+    f, ts = make_filter(P, torch, cfg_id, N, G, M, N, 0, dev, local_rank)
+    f.set_particles(w["poses"], w["logw"])
+    f.set_maps(w["maps"], w["sizes"])
+    d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    d_noise = torch.from_numpy(w["noise"][0].copy()).to(dev)
+    control = (2.0, 0.05)
+    u = float(np.random.default_rng(0x5EED0000 + cfg_id).random())
+    torch.cuda.synchronize()
+    f.set_frozen(True)  # steady state: no step commits, every iteration restarts from the same snapshot
+
+    def step():
+        f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=True)
+
+    def sync():
+        f.sync()
+        torch.cuda.synchronize()
+
+    elapsed, gpu_region_ms, pcts, preroll = timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms)
+    st = f.status()
+
+    # kernel durations from HIP events on the filter's stream (separate pass: events perturb the timed loop)
+    k_ev = min(steps, 100)
+    f.timing_reset()
+    f.timing(True)
+    for _ in range(k_ev):
+        step()
+    sync()
+    ms, cnt = f.timing_read()
+    f.timing(False)
+    avg_ms = ms / np.maximum(cnt, 1)
+
+    # the same loop with the reference's trigger instead of a forced resample (nEff <= resample_threshold)
+    unforced = None
+    if extras or cpu_seconds > 0:
+        k_un = min(steps, 200)
+        for _ in range(5):
+            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
+        sync()
+        tu = time.perf_counter()
+        for _ in range(k_un):
+            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
+        sync()
+        unforced = k_un / (time.perf_counter() - tu)
+
+    # stage breakdown (SURVEY.md §8d) from the diagnostic instantiation of the update kernel: in-kernel s_memrealtime
+    # stamps per workgroup (shares of the per-particle critical path; the stamped kernel is not the timed one)
+    stages = None
+    if extras and cfg_id != 5:
+        names = ["classify+ekf", "normalisers", "nondetect_emit", "detect_emit", "finalise+births", "sort", "merge_rounds",
+                 "sort_by_seed", "segments", "moment_matching", "append"]
+        f.debug(2)
+        for _ in range(2):
+            f.update(w["z"][0])
+        f.sync()
+        st_ = f.stamps().astype(np.int64)
+        dd = np.diff(st_[:, :12], axis=1) * 0.01
+        stages = {nm: float(dd[:, k].mean()) for k, nm in enumerate(names)}
+        stages["workgroup_total"] = float(((st_[:, 11] - st_[:, 0]) * 0.01).mean())
+        f.debug(0)
+
+    # in-run HBM ceiling (SURVEY.md §8d): a device-to-device copy of 1 GiB on the same stream, read + write bytes
+    copy_gbs = None
+    if extras:
+        src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst_t = torch.empty_like(src_t)
+        dst_t.copy_(src_t)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(ts)
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        c1.record(ts)
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src_t.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src_t, dst_t
+
+    pair_ms = avg_ms[P._lib.K_UPDATE_MERGE]              # event pair around every launch (separate pass)
+    one_launch_per_step = cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0
+    # when the whole step is ONE launch of the dominant kernel (fused step), the events bracketing the timed
+    # region give its average duration directly (launch-to-launch), free of the pair's marker packets
+    ker_ms = gpu_region_ms / steps if one_launch_per_step else pair_ms
+    other = {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT], "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}
+    roof, valu = roofline_entries(P, S, cfg_id, N, G, M, ker_ms, pair_ms, gpu_region_ms / steps, copy_gbs, other)
+    res = {
+        "value": steps / elapsed,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "ms_per_step_gpu_p10_p50_p90": pcts,
+        "preroll_steps": preroll,
+        "config": {"workload": "BASELINE.json configs[%d]: %d particles x %d Gaussians/particle x %d meas/step%s, Ackerman motion, "
+                               "forced resample every step, frozen snapshot, whole step = ONE launch" %
+                               (cfg_id - 1, N, G, M, " (CPHD variant, max_cardinality 255)" if cfg_id == 5 else ""),
+                   "particles_total": N, "gaussians_per_particle": G, "measurements_per_step": M,
+                   "one_launch_per_step": bool(one_launch_per_step),
+                   "max_survivors": st["max_survivors"], "max_map": st["max_map"],
+                   "steps_per_s_unforced_resample": unforced},
+        "stages_us_per_workgroup": stages,
+        "roofline": roof,
+        "roofline_valu": valu,
+        "cpu_baseline": cpu_baseline(w, cfg_id, cpu_seconds) if cpu_seconds > 0 else None,
+    }
+    f.close()
+    return res
+
+
+def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, local_rank, rank, world, share, one_rank,
+                same_set=True, preroll_ms=PREROLL_MS):
+    """N > 1: ONE filter of n_global particles sharded over the ranks.  same_set: every rank generates the SAME n_global
+    particles and takes its slice (configs[3]); False: the round-1 weak-scaling workload (n_global / world fresh particles
+    per rank, same measurement set)."""
+    c = S.CONFIGS[cfg_id]
+    G, M = c["G"], c["M"]
+    off, n = D.shard_range(n_global, world, rank)
+    seed = 0x5EED0000 + cfg_id
+    if same_set:
+        wf = S.make_workload(n_global, G, M, seed=seed, clustered=c["clustered"])
+        w = {k: (wf[k][off:off + n] if k in ("poses", "logw", "maps", "sizes") else wf[k]) for k in wf}
+        w["noise"] = wf["noise"][:, off:off + n]
+        lw = w["logw"]                                   # the global set is normalised as generated
+        del wf
+    else:
+        w = S.make_workload(n, G, M, seed=seed + 1000 * rank, clustered=c["clustered"])
+        shared = S.make_workload(1, G, M, seed=seed, clustered=c["clustered"])
+        w["z"] = shared["z"]                             # one filter has one scan: the same measurement set on every rank
+        lw = w["logw"] - np.float32(np.log(world))       # the global set sums to one
+    f, ts = make_filter(P, torch, cfg_id, n, G, M, n_global, off, dev, local_rank)
+    f.set_particles(w["poses"], np.ascontiguousarray(lw, np.float32))
+    f.set_maps(w["maps"], w["sizes"])
+    d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    d_noise = torch.from_numpy(np.ascontiguousarray(w["noise"][0])).to(dev)
+    control = (2.0, 0.05)
+    # the resampling uniform is one draw shared by all ranks (every rank must compute the same global indices)
+    u = float(np.random.default_rng(seed).random())
+    torch.cuda.synchronize()
+    f.set_frozen(True)
+    shard = D.GpuShard(f, n_global)
+    sf = D.ShardedFilter(shard, n_global, rank, world)
+    sf.collectives = True
+    if os.environ.get("PHD_BENCH_EXCHANGE") == "alltoall":
+        sf.gathered_limit = 0
+    gathered = sf.gathered()                    # small shards: whole-shard all-gather; else all-to-all of the migrants
+
+    def step():
+        if gathered:
+            # one launch for predict + update + prune + merge, written straight into the export rows (raw weights
+            # in the row headers) -> ONE fixed-size RCCL all-gather of the shards -> global normalise + resample
+            # indices + import of this shard's parents: nothing waits for the host
+            rows = shard.step_local_rows(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+            sf.resample_gathered(u, weights_in_rows=True, want_idx=False, rows=rows)
+        else:
+            # one launch for predict + update + prune + merge + raw weights, then
+            shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+            # RCCL all-gather of the raw weights, one launch for the global normalise + resample indices (indices
+            # to the host for the plan), RCCL all-to-all of the migrating particles, commit
+            allw = sf.gather_logweights()
+            sf.resample(u, all_raw_logw=allw)   # the bench forces the resample: no host round trip for nEff
+
+    def sync():
+        f.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def agree(x):
+        t_ = torch.tensor([x], dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
+    elapsed, gpu_region_ms, pcts, preroll = timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms, agree)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    st = f.status()
+
+    k_ev = min(steps, 50)
+    f.timing_reset()
+    f.timing(True)
+    for _ in range(k_ev):
+        step()
+    sync()
+    ms, cnt = f.timing_read()
+    f.timing(False)
+    avg_ms = ms / np.maximum(cnt, 1)
+
+    # where a step's time goes (SURVEY.md §8e: "report resample-with-migration time separately") — the phases
+    # run back to back with a device synchronisation after each, so the parts add up to more than a pipelined step
+    k_bd = min(steps, 30)
+
+    def tick():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    if gathered:
+        acc = {"local_step_into_rows": 0.0, "all_gather_rows": 0.0, "normalise+indices+import": 0.0}
+    else:
+        acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
+    migrants = 0
+    for _ in range(k_bd):
+        t_a = tick()
+        if gathered:
+            rows = shard.step_local_rows(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+            t_b = tick()
+            allrows = sf._gather_rows(rows)
+            t_c = tick()
+            shard.resample_gathered(allrows, u, world, rank, True, False)
+            t_d = tick()
+            ts_ = (t_b - t_a, t_c - t_b, t_d - t_c)
+        else:
+            shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
+            t_b = tick()
+            allw = sf.gather_logweights()
+            t_c = tick()
+            sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)
+            t_d = tick()
+            recv = sf._exchange(send[:sum(sc)], sc, rc, shard.pack_bytes())
+            t_e = tick()
+            shard.resample_end(recv)
+            t_f = tick()
+            ts_ = (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)
+            migrants = int(sum(rc))
+        for key, dt_ in zip(acc, ts_):
+            acc[key] += dt_
+    breakdown = {key: 1e6 * v / k_bd for key, v in acc.items()}
+    if not gathered:
+        breakdown["resample_with_migration"] = breakdown["resample_begin"] + breakdown["all_to_all"] + breakdown["resample_end"]
+        breakdown["particles_received_rank0"] = migrants
+    else:
+        breakdown["resample_with_migration"] = breakdown["all_gather_rows"] + breakdown["normalise+indices+import"]
+    sync()
+
+    pair_ms = avg_ms[P._lib.K_UPDATE_MERGE]
+    other = {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT], "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}
+    roof, valu = roofline_entries(P, S, cfg_id, n, G, M, pair_ms, pair_ms, gpu_region_ms / steps, None, other, with_traffic=False)
+    res = {
+        "value": steps / elapsed,                          # FILTER steps per second (the shards step together)
+        "ms_per_step": 1e3 * elapsed / steps,
+        "ms_per_step_gpu_p10_p50_p90": pcts,
+        "preroll_steps": preroll,
+        "config": {"workload": ("BASELINE.json configs[3]: ONE filter of %d particles x %d Gaussians/particle x %d meas/step sharded "
+                                "over %d ranks (rank r owns particles [r n, (r+1) n), n = %d, of the same generated set; same "
+                                "measurement set, control and uniform on every rank), RCCL log-weight all-gather + global systematic "
+                                "resample + migration every step, frozen snapshot" % (n_global, G, M, world, n)) if same_set else
+                               ("weak-scaling workload of round 1: %d particles x %d x %d per rank (fresh particles per rank, same "
+                                "measurement set), one %d-particle filter" % (n, G, M, n_global)),
+                   "particles_total": n_global, "particles_per_rank": n, "gaussians_per_particle": G, "measurements_per_step": M,
+                   "value_counts": "filter steps per second (K / max-over-ranks time)",
+                   "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                   "max_survivors": st["max_survivors"], "max_map": st["max_map"],
+                   "multi_gpu_phase_us_rank0": breakdown,
+                   "multi_gpu_exchange": "gathered" if gathered else "alltoall",
+                   **({"one_rank_rccl_dry_run": True} if one_rank else {}),
+                   **({"share_gpu_dry_run": True} if share else {})},
+        "roofline": roof,
+        "roofline_valu": valu,
+    }
+    f.close()
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 2000 timed steps of 24 us are 50 ms — long enough for the clocks to settle (400-step runs read ~2 % lower)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", type=int, default=2, help="workload: 2, 3 (BASELINE.json configs[1], [2]) or 5 (configs[4], CPHD)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    # defaults: 200 timed steps of 0.4 ms after the clock pre-roll
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=0,
+                    help="headline workload: 0 = the default (3 at N = 1: BASELINE.json configs[2]; 4 at N > 1: configs[3] sharded); "
+                         "2, 3, 5 (configs[1], [2], [4] = CPHD) at N = 1")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the headline's cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only")
+    ap.add_argument("--preroll-ms", type=float, default=PREROLL_MS)
+    ap.add_argument("--bare", action="store_true",
+                    help="profiling runs (rocprofv3): headline loop only — no riders, no stamped/unforced/copy passes, no CPU leg")
     args = ap.parse_args()
 
     import torch
@@ -129,250 +549,63 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    c = S.CONFIGS[args.config]
-    N, G, M = c["N"], c["G"], c["M"]
-    # every rank's shard: the same distribution, a different seed
-    w = S.make_workload(N, G, M, seed=0x5EED0000 + args.config + 1000 * rank, clustered=c["clustered"])
-    cfg = P.default_config(n_particles=N * world)
-    if args.config == 5:                                      # BASELINE.json configs[4]: the CPHD variant
-        cfg.filterType = 1
-        cfg.maxCardinality = 255
-    # one stream for everything: the filter's kernels and (N > 1) the RCCL collectives torch enqueues
-    ts = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(ts)
-    stream = ts.cuda_stream
-    f = P.PhdFilter(cfg, n_particles=N, map_capacity=2 * G, max_measurements=M, device=local_rank, stream=stream,
-                    global_particles=N * world, global_offset=N * rank)
-    lw = w["logw"] - np.float32(np.log(world)) if world > 1 else w["logw"]  # the global set sums to one
-    f.set_particles(w["poses"], lw.astype(np.float32))
-    f.set_maps(w["maps"], w["sizes"])
-    d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
-    d_noise = torch.from_numpy(w["noise"][0].copy()).to(dev)
-    control = (2.0, 0.05)
-    # the resampling uniform is one draw shared by all ranks (every rank must compute the same global indices)
-    u = float(np.random.default_rng(0x5EED0000 + args.config).random())
-    torch.cuda.synchronize()
-
-    f.set_frozen(True)  # steady state: no step commits, every iteration restarts from the same snapshot
+    secondary = []
     if not multi:
-        def step():
-            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=True)
+        cfg_id = args.config or 3
+        res = run_single(P, S, torch, cfg_id, args.steps, args.warmup, 0.0 if args.bare else args.cpu_seconds, dev, local_rank,
+                         args.preroll_ms, extras=not args.bare)
+        if not args.no_secondary and not args.bare:
+            for sid in (2, 3, 5, 4):
+                if sid == cfg_id:
+                    continue
+                # riders: shorter CPU leg, no copy-ceiling / stage pass (reported once, by the headline); configs[3]
+                # (16384 particles, the multi-GPU workload) on this ONE GPU is the N = 1 point of the strong-scaling curve
+                k = args.steps if sid != 2 else max(args.steps, 2000)   # 23 us steps: 2000 of them are 50 ms
+                r = run_single(P, S, torch, sid, k, max(args.warmup, 20 if sid != 2 else 200),
+                               0.0 if sid == 4 else min(args.cpu_seconds, 4.0), dev, local_rank, args.preroll_ms, extras=False)
+                r["steps"] = k
+                secondary.append(r)
+        scaling = "weak"   # N = 1: a single point of either curve; per-GPU work is what the N > 1 line divides
     else:
-        shard = D.GpuShard(f, N * world)
-        sf = D.ShardedFilter(shard, N * world, rank, world)
-        sf.collectives = True
-        if os.environ.get("PHD_BENCH_EXCHANGE") == "alltoall":
-            sf.gathered_limit = 0
-        gathered = sf.gathered()                    # small shards (this config up to 8 ranks): whole-shard all-gather
-
-        def step():
-            if gathered:
-                # one launch for predict + update + prune + merge, written straight into the export rows (raw weights
-                # in the row headers) -> ONE fixed-size RCCL all-gather of the shards -> global normalise + resample
-                # indices + import of this shard's parents: nothing waits for the host
-                rows = shard.step_local_rows(control, d_noise.data_ptr(), d_z.data_ptr(), M)
-                sf.resample_gathered(u, weights_in_rows=True, want_idx=False, rows=rows)
-            else:
-                # one launch for predict + update + prune + merge + raw weights, then
-                shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
-                # RCCL all-gather of the raw weights, one launch for the global normalise + resample indices (indices
-                # to the host for the plan), RCCL all-to-all of the migrating particles, commit
-                allw = sf.gather_logweights()
-                sf.resample(u, all_raw_logw=allw)   # the bench forces the resample: no host round trip for nEff
-
-    def sync():
-        f.sync()
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # HIP events on the stream the kernels run on (torch's current stream IS the filter's stream), bracketing
-    # the timed region: GPU time of the K steps without the per-launch event pairs of the pass below
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(ts)
-    chunk = max(1, args.steps // 20)            # an (asynchronous) event every `chunk` steps: the spread of the step time
-    marks = []
-    for k in range(args.steps):
-        step()
-        if (k + 1) % chunk == 0 and k + 1 < args.steps:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(ts)
-            marks.append(e)
-    ev1.record(ts)
-    sync()
-    elapsed = time.perf_counter() - t0
-    gpu_region_ms = ev0.elapsed_time(ev1)
-    edges = [ev0] + marks + [ev1]
-    counts = [chunk] * len(marks) + [args.steps - chunk * len(marks)]
-    per_step = sorted(a.elapsed_time(b) / c for a, b, c in zip(edges[:-1], edges[1:], counts) if c > 0)
-    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    st = f.status()
-
-    # kernel durations from HIP events on the filter's stream (separate pass: events perturb the timed loop)
-    k_ev = min(args.steps, 100)
-    f.timing_reset()
-    f.timing(True)
-    for _ in range(k_ev):
-        step()
-    sync()
-    ms, cnt = f.timing_read()
-    f.timing(False)
-    avg_ms = ms / np.maximum(cnt, 1)
-
-    # N > 1: where a step's time goes ("report resample-with-migration time separately") — the phases
-    # run back to back with a device synchronisation after each, so the parts add up to more than a pipelined step
-    breakdown = None
-    if multi:
-        k_bd = min(args.steps, 50)
-
-        def tick():
-            torch.cuda.synchronize()
-            return time.perf_counter()
-
-        if gathered:
-            acc = {"local_step_into_rows": 0.0, "all_gather_rows": 0.0, "normalise+indices+import": 0.0}
-        else:
-            acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
-        for _ in range(k_bd):
-            t_a = tick()
-            if gathered:
-                rows = shard.step_local_rows(control, d_noise.data_ptr(), d_z.data_ptr(), M)
-                t_b = tick()
-                allrows = sf._gather_rows(rows)
-                t_c = tick()
-                shard.resample_gathered(allrows, u, world, rank, True, False)
-                t_d = tick()
-                ts_ = (t_b - t_a, t_c - t_b, t_d - t_c)
-            else:
-                shard.step_local_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M)
-                t_b = tick()
-                allw = sf.gather_logweights()
-                t_c = tick()
-                sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)
-                t_d = tick()
-                recv = sf._exchange(send[:sum(sc)], sc, rc, shard.pack_bytes())
-                t_e = tick()
-                shard.resample_end(recv)
-                t_f = tick()
-                ts_ = (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)
-            for key, dt_ in zip(acc, ts_):
-                acc[key] += dt_
-        breakdown = {key: 1e6 * v / k_bd for key, v in acc.items()}
-        sync()
-
-    # the same loop with the reference's trigger instead of a forced resample (nEff <= resample_threshold)
-    unforced = None
-    if not multi:
-        k_un = min(args.steps, 200)
-        for _ in range(5):
-            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
-        sync()
-        tu = time.perf_counter()
-        for _ in range(k_un):
-            f.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=False)
-        sync()
-        unforced = k_un / (time.perf_counter() - tu)
-
-    # stage breakdown from the diagnostic instantiation of the update kernel: in-kernel s_memrealtime
-    # stamps per workgroup (shares of the per-particle critical path; the stamped kernel is not the timed one)
-    stages = None
-    if not multi and args.config != 5:
-        names = ["classify+ekf", "normalisers", "nondetect_emit", "detect_emit", "finalise+births", "sort", "merge_rounds",
-                 "sort_by_seed", "segments", "moment_matching", "append"]
-        f.debug(2)
-        for _ in range(2):
-            f.update(w["z"][0])
-        f.sync()
-        st_ = f.stamps().astype(np.int64)
-        dd = np.diff(st_[:, :12], axis=1) * 0.01
-        stages = {nm: float(dd[:, k].mean()) for k, nm in enumerate(names)}
-        stages["workgroup_total"] = float(((st_[:, 11] - st_[:, 0]) * 0.01).mean())
-        f.debug(0)
-
-    # in-run HBM ceiling: a device-to-device copy of 1 GiB on the same stream, read + write bytes
-    copy_gbs = None
-    if not multi:
-        src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        dst_t = torch.empty_like(src_t)
-        dst_t.copy_(src_t)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record(ts)
-        for _ in range(5):
-            dst_t.copy_(src_t)
-        c1.record(ts)
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * src_t.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-        del src_t, dst_t
+        cfg_id = args.config or 4
+        if one_rank and not args.config:
+            cfg_id = 2                                        # the dry run's historical workload: 256 x 64 x 32
+        n_global = S.CONFIGS[cfg_id]["N"] if (cfg_id == 4 or one_rank) else S.CONFIGS[cfg_id]["N"] * world
+        res = run_sharded(P, S, D, torch, dist, cfg_id, n_global, args.steps, args.warmup, dev, local_rank, rank, world, share,
+                          one_rank, same_set=True, preroll_ms=args.preroll_ms)
+        if not args.no_secondary and not args.bare and not one_rank:
+            k = max(args.steps, 400)
+            r = run_sharded(P, S, D, torch, dist, 2, 256 * world, k, max(args.warmup, 40), dev, local_rank, rank, world, share,
+                            one_rank, same_set=False, preroll_ms=args.preroll_ms)
+            r["steps"] = k
+            r["shard_steps_per_s"] = r["value"] * world       # round 1's unit for this workload (ranks x steps / time)
+            secondary.append(r)
+        scaling = "strong"  # total work (one 16384-particle filter) is fixed as N grows
 
     if rank == 0:
-        b_step = S.algorithmic_bytes(N, G, M)               # per launch of the update+merge kernel (one shard)
-        b_min = N * (28 * G + 28 * G + 32)                   # compulsory traffic
-        if args.config == 5:                                 # CPHD: + one cardinality row read and written per particle
-            b_step += N * 2 * 4 * 256
-            b_min += N * 2 * 4 * 256
-        pair_ms = avg_ms[P._lib.K_UPDATE_MERGE]              # event pair around every launch (separate pass)
-        one_launch_per_step = not multi and cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0
-        # when the whole step is ONE launch of the dominant kernel (fused step), the events bracketing the timed
-        # region give its average duration directly (launch-to-launch), free of the pair's marker packets
-        ker_ms = gpu_region_ms / args.steps if one_launch_per_step else pair_ms
-        ker_s = ker_ms * 1e-3
-        achieved = b_step / ker_s / 1e9 if ker_s > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh writes the
-        # summary; rocprofv3 cannot run inside the bench) — null if this configuration was not profiled
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic_cfg%d.json" % args.config)
-        if not multi and os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf))["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
         out = {
             "metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas",
-            "value": world * args.steps / elapsed,
+            "value": res["value"],
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "ms_per_step_gpu_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
+            "preroll_steps": res["preroll_steps"],
+            "ms_per_step": res["ms_per_step"],
+            "ms_per_step_gpu_p10_p50_p90": res["ms_per_step_gpu_p10_p50_p90"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[%d]: %d particles x %d Gaussians/particle x %d meas/step per GPU, "
-                                   "Ackerman motion, forced resample every step, frozen snapshot" % (args.config - 1, N, G, M),
-                       "particles_total": N * world, "gaussians_per_particle": G, "measurements_per_step": M,
-                       "value_counts": "shard-steps (ranks x steps) per second",
-                       "max_survivors": st["max_survivors"], "max_map": st["max_map"],
-                       "steps_per_s_unforced_resample": unforced, "multi_gpu_phase_us_rank0": breakdown,
-                       "multi_gpu_exchange": (("gathered" if gathered else "alltoall") if multi else None),
-                       **({"one_rank_rccl_dry_run": True} if one_rank else {})},
-            "stages_us_per_workgroup": stages,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
-                         "kernel_avg_us_event_pairs": 1e3 * pair_ms, "gpu_region_ms_per_step": gpu_region_ms / args.steps,
-                         "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
-                         "device_copy_ceiling_gbs": copy_gbs,
-                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                         "other_kernels_avg_us": {"phd_predict_kernel": 1e3 * avg_ms[P._lib.K_PREDICT],
-                                                  "phd_weights_kernel": 1e3 * avg_ms[P._lib.K_WEIGHTS]}},
+            "config": res["config"],
+            "stages_us_per_workgroup": res.get("stages_us_per_workgroup"),
+            "roofline": res["roofline"],
+            "roofline_valu": res["roofline_valu"],
+            "cpu_baseline": res.get("cpu_baseline"),
+            "secondary": secondary,
         }
-        if not multi and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(w, args.config, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out))
-    f.close()
     if multi:
         dist.destroy_process_group()
 

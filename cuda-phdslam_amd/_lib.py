@@ -64,6 +64,12 @@ class Options(C.Structure):
                 ("global_particles", C.c_int32), ("global_offset", C.c_int32)]
 
 
+class StepReport(C.Structure):
+    """phd_step_report: status word, high-water marks, nEff and resample decision of the last weights routine"""
+    _fields_ = [("status", C.c_uint32), ("max_survivors", C.c_int32), ("max_map", C.c_int32), ("neff", C.c_float),
+                ("did_resample", C.c_int32)]
+
+
 class Control(C.Structure):
     _fields_ = [("alpha", C.c_float), ("v_encoder", C.c_float)]
 
@@ -118,7 +124,9 @@ SYMBOLS = {
     "phd_global_resample_begin": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "phd_step_local_dev": (_i, [_vp, Control, _vp, _vp, _i]),
     "phd_global_resample_end": (_i, [_vp, _vp]),
-    "phd_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "phd_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "phd_step_report_get": (_i, [_vp, _vp]),
+    "phd_set_particle_count": (_i, [_vp, _i]),
     "phd_export_shard_dev": (_i, [_vp, _vp, _vp]),
     "phd_step_local_rows_dev": (_i, [_vp, Control, _vp, _vp, _i, _vp, _vp]),
     "phd_global_resample_gathered": (_i, [_vp, _vp, _d, _i, _i, _i, _vp]),

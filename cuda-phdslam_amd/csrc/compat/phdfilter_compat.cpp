@@ -41,18 +41,28 @@ int needed_capacity(const SynthSLAM& p, int n_meas)
     return cap;
 }
 
+// The filter is created for the CONFIGURED particle count; with the particle shotgun (n_predict_particles = k > 1,
+// src/phdfilter.cu:1185-1238) the caller's SynthSLAM grows by k per phdPredict and shrinks back in
+// resampleParticles(particles, config.n_particles) (src/main.cpp:1289): the library holds room for
+// 5 n_particles k particles, and the count it works on follows the SynthSLAM of each call.
 void ensure_filter(const SynthSLAM& p, int n_meas)
 {
     const int cap = needed_capacity(p, n_meas);
-    if (g_filter && g_n == p.n_particles && cap <= g_cap) return;
-    if (g_filter) phd_destroy(g_filter);
-    g_filter = nullptr;
-    phd_options o = {};
-    o.n_particles = p.n_particles;
-    o.map_capacity = std::max(cap, g_cap);
-    CHK(phd_create(&config, &o, &g_filter));
-    g_n = p.n_particles;
-    g_cap = o.map_capacity;
+    const int k = config.nPredictParticles > 1 ? config.nPredictParticles : 1;
+    int base = p.n_particles;
+    if (k > 1 && config.n_particles > 0 && p.n_particles >= config.n_particles && p.n_particles <= 5 * config.n_particles * k)
+        base = config.n_particles;
+    if (!(g_filter && g_n == base && cap <= g_cap)) {
+        if (g_filter) phd_destroy(g_filter);
+        g_filter = nullptr;
+        phd_options o = {};
+        o.n_particles = base;
+        o.map_capacity = std::max(cap, g_cap);
+        CHK(phd_create(&config, &o, &g_filter));
+        g_n = base;
+        g_cap = o.map_capacity;
+    }
+    if (phd_n_particles(g_filter) != p.n_particles) CHK(phd_set_particle_count(g_filter, p.n_particles));
 }
 
 void upload(const SynthSLAM& p)
@@ -120,13 +130,39 @@ void phdPredict(SynthSLAM& particles, ...)
     va_end(ap);
     ensure_filter(particles, 0);
     CHK(phd_set_particles(g_filter, particles.states.data(), particles.weights.data(), particles.n_particles));
-    // host-drawn noise in the reference's order (n_alpha, n_encoder) per particle (src/phdfilter.cu:1147-1152)
-    std::vector<AckermanNoise> noise(particles.n_particles);
+    // host-drawn noise in the reference's order (n_alpha, n_encoder) per PREDICTED particle (src/phdfilter.cu:1147-1152)
+    const int k = config.nPredictParticles > 1 ? config.nPredictParticles : 1;
+    const int n = particles.n_particles, n_pred = n * k;
+    std::vector<AckermanNoise> noise((size_t)n_pred);
     for (auto& nz : noise) {
         nz.n_alpha = (REAL)(config.stdAlpha * randn());
         nz.n_encoder = (REAL)(config.stdEncoder * randn());
     }
     CHK(phd_predict_ackerman(g_filter, control, noise.data()));
+    if (k > 1) {
+        // the reference grows the SynthSLAM (src/phdfilter.cu:1182-1234): every map, cardinality row and resample index
+        // k times in place, weights - log k, n_particles = nPredict.  (The device shares the maps through its parent
+        // indirection; the host copies are what the caller's SynthSLAM owns.)
+        if (phd_n_particles(g_filter) != n_pred) die("phdPredict (particle shotgun)");
+        std::vector<std::vector<Gaussian2D> > maps((size_t)n_pred);
+        std::vector<std::vector<REAL> > card((size_t)n_pred);
+        std::vector<int> ridx((size_t)n_pred);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < k; ++j) {
+                maps[(size_t)i * k + j] = particles.maps_static[i];
+                card[(size_t)i * k + j] = particles.cardinalities[i];
+                ridx[(size_t)i * k + j] = particles.resample_idx[i];
+            }
+        particles.maps_static.swap(maps);
+        particles.cardinalities.swap(card);
+        particles.resample_idx.swap(ridx);
+        particles.states.resize((size_t)n_pred);
+        particles.weights.resize((size_t)n_pred);
+        particles.variances.resize((size_t)n_pred);
+        particles.n_particles = n_pred;
+        CHK(phd_get_particles(g_filter, particles.states.data(), particles.weights.data()));   // weights - log k (:1213)
+        return;
+    }
     CHK(phd_get_particles(g_filter, particles.states.data(), nullptr));
 }
 
@@ -154,16 +190,21 @@ REAL computeNeff(SynthSLAM& particles)
 
 SynthSLAM resampleParticles(SynthSLAM oldParticles, int n_new_particles)
 {
-    if (n_new_particles >= 0 && n_new_particles != oldParticles.n_particles) {
-        fprintf(stderr, "resampleParticles: changing the particle count is not supported\n");
+    // n_new == n, or a grown (shotgun) set back to the configured count (src/main.cpp:1289)
+    const int n_old = oldParticles.n_particles;
+    if (n_new_particles < 0) n_new_particles = n_old;
+    const bool shrink = n_new_particles != n_old;
+    if (shrink && !(config.nPredictParticles > 1 && n_new_particles == config.n_particles && n_old > n_new_particles)) {
+        fprintf(stderr, "resampleParticles: the particle count can only change back to n_particles after a particle shotgun\n");
         exit(EXIT_FAILURE);
     }
     ensure_filter(oldParticles, 0);
-    CHK(phd_set_particles(g_filter, nullptr, oldParticles.weights.data(), oldParticles.n_particles));
+    CHK(phd_set_particles(g_filter, nullptr, oldParticles.weights.data(), n_old));
     const double u = randu01();
-    std::vector<int32_t> idx(oldParticles.n_particles);
-    CHK(phd_resample(g_filter, &u, 1, idx.data()));
-    return oldParticles.copy_particles(std::vector<int>(idx.begin(), idx.end()));
+    std::vector<int32_t> idx((size_t)n_old);
+    CHK(phd_resample(g_filter, &u, 1, idx.data()));           // a grown set comes back with n_particles indices
+    if (phd_n_particles(g_filter) != n_new_particles) die("resampleParticles (particle count)");
+    return oldParticles.copy_particles(std::vector<int>(idx.begin(), idx.begin() + n_new_particles));
 }
 
 void recoverSlamState(SynthSLAM& particles, ConstantVelocityState& expectedPose, std::vector<REAL>& cn_estimate)

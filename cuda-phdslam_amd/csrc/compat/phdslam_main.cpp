@@ -259,8 +259,14 @@ int main(int argc, char** argv)
         n_cur = phd_n_particles(f);
         phd_pose expected;
         int32_t n_map = 0, who = 0;
-        // weighted-mean pose, arg-max particle's map, all poses and weights: one call, one synchronisation
-        CHK(phd_state_snapshot(f, &expected, map.data(), (int)map.size(), &n_map, &who, poses.data(), logw.data()));
+        // weighted-mean pose, arg-max particle's map, all poses and weights AND the step's report (capacity status, the
+        // nEff the update's weights routine computed): one call, the ONE host synchronisation of the step
+        phd_step_report rep;
+        {
+            const int rc = phd_state_snapshot(f, &expected, map.data(), (int)map.size(), &n_map, &who, poses.data(), logw.data(), &rep);
+            if (rc == PHD_ERR_NAN) { printf("nan weights detected! exiting...\n"); break; }              // :1307-1311
+            if (rc != PHD_OK) die("phd_state_snapshot");
+        }
         if ((config.mapEstimate & 2) && n_cur > 1) {
             // expected-a-posteriori map (recoverSlamState, :363-379).  map_estimate = 2: it is the map of the log;
             // map_estimate = 3 (both): the MAP map stays in the log, the EAP map goes to expected_mapNNNNN.log
@@ -293,8 +299,20 @@ int main(int argc, char** argv)
         }
         PROF_MARK(2);
         // nEff test and resampling (:1281-1297)
+        // The trigger (:1286) is decided here from the report's nEff — the same float the device would compare — so the
+        // resample is enqueued without waiting for anything (the parent indices come back only for the 7-line log).
+        // A grown particle set (shotgun) keeps the library's own trigger, which also tests N > 5 n_particles.
         int32_t did = 0;
-        CHK(phd_resample_if_needed(f, randu01(), M > 0, &did, ridx.data()));
+        {
+            const double u = randu01();
+            if (kshot > 1) {
+                CHK(phd_resample_if_needed(f, u, M > 0, &did, ridx.data()));
+            } else {
+                did = (M > 0 && rep.neff <= config.resampleThresh) ? 1 : 0;
+                if (did) CHK(phd_resample(f, &u, 1, log7 ? ridx.data() : nullptr));
+                else if (log7) for (int i = 0; i < n_cur; ++i) ridx[i] = i;                              // :1292-1296
+            }
+        }
         PROF_MARK(3);
         {
             // weights and poses are those of the step (before resampling); a resample that shrinks a grown
@@ -319,13 +337,9 @@ int main(int argc, char** argv)
             }
         }
         PROF_MARK(4);
-        uint32_t st = 0;
-        if (phd_device_status(f, &st, nullptr, nullptr) != PHD_OK) die("capacity check");
         gettimeofday(&t1, nullptr);
         double elapsed = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_usec - t0.tv_usec) / 1000.0;
         if (FILE* tf = fopen(timefile.c_str(), "a")) { fprintf(tf, "%g\n", elapsed); fclose(tf); } // :1300-1305
-        float ne = 0;
-        if (phd_neff(f, &ne) != PHD_OK) { printf("nan weights detected! exiting...\n"); break; }  // :1307-1311
         printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", n, nSteps, M, n_cur, n_map, did, elapsed);
     }
     if (prof && nSteps > 0)

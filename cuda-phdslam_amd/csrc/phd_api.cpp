@@ -89,6 +89,9 @@ struct phd_filter {
     double* d_uniforms = nullptr; // n entries
     double* cdf = nullptr;        // n_global entries
     int* idx = nullptr;           // n_global entries
+    // step report: status word, high-water marks, nEff and the resample decision live in ONE device block
+    // (report[0..4]) so that one download fetches them all (phd_step_report, phd_state_snapshot)
+    unsigned* report = nullptr;
     float* neff = nullptr;
     int* did = nullptr;
     float* state_pose = nullptr;
@@ -224,7 +227,9 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         f->lfact_len = std::max(f->cn_len, f->MM + 1) + 1;
         f->lds_bytes += cphd_lds_bytes(f->cn_len, f->MM);
     }
-    if (f->lds_bytes > 160 * 1024) {
+    // a launch can use 160 KiB minus what the kernel's instantiations declare statically (the fused ones carry the
+    // weights routine's arrays): refuse here what launch_update_merge could not launch
+    if (f->lds_bytes + update_static_lds_bytes() > 160 * 1024) {
         delete f;
         return fail(PHD_ERR_CAPACITY, "phd_create: map_capacity/survivor_capacity need more than 160 KiB of LDS");
     }
@@ -248,9 +253,10 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->d_uniforms, std::max(f->n_max, f->n_global)));
     A(dalloc(&f->cdf, std::max(f->n_max, f->n_global)));
     A(dalloc(&f->idx, std::max(f->n_max, f->n_global)));
-    A(dalloc(&f->neff, 1)); A(dalloc(&f->did, 1));
+    A(dalloc(&f->report, 8));
+    f->status = f->report; f->max_surv = (int*)f->report + 1; f->max_map = (int*)f->report + 2;
+    f->neff = (float*)f->report + 3; f->did = (int*)f->report + 4;
     A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
-    A(dalloc(&f->status, 1)); A(dalloc(&f->max_surv, 1)); A(dalloc(&f->max_map, 1));
     A(dalloc(&f->d_tmp_int, f->n_max));
     A(dalloc(&f->ticket, 1));
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
@@ -267,10 +273,8 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     hipMemsetAsync(f->maps[1], 0, slab * sizeof(float), f->stream);
     hipMemsetAsync(f->counts[0], 0, f->n_max * sizeof(int), f->stream);
     hipMemsetAsync(f->counts[1], 0, f->n_max * sizeof(int), f->stream);
-    hipMemsetAsync(f->status, 0, 4, f->stream);
+    hipMemsetAsync(f->report, 0, 8 * 4, f->stream);
     hipMemsetAsync(f->ticket, 0, 4, f->stream);
-    hipMemsetAsync(f->max_surv, 0, 4, f->stream);
-    hipMemsetAsync(f->max_map, 0, 4, f->stream);
     for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n_max, f->stream);
     if (f->cphd) {
         // uniform cardinality -log(maxCardinality+1) (src/main.cpp:1142); log factorials by the reference's
@@ -306,8 +310,8 @@ extern "C" int phd_destroy(phd_filter* f)
     for (int k = 0; k < 3; ++k) { hipFree(f->parent[k]); hipFree(f->pose[k]); }
     hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
-    hipFree(f->neff); hipFree(f->did); hipFree(f->state_pose); hipFree(f->state_argmax);
-    hipFree(f->status); hipFree(f->max_surv); hipFree(f->max_map); hipFree(f->d_tmp_int); hipFree(f->ticket);
+    hipFree(f->report); hipFree(f->state_pose); hipFree(f->state_argmax);
+    hipFree(f->d_tmp_int); hipFree(f->ticket);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
@@ -654,6 +658,7 @@ struct FusedWeights {
 };
 static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0,
                               WeightArgs& w, int& free_pose);
+static int interpret_report(phd_filter* f, const unsigned raw[8], phd_step_report* out);
 static void commit_weights(phd_filter* f, int mode, int free_pose);
 
 static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, const FusedPredict* fp = nullptr,
@@ -889,6 +894,26 @@ extern "C" int phd_step_dev(phd_filter* f, phd_ackerman_control u, const phd_ack
     CHECK_F(f);
     int rc;
     int M = std::min(n_meas, f->MM);
+    if (f->cfg.nPredictParticles > 1) {
+        // particle shotgun (src/phdfilter.cu:797-823,1185-1238): the fused in-kernel predict is 1:1, so this step is
+        // the staged sequence — predict multiplies the set by k (log-weights - log k, maps shared through the parent
+        // indirection), the update runs on the grown set, and the resample is run_synth's trigger
+        // (src/main.cpp:1286: nEff <= threshold with measurements, or N > 5 n_particles) back to n_particles
+        rc = do_predict(f, u, d_noise);
+        if (rc) return rc;
+        if (M > 0) {
+            rc = phd_update_dev(f, d_z, M);
+            if (rc) return rc;
+        }
+        if (force_resample) {
+            const int n_new = (f->n == f->n_base || f->n_global != f->n_base) ? f->n : f->n_base;
+            rc = do_weights(f, WM_RESAMPLE_FORCE | WM_COMMIT, nullptr, 1, uniform);
+            if (rc) return rc;
+            if (!f->frozen) f->n = n_new;
+            return PHD_OK;
+        }
+        return phd_resample_if_needed(f, uniform, M > 0, nullptr, nullptr);
+    }
     int mode = WM_COMMIT | (force_resample ? WM_RESAMPLE_FORCE : WM_RESAMPLE_AUTO);
     if (M <= 0) {
         rc = do_predict(f, u, d_noise); // no measurements: predict only (src/main.cpp:1244-1260)
@@ -932,7 +957,7 @@ extern "C" int phd_map_estimate(phd_filter* f, phd_gaussian2d* out, int capacity
 // recoverSlamState in one call and ONE host synchronisation (phd_expected_pose + phd_map_estimate + phd_get_particles make
 // three): the arg-max particle's map is unpacked by a kernel that takes the index from device memory
 extern "C" int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gaussian2d* map_out, int capacity, int32_t* n_map_out,
-                                  int32_t* particle_out, phd_pose* poses_out, float* log_weights_out)
+                                  int32_t* particle_out, phd_pose* poses_out, float* log_weights_out, phd_step_report* report_out)
 {
     CHECK_F(f);
     if (!expected_out || !map_out || !n_map_out) return fail(PHD_ERR_INVALID_ARG, "phd_state_snapshot: null output");
@@ -950,7 +975,16 @@ extern "C" int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gau
         HIPCHK(hipMemcpyAsync(map_out, f->d_concat, (size_t)ncopy * sizeof(phd_gaussian2d), hipMemcpyDeviceToHost, f->stream));
     if (poses_out) HIPCHK(hipMemcpyAsync(poses_out, f->pose[f->pose_cur], f->n * sizeof(phd_pose), hipMemcpyDeviceToHost, f->stream));
     if (log_weights_out) HIPCHK(hipMemcpyAsync(log_weights_out, f->logw, f->n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    unsigned raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (report_out) HIPCHK(hipMemcpyAsync(raw, f->report, sizeof(raw), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
+    if (report_out) {
+        // the step's report rides on the same download: capacity overflow, the fused step's time-out, and the nEff / resample
+        // decision the step's weights routine left (src/main.cpp:1281-1311: the NaN exit tests the PRE-resample nEff)
+        rc = interpret_report(f, raw, report_out);
+        if (rc) return rc;
+        if (report_out->neff != report_out->neff) return fail(PHD_ERR_NAN, "nan weights detected");
+    }
     if (am < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
     *n_map_out = nm;
     if (particle_out) *particle_out = am;
@@ -1144,7 +1178,8 @@ extern "C" int phd_step_local_dev(phd_filter* f, phd_ackerman_control u, const p
         HIPCHK(hipMemcpyAsync(f->logw_raw, f->logw, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
         return PHD_OK;
     }
-    if (f->n != f->n_base) return fail(PHD_ERR_UNSUPPORTED, "phd_step_local_dev: particle shotgun shards use the staged calls");
+    if (f->n != f->n_base || f->cfg.nPredictParticles > 1)
+        return fail(PHD_ERR_UNSUPPORTED, "phd_step_local_dev: particle shotgun shards (n_predict_particles > 1) use the staged calls");
     FusedPredict fp = {u, d_noise};
     f->want_raw = true;
     int rc = do_update_merge(f, d_z, M, &fp);
@@ -1404,7 +1439,9 @@ extern "C" int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, co
     CHECK_F(f);
     if (!d_rows) return fail(PHD_ERR_INVALID_ARG, "phd_step_local_rows_dev: null output");
     const int M = std::min(n_meas, f->MM);
-    if (M <= 0 || f->n != f->n_base) { // no measurements / particle shotgun: the staged form
+    if (f->cfg.nPredictParticles > 1)
+        return fail(PHD_ERR_UNSUPPORTED, "phd_step_local_rows_dev: particle shotgun shards (n_predict_particles > 1) use the staged calls");
+    if (M <= 0 || f->n != f->n_base) { // no measurements: the staged form
         int rc = phd_step_local_dev(f, u, d_noise, d_z, n_meas);
         if (rc) return rc;
         return phd_export_shard_dev(f, d_rows, bytes_out);
@@ -1491,6 +1528,7 @@ extern "C" int phd_debug_enable(phd_filter* f, int enable)
     CHECK_F(f);
     f->debug = (enable & 1) != 0;
     f->want_stamps = (enable & 2) != 0; // diagnostic instantiation with phase stamps
+    f->fuse_enabled = (enable & 4) == 0; // bit 2: never fuse the weights routine into the update launch (parity tests)
     if (f->debug) return ensure_debug(f);
     return PHD_OK;
 }
@@ -1550,20 +1588,64 @@ extern "C" int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out)
     return PHD_OK;
 }
 
-extern "C" int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out)
+// the device's step report block -> host struct; interprets the sticky status bits.  A time-out of the fused step's
+// weights workgroup left the ticket counter mid-count: the counter is re-zeroed and the bit cleared here, so the
+// NEXT step is sound again — this one is reported as failed.
+static int interpret_report(phd_filter* f, const unsigned raw[8], phd_step_report* out)
+{
+    phd_step_report r;
+    r.status = raw[0];
+    r.max_survivors = (int32_t)raw[1];
+    r.max_map = (int32_t)raw[2];
+    memcpy(&r.neff, &raw[3], 4);
+    r.did_resample = (int32_t)raw[4];
+    if (out) *out = r;
+    if (r.status & PHD_STATUS_TAIL_TIMEOUT) {
+        (void)hipStreamSynchronize(f->stream);
+        (void)hipMemsetAsync(f->ticket, 0, 4, f->stream);
+        const unsigned cleared = r.status & ~(unsigned)PHD_STATUS_TAIL_TIMEOUT;
+        (void)hipMemcpyAsync(f->status, &cleared, 4, hipMemcpyHostToDevice, f->stream);
+        (void)hipStreamSynchronize(f->stream);
+        return fail(PHD_ERR_HIP, "fused step: the weights workgroup timed out waiting for the particles' workgroups "
+                                 "(step failed; the hand-off counter has been reset)");
+    }
+    if (r.status) return fail(PHD_ERR_CAPACITY, std::string("device capacity overflow:") + ((r.status & 1) ? " map_capacity" : "") +
+                                                    ((r.status & 2) ? " survivor_capacity" : ""));
+    return PHD_OK;
+}
+
+extern "C" int phd_step_report_get(phd_filter* f, phd_step_report* out)
 {
     CHECK_F0(f);
-    uint32_t st = 0;
-    int ms = 0, mm = 0;
-    HIPCHK(hipMemcpyAsync(&st, f->status, 4, hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(&ms, f->max_surv, 4, hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(&mm, f->max_map, 4, hipMemcpyDeviceToHost, f->stream));
+    unsigned raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(raw, f->report, sizeof(raw), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
-    if (status_out) *status_out = st;
-    if (max_survivors_out) *max_survivors_out = ms;
-    if (max_map_out) *max_map_out = mm;
-    if (st & 4) return fail(PHD_ERR_HIP, "fused step: the weights workgroup timed out waiting for the particles' workgroups");
-    if (st) return fail(PHD_ERR_CAPACITY, std::string("device capacity overflow:") + ((st & 1) ? " map_capacity" : "") +
-                                              ((st & 2) ? " survivor_capacity" : ""));
+    return interpret_report(f, raw, out);
+}
+
+extern "C" int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out)
+{
+    phd_step_report r;
+    memset(&r, 0, sizeof(r));
+    const int rc = phd_step_report_get(f, &r);
+    if (status_out) *status_out = r.status;
+    if (max_survivors_out) *max_survivors_out = r.max_survivors;
+    if (max_map_out) *max_map_out = r.max_map;
+    return rc;
+}
+
+// Declare that the filter now holds n particles (1 <= n <= its maximum: n_particles, or 5 n_particles
+// n_predict_particles with the particle shotgun): the host-side mirror of a SynthSLAM whose particle count changed
+// outside the library (src/phdfilter.cu:1185-1238 grows it in phdPredict, src/main.cpp:1289 shrinks it).  The map
+// indirection is reset; the caller uploads particles and maps afterwards.
+extern "C" int phd_set_particle_count(phd_filter* f, int n)
+{
+    CHECK_F(f);
+    if (n < 1 || n > f->n_max) return fail(PHD_ERR_CAPACITY, "phd_set_particle_count: n outside 1..maximum particle count");
+    if (f->frozen) return fail(PHD_ERR_UNSUPPORTED, "phd_set_particle_count: filter is frozen");
+    f->n = n;
+    HIPCHK(launch_iota(f->parent[f->pcur], f->n_max, f->stream));
+    f->parent_dirty = false;
+    f->pose_for_update = nullptr;
     return PHD_OK;
 }

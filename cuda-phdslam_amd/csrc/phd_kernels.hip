@@ -80,25 +80,36 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         // (agent scope, bounded) and then reads with sc1 loads.  Only this workgroup ever waits, and for workgroups
         // that wait for nothing, so the order in which the dispatcher places them does not matter.
         const unsigned n_wg = gridDim.x - 1;
+        __shared__ int s_tail_ok;
         if (tid == 0) {
             unsigned spins = 0;
+            bool ok = true;
             while (__hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_wg) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 24)) { atomicOr(A.status, PHD_STATUS_TAIL_TIMEOUT); break; }   // ~seconds: never in practice
+                if (++spins > (1u << 24)) { ok = false; break; }   // ~seconds: never in practice
             }
-            __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // ready for the next launch
+            // time-out: the particles' workgroups are still adding to the ticket, so it is NOT reset here and the routine
+            // does NOT run on incomplete data; the status bit makes the host fail the step and re-zero the ticket
+            // (phd_device_status / phd_step_report)
+            if (ok) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            else atomicOr(A.status, PHD_STATUS_TAIL_TIMEOUT);
+            s_tail_ok = ok ? 1 : 0;
         }
         __syncthreads();
-        // up to 512 particles need four waves (the instantiation the staged calls launch, so both paths agree bit for
-        // bit there too); the other four leave first: the routine's barriers then wait for half as many waves
-        if (A.wa.n <= 256 && A.wa.n_new <= A.wa.n) {
-            if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread: same tree, same bits
-        } else if (A.wa.n <= 512 && A.wa.n_new <= A.wa.n) {
+        if (!s_tail_ok) return;
+        // the instantiation launch_weights runs for this particle count (one table — 256 threads up to 512 particles, 512 up to 4096: the
+        // reduction trees, hence the bits of the log-sum-exp and of nEff, are a function of the block size), so
+        // phd_step_dev and the staged calls agree bit for bit.  Up to 512 particles that is four waves; the other
+        // four leave first: the routine's barriers then wait for half as many waves
+        const bool shrink = A.wa.n_new <= A.wa.n;   // (the register-resident routine commits logw[j], j < n)
+        if (A.wa.n <= 256 && shrink) {
+            if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread
+        } else if (A.wa.n <= 512 && shrink) {
             if (tid < 256) weights_body<256, 2, true>(A.wa, lds_raw);
         } else if (A.wa.n <= 2 * PHD_T) {
             weights_body<PHD_T, 2, true>(A.wa, lds_raw);
         } else {
-            weights_body<PHD_T, 8, true>(A.wa, lds_raw);                 // up to 4096: what launch_weights runs for these sizes
+            weights_body<PHD_T, 8, true>(A.wa, lds_raw);                 // up to 4096
         }
         return;
     }
@@ -755,6 +766,25 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
+static const void* const k_update_fns[6] = {(const void*)phd_update_merge_kernel<false, false, false>,
+                                            (const void*)phd_update_merge_kernel<true, false, false>,
+                                            (const void*)phd_update_merge_kernel<false, true, false>,
+                                            (const void*)phd_update_merge_kernel<false, false, true>,
+                                            (const void*)phd_update_merge_kernel<true, false, true>,
+                                            (const void*)phd_update_merge_kernel<false, true, true>};
+
+// the largest static __shared__ footprint among the instantiations of the update kernel (the fused ones carry the
+// weights routine's arrays): what a launch can use dynamically is 160 KiB minus this
+size_t update_static_lds_bytes()
+{
+    size_t mx = 0;
+    for (int k = 0; k < 6; ++k) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, k_update_fns[k]) == hipSuccess && fa.sharedSizeBytes > mx) mx = fa.sharedSizeBytes;
+    }
+    return mx;
+}
+
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st)
 {
     // function attributes are per device: set once for every device this process launches on
@@ -764,12 +794,7 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
         // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
-        const void* fns[6] = {(const void*)phd_update_merge_kernel<false, false, false>,
-                              (const void*)phd_update_merge_kernel<true, false, false>,
-                              (const void*)phd_update_merge_kernel<false, true, false>,
-                              (const void*)phd_update_merge_kernel<false, false, true>,
-                              (const void*)phd_update_merge_kernel<true, false, true>,
-                              (const void*)phd_update_merge_kernel<false, true, true>};
+        const void* const* fns = k_update_fns;
         for (int k = 0; k < 6; ++k) {
             hipFuncAttributes fa;
             hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
@@ -831,10 +856,14 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
         attr_set = true;
     }
     const size_t dyn = (size_t)a.n * 8; // the fixed-point CDF, one u64 per particle
-    if (a.n <= 512 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, a);
-    else if (a.n <= 2048 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<256, 8>), dim3(1), dim3(256), dyn, st, a);
-    else if (a.n <= 4096 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, a);
-    else if (a.n <= 16384 && a.n_new <= a.n) hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, a);
+    // one table for this launcher and for the fused tail of the update kernel : 256 threads up
+    // to 512 particles, 512 up to 4096, 1024 above; R = registers per thread
+    const bool small = a.n_new <= a.n && a.n <= 16384;
+    if (small && a.n <= 256) hipLaunchKernelGGL((phd_weights_small_kernel<256, 1>), dim3(1), dim3(256), dyn, st, a);
+    else if (small && a.n <= 512) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, a);
+    else if (small && a.n <= 1024) hipLaunchKernelGGL((phd_weights_small_kernel<512, 2>), dim3(1), dim3(512), dyn, st, a);
+    else if (small && a.n <= 4096) hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, a);
+    else if (small) hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, a);
     else if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(phd_weights_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();

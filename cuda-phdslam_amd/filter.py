@@ -176,9 +176,20 @@ class PhdFilter:
         n, who = C.c_int32(0), C.c_int32(0)
         poses = np.zeros(self.n, POSE)
         lw = np.zeros(self.n, np.float32)
-        check(lib().phd_state_snapshot(self._h, ptr(e), ptr(out), self.cap, C.byref(n), C.byref(who), ptr(poses), ptr(lw)),
-              "phd_state_snapshot")
+        rep = L.StepReport()
+        check(lib().phd_state_snapshot(self._h, ptr(e), ptr(out), self.cap, C.byref(n), C.byref(who), ptr(poses), ptr(lw),
+                                       C.byref(rep)), "phd_state_snapshot")
+        self.last_report = rep
         return e[0], out[:n.value].copy(), who.value, poses, lw
+
+    def step_report(self):
+        """status word, high-water marks, nEff and resample decision of the last weights routine: one download"""
+        rep = L.StepReport()
+        check(lib().phd_step_report_get(self._h, C.byref(rep)), "phd_step_report_get")
+        return rep
+
+    def set_particle_count(self, n):
+        check(lib().phd_set_particle_count(self._h, int(n)), "phd_set_particle_count")
 
     def expected_map(self, capacity=None):
         """EAP map (config map_estimate & 2): computeExpectedMap, src/main.cpp:290-316, on the device"""

@@ -342,7 +342,7 @@ int phd_timing_reset(phd_filter* f);
  * un-pruned slab.  Valid after phd_update until the next hot-path call.
  * Also the per-particle log-weight increments of the last update (src/phdfilter.cu:2260-2263).
  * ---------------------------------------------------------------------------------- */
-int phd_debug_enable(phd_filter* f, int enable); /* bit 0: survivor inspection, bit 1: phase stamps */
+int phd_debug_enable(phd_filter* f, int enable); /* bit 0: survivor inspection, bit 1: phase stamps, bit 2: staged launches only (no fused weights tail) */
 /* phase stamps of the last update (diagnostic kernel instantiation): out[n_particles][16], 100 MHz ticks */
 int phd_debug_get_stamps(phd_filter* f, uint64_t* out);
 int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, int32_t* slab_index_out,
@@ -352,11 +352,27 @@ int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out);
  * workgroup of a fused step gave up waiting for the particles' workgroups (-> PHD_ERR_HIP; a bounded spin of seconds, never
  * seen in practice) */
 int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out);
+/* everything the driver loop tests after a step, in ONE download (replaces the separate phd_device_status + phd_neff
+ * round trips; run_synth's tests: src/main.cpp:1281-1311): the sticky status word and high-water marks, and the nEff /
+ * resample decision left by the step's weights routine (phd_update, phd_resample_if_needed, phd_step_dev: nEff of the
+ * normalised weights BEFORE any resample, as the reference's NaN exit needs it).  Returns what phd_device_status returns;
+ * after a fused-step time-out (status bit 2) the hand-off counter is reset so that later steps are sound. */
+typedef struct {
+    uint32_t status;
+    int32_t max_survivors, max_map;
+    float neff;
+    int32_t did_resample;
+} phd_step_report;
+int phd_step_report_get(phd_filter* f, phd_step_report* out);
+/* the host-side mirror of a SynthSLAM whose particle count changed outside the library (phdPredict grows it by
+ * n_predict_particles, src/phdfilter.cu:1185-1238; resampleParticles shrinks it, src/main.cpp:1289): the filter now holds
+ * n particles (1 <= n <= n_particles, or 5 n_particles n_predict_particles with the shotgun); upload particles and maps next */
+int phd_set_particle_count(phd_filter* f, int n);
 /* recoverSlamState (src/main.cpp:318-361) in one call and one host synchronisation: weighted-mean pose, the map of the
  * arg-max particle (map_out[capacity], *n_map_out entries, *particle_out its index), and optionally every particle's pose and
  * log-weight — what phd_expected_pose + phd_map_estimate + phd_get_particles return in three round trips */
 int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gaussian2d* map_out, int capacity, int32_t* n_map_out,
-                       int32_t* particle_out, phd_pose* poses_out, float* log_weights_out);
+                       int32_t* particle_out, phd_pose* poses_out, float* log_weights_out, phd_step_report* report_out /* optional */);
 
 /* ------------------------------------------------------------------------------------
  * Host-side boundary helpers (no device needed): config file, data files, log writer

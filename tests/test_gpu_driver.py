@@ -181,3 +181,108 @@ int main(int argc, char** argv) {
         assert abs(float(t[2]) - lw[i]) <= 1e-6 * abs(lw[i]) and int(t[3]) == len(maps[i])
         assert abs(float(t[4]) - maps[i]["weight"][0]) <= 1e-6 * maps[i]["weight"][0]
         assert int(out[3 + N + i].split()[2]) == idx[i]
+
+
+def test_phdfilter_h_adapter_particle_shotgun(tmp_path):
+    """n_predict_particles = 2 through the adapter (the old adapter read past its noise vector and wrote n k poses
+    into a vector of n): phdPredict grows the caller's SynthSLAM like the reference (src/phdfilter.cu:1182-1234 — maps,
+    cardinalities and resample indices k times, weights - log k, n_particles = n k), phdUpdateSynth works on the grown
+    set, resampleParticles(particles, config.n_particles) brings it back (src/main.cpp:1289).  Same numbers as the
+    C-ABI driven from Python."""
+    P = importlib.import_module("cuda-phdslam_amd")
+    src = tmp_path / "adapter_shotgun.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "phdfilter_compat.h"
+int main(int argc, char** argv) {
+    char ddir[1024]; int32_t ns;
+    if (phd_config_load(argv[1], &config, ddir, sizeof(ddir), &ns)) { printf("cfg: %s\n", phd_last_error()); return 1; }
+    config.nPredictParticles = 2;
+    phd_compat_seed_rng(4);
+    setDeviceConfig(config);
+    const int N = config.n_particles;
+    SynthSLAM particles(N);
+    for (int i = 0; i < N; ++i) {
+        particles.states[i] = ConstantVelocityState{0.01f * i, -0.02f * i, 0.001f * i, 0, 0, 0};
+        particles.weights[i] = -2.7725887f - 0.01f * i;
+        particles.resample_idx[i] = i;
+        for (int g = 0; g < 5; ++g) {
+            Gaussian2D f; f.cov[0] = 0.04f; f.cov[1] = f.cov[2] = 0.001f * g; f.cov[3] = 0.09f;
+            f.mean[0] = 2.0f + 1.5f * g + 0.01f * i; f.mean[1] = -3.0f + 1.1f * g; f.weight = 0.5f + 0.1f * g;
+            particles.maps_static[i].push_back(f);
+        }
+    }
+    AckermanControl u; u.alpha = 0.05f; u.v_encoder = 2.0f;
+    phdPredict(particles, u);
+    printf("grown %d %zu %zu %zu %zu\n", particles.n_particles, particles.states.size(), particles.weights.size(),
+           particles.maps_static.size(), particles.resample_idx.size());
+    for (int i = 0; i < particles.n_particles; ++i)
+        printf("g %d %.9g %.9g %.9g %d\n", i, particles.weights[i], particles.states[i].px, particles.maps_static[i][0].mean[0], particles.resample_idx[i]);
+    measurementSet Z;
+    for (int m = 0; m < 6; ++m) { RangeBearingMeasurement z; z.range = 3.0f + m; z.bearing = -1.0f + 0.4f * m; z.label = 0; Z.push_back(z); }
+    phdUpdateSynth(particles, Z);
+    for (int i = 0; i < particles.n_particles; ++i) printf("p %d %.9g %zu\n", i, particles.weights[i], particles.maps_static[i].size());
+    SynthSLAM rs = resampleParticles(particles, config.n_particles);
+    printf("back %d\n", rs.n_particles);
+    for (int i = 0; i < rs.n_particles; ++i) printf("r %d %d %zu\n", i, rs.resample_idx[i], rs.maps_static[i].size());
+    return 0;
+}
+''')
+    exe = tmp_path / "adapter_shotgun"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "csrc", "compat"), "-Wno-varargs", str(src), "-o", str(exe),
+                           "-L" + PKG, "-lphdfilter_compat", "-lphdslam", "-Wl,-rpath," + PKG])
+    d = str(tmp_path)
+    cfg_path = write_dataset(d, n_particles=16)
+    r = subprocess.run([str(exe), cfg_path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.split("\n")
+    rng = C.CDLL(os.path.join(PKG, "libphdfilter_compat.so"))
+    rng.randn.restype = C.c_double
+    rng.randu01.restype = C.c_double
+    rng.phd_compat_seed_rng(C.c_uint64(4))
+    cfg, _, _ = P.load_config(cfg_path)
+    cfg.nPredictParticles = 2
+    N, k = 16, 2
+    poses = np.zeros(N, P.POSE)
+    poses["px"] = np.float32(0.01) * np.arange(N, dtype=np.float32)
+    poses["py"] = np.float32(-0.02) * np.arange(N, dtype=np.float32)
+    poses["ptheta"] = np.float32(0.001) * np.arange(N, dtype=np.float32)
+    maps = []
+    for i in range(N):
+        g = np.zeros(5, P.GAUSSIAN)
+        for j in range(5):
+            g[j]["cov"] = [0.04, np.float32(0.001) * np.float32(j), np.float32(0.001) * np.float32(j), 0.09]
+            g[j]["mean"] = [np.float32(2.0) + np.float32(1.5) * np.float32(j) + np.float32(0.01) * np.float32(i),
+                            np.float32(-3.0) + np.float32(1.1) * np.float32(j)]
+            g[j]["weight"] = np.float32(0.5) + np.float32(0.1) * np.float32(j)
+        maps.append(g)
+    z = np.zeros(6, P.MEAS)
+    z["range"] = 3.0 + np.arange(6)
+    z["bearing"] = np.float32(-1.0) + np.float32(0.4) * np.arange(6, dtype=np.float32)
+    lw0 = np.float32(-2.7725887) - np.float32(0.01) * np.arange(N, dtype=np.float32)
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=256) as f:
+        f.set_particles(poses, lw0)
+        f.set_maps(maps)
+        noise = np.zeros((N * k, 2), np.float32)
+        for i in range(N * k):
+            noise[i, 0] = cfg.stdAlpha * rng.randn()
+            noise[i, 1] = cfg.stdEncoder * rng.randn()
+        f.predict((2.0, 0.05), noise)
+        pg, lg = f.get_particles()
+        f.update(z)
+        _, lw = f.get_particles()
+        sizes = f.map_sizes()
+        idx = f.resample(rng.randu01())
+        sizes_after = f.map_sizes()
+    assert out[0].split() == ["grown", "32", "32", "32", "32", "32"], out[0]
+    for i in range(N * k):
+        t = out[1 + i].split()
+        assert abs(float(t[2]) - lg[i]) <= 2e-6 * abs(lg[i]) and abs(float(t[3]) - pg["px"][i]) <= 1e-6
+        assert abs(float(t[4]) - maps[i // k]["mean"][0][0]) <= 1e-6 and int(t[5]) == i // k
+        t = out[1 + N * k + i].split()
+        assert abs(float(t[2]) - lw[i]) <= 2e-6 * abs(lw[i]) and int(t[3]) == sizes[i]
+    assert out[1 + 2 * N * k].split() == ["back", "16"]
+    for i in range(N):
+        t = out[2 + 2 * N * k + i].split()
+        assert int(t[2]) == idx[i] and int(t[3]) == sizes_after[i]

@@ -1,0 +1,62 @@
+"""The CPU oracle against its own FROZEN outputs (tests/golden/oracle_steps.npz; SURVEY.md §8c fixtures): the oracle was
+changed during round 1 (fixed-point CDF, det_exp) while every parity test compared the device with the LIVE oracle —
+nothing would have caught the two drifting together.  The device is tested against the same file
+(tests/test_gpu_golden.py).
+
+Stages without transcendentals (merge, resampling indices from given weights) must reproduce the file BIT FOR BIT on
+any host; the stages that call libm (atan2f, logf, expf: last-bit rounding is a property of the host's libm) within
+the tolerances of the device tests, structure compared where the frozen decision margins allow."""
+import numpy as np
+import pytest
+
+from golden_utils import CASES, CONTROL, load_case
+from oracle import oracle as O
+from parity_utils import assert_maps_close, oracle_config_from, oracle_full_update, pkg
+
+PRUNE_MARGIN = 2e-3
+MERGE_MARGIN = 2e-4
+
+
+@pytest.mark.parametrize("n,g,m,seed", CASES)
+def test_oracle_reproduces_its_frozen_outputs(n, g, m, seed):
+    c = load_case(n, g, m, seed)
+    ocfg = oracle_config_from(pkg().default_config())
+    pred = O.predict_ackerman(c["poses"], CONTROL[1], CONTROL[0], c["noise"], ocfg)
+    for k in ("px", "py", "ptheta"):
+        assert np.abs(pred[k] - c["pred"][k]).max() < 2e-6, k
+    n_struct = 0
+    dl = []
+    for p in range(n):
+        # the update from the FROZEN predicted pose (so a libm difference in the predict does not leak in)
+        r = oracle_full_update(c["pred"][p], c["maps"][p, :c["sizes"][p]], c["z"], ocfg)
+        dl.append(r["dlogw"])
+        assert abs(r["dlogw"] - c["dlogw"][p]) < 2e-3 + 2e-4 * abs(c["dlogw"][p])
+        # merge: no transcendental in it -> bit for bit on the frozen survivors
+        om = O.merge(c["surv_of"](p), ocfg)
+        cls0 = c["maps"][p, :c["sizes"][p]][r["cls"] == 0]
+        want = c["map_of"](p)
+        got = np.concatenate([om, cls0]) if len(cls0) else om
+        assert len(got) == len(want)
+        for fld in ("weight", "mean", "cov"):
+            assert np.array_equal(got[fld].view(np.uint32), want[fld].view(np.uint32)), (p, fld)
+        pm, mm = c["margins"][p, 0], c["margins"][p, 1]
+        if pm > PRUNE_MARGIN:
+            assert np.array_equal(r["slab_idx"], c["sidx_of"](p)), "particle %d: survivor set differs from the frozen one" % p
+            assert_maps_close(r["survivors"], c["surv_of"](p), ordered=True, what="survivors of particle %d" % p)
+            if mm > MERGE_MARGIN:
+                n_struct += 1
+                assert_maps_close(r["map"], want, what="map of particle %d" % p)
+    assert n_struct >= 0.5 * n, (n_struct, n)
+    # weights from the frozen increments; indices from the frozen weights: exact integer arithmetic (fixed-point CDF)
+    lw = O.normalize_weights(c["logw"], c["dlogw"])
+    assert np.abs(lw - c["logw_norm"]).max() < 2e-6
+    assert abs(O.neff(c["logw_norm"]) - float(c["neff"])) < 1e-5 * max(1.0, float(c["neff"]))
+    assert np.array_equal(O.resample(c["logw_norm"], float(c["uniform"])), c["idx"])
+
+
+def test_frozen_file_covers_the_three_shapes_and_seeds():
+    for (n, g, m, seed) in CASES:
+        c = load_case(n, g, m, seed)
+        assert c["poses"].shape == (n,) and c["maps"].shape == (n, g) and c["z"].shape == (m,)
+        assert c["nsurv"].sum() == len(c["surv"]) and c["out_sizes"].sum() == len(c["out_maps"])
+        assert np.all(np.diff(c["idx"]) >= 0)

@@ -1,35 +1,47 @@
 #!/bin/bash
-# one GPU-box visit: tests, smoke, bench (configs 2 and 3), rocprofv3 kernel trace of the bench command,
-# PMC traffic passes.  usage (repo root on the GPU box): bash tools/gpu_round.sh <tag>
-tag=${1:-r01}
+# one GPU-box visit: tests, smoke, the driver's bench invocation + a long run, phase stamps, rocprofv3 kernel trace of the
+# bench command, PMC passes (HBM traffic, SQ issue counters), the N > 1 dry runs.
+# usage (repo root on the GPU box): bash tools/gpu_round.sh <tag> [quick]
+tag=${1:-r02}; quick=$2
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --timeout 600 --durations=5 > gpurun_out/gpu_tests_$tag.log 2>&1
+python -m pytest tests -m gpu -q --timeout 900 --durations=8 -s > gpurun_out/gpu_tests_$tag.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/gpu_tests_$tag.log
-tail -8 gpurun_out/gpu_tests_$tag.log
+grep -E "structurally compared|passed|failed|error" gpurun_out/gpu_tests_$tag.log | tail -12
 python __graft_entry__.py smoke 2>&1 | tail -1
-python bench.py > gpurun_out/bench_cfg2_$tag.json 2> gpurun_out/bench_cfg2_$tag.err
-cat gpurun_out/bench_cfg2_$tag.json
-python bench.py --config 3 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out/bench_cfg3_$tag.json 2> gpurun_out/bench_cfg3_$tag.err
-cat gpurun_out/bench_cfg3_$tag.json
-python bench.py --config 5 --steps 100 --warmup 10 --cpu-seconds 10 > gpurun_out/bench_cfg5_$tag.json 2> gpurun_out/bench_cfg5_$tag.err
-cat gpurun_out/bench_cfg5_$tag.json
-# the N > 1 step on a one-rank RCCL group (what the multi-rank path costs before any link): both exchange forms
-for ex in gathered alltoall; do
-  PHD_BENCH_EXCHANGE=$ex PHD_BENCH_ONE_RANK_RCCL=1 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 2> /dev/null | grep metric > gpurun_out/bench_cfg2_onerank_${ex}_$tag.json
-  cat gpurun_out/bench_cfg2_onerank_${ex}_$tag.json | cut -c1-160
-done
-python tools/phase_profile.py 2 3 > gpurun_out/phase_$tag.log 2>&1
+# exactly what the driver runs
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_$tag.json 2> gpurun_out/bench_driver_$tag.err
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench_driver_$tag.json").read().strip().splitlines()[-1])
+print("driver-style: %.1f steps/s (%.4f ms) preroll %d | cpu %s" % (d["value"], d["ms_per_step"], d["preroll_steps"], (d["cpu_baseline"] or {}).get("value")))
+for s in d["secondary"]:
+    print("   secondary:", s["config"]["workload"][:48], "%.1f steps/s" % s["value"])
+PY
+# a long run of the headline for comparison (the 3 % criterion)
+python bench.py --steps 400 --warmup 40 --no-secondary --cpu-seconds 0 > gpurun_out/bench_cfg3_long_$tag.json 2> gpurun_out/bench_cfg3_long_$tag.err
+python -c "import json;d=json.loads(open('gpurun_out/bench_cfg3_long_$tag.json').read().strip().splitlines()[-1]);print('long run: %.1f steps/s, stages %s' % (d['value'], d['stages_us_per_workgroup']))"
+python tools/phase_profile.py 2 3 5 > gpurun_out/phase_$tag.log 2>&1
+[ -n "$quick" ] && exit 0
 (python tools/e2e_run.py 256; python tools/e2e_run.py 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/e2e_$tag.log
 cat gpurun_out/e2e_$tag.log
+# the N > 1 paths on this one GPU: two ranks sharing device 0 (gloo transport) on the configs[3] split, one-rank RCCL
+PHD_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+  bench.py --gpus 2 --steps 5 --warmup 2 --preroll-ms 0 2> gpurun_out/bench_share2_$tag.err | grep metric > gpurun_out/bench_share2_$tag.json
+cut -c1-400 gpurun_out/bench_share2_$tag.json
+for ex in gathered alltoall; do
+  PHD_BENCH_EXCHANGE=$ex PHD_BENCH_ONE_RANK_RCCL=1 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 2> /dev/null | grep metric > gpurun_out/bench_cfg2_onerank_${ex}_$tag.json
+  cut -c1-200 gpurun_out/bench_cfg2_onerank_${ex}_$tag.json
+done
 cd /tmp && export TMPDIR=/tmp
-for cfg in 2 3 5; do
-  st=2000; wu=200; [ $cfg != 2 ] && st=50 && wu=40
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --steps $st --warmup $wu --cpu-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag.log 2>&1
+for cfg in 3 2 5; do
+  st=50; wu=40; [ $cfg = 2 ] && st=2000 && wu=200
+  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --bare --steps $st --warmup $wu > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag.log 2>&1
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_cfg${cfg}_$tag -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_cfg${cfg}_$tag.csv && head -5 $f
+  [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_cfg${cfg}_$tag.csv && head -4 $f
 done
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_traffic.sh 2 $tag
 bash tools/pmc_traffic.sh 3 $tag
+bash tools/pmc_traffic.sh 2 $tag
 bash tools/pmc_sq.sh 3 $tag > gpurun_out/sq_counters_$tag.txt 2>&1
 bash tools/pmc_sq.sh 2 $tag >> gpurun_out/sq_counters_$tag.txt 2>&1
+tail -3 gpurun_out/sq_counters_$tag.txt | cut -c1-600
