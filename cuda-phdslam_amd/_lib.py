@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphdslam.so")
+# PHD_LIB: an A/B build of the same library (make variant NAME=..., tools/ab_bench.sh); default: the product
+LIB_PATH = os.environ.get("PHD_LIB") or os.path.join(_HERE, "libphdslam.so")
 
 GAUSSIAN = np.dtype([("cov", np.float32, 4), ("mean", np.float32, 2), ("weight", np.float32)])
 POSE = np.dtype([("px", np.float32), ("py", np.float32), ("ptheta", np.float32),

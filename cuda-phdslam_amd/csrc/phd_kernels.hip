@@ -278,6 +278,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                            : safe_log(cfg.minFeatureWeight) + safe_log(cfg.clutterDensity + cfg.birthWeight) - 1e-3f;
     int ncw = 0; // terms listed by this wave
     // ---- pass 1: normalisers ----------------------------------------------------------------------
+#ifdef PHD_DUP_PASS1   // throughput experiment (tools/ab_bench.sh): the phase runs PHD_DUP_PASS1 extra times, same results
+    for (int dup_ = 0; dup_ <= PHD_DUP_PASS1; ++dup_) { ncw = 0; __builtin_amdgcn_sched_barrier(0);
+#endif
     for (int mt = 0; mt < m_tiles; ++mt) {
         const int m = mt * 64 + lm;
         const bool mvalid = (m < M) && L.zok[m < M ? m : 0];
@@ -306,6 +309,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         for (int off = Mp; off < 64; off <<= 1) acc += xor_lane(acc, off);
         if (js == 0 && m < M) L.zpart[wave * A.MM + m] = acc;
     }
+#ifdef PHD_DUP_PASS1
+    }
+#endif
     if (sparse2 && lane == 0) L.ctr[CTR_TMP + wave] = ncw; // the per-wave slots are free between the classification and the merge
     __syncthreads();
     float lz_local = 0.f;

@@ -19,6 +19,9 @@ typedef LDS_T(u32)* lds_u32;
 typedef LDS_T(u16)* lds_u16;
 typedef LDS_T(unsigned char)* lds_u8;
 
+// merge rounds: window copy (pos[64] | gA[64] | gB[64]) + the round's seed records (2 x 72 float4), behind the sort arrays
+#define PHD_RWIN_BYTES (4u * 64u + 2u * 16u * 64u + 2u * 16u * 72u)
+
 struct LdsOffsets {
     u32 w, mx, my, xx, xy, yy, tr, u;
     u32 alias;      // start of the aliased region
@@ -38,7 +41,7 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     o.alias = p;
     const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C) + 2u * align16u(16u * (u32)C) +
                      align16u(4u * (u32)C);
-    const u32 sort1 = 3u * sv;
+    const u32 sort1 = 3u * sv + PHD_RWIN_BYTES;   // sort arrays / round lists + the rounds' window and seed records
     const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
     u32 amax = feat > sort1 ? feat : sort1;
     amax = amax > sort2 ? amax : sort2;
@@ -65,6 +68,12 @@ struct Lds {
     lds_f32 w, mx, my, xx, xy, yy;
     lds_f32 tr; // trace of the covariance (+inf if not SPD): cheap far-pair filter of the merge
     lds_i32 u; // slab index (sort tie-break); after the sort: cluster assignment
+    // the same 32 S bytes as two float4 arrays, the layout of the SORTED survivors in the round-based merge (S > 256):
+    //   gA[i] = (mean x, mean y, E, weight)   E = |mean|^2 (1 - 2e-6) - 0.505 T tr: the far-pair filter's per-Gaussian term
+    //   gB[i] = (cov xx, cov xy, cov yy, cluster assignment as int bits)
+    // one ds_read_b128 per use instead of three to six ds_read_b32 with their address arithmetic
+    LDS_T(v4f)* gA;
+    LDS_T(v4f)* gB;
     // aliased region
     LDS_T(v4f)* f_a;                           // per in-range feature: (r, b, S00, S01+S10)
     LDS_T(v2f)* f_c;                           //                       (S11, folded log-weight base)
@@ -75,6 +84,7 @@ struct Lds {
     lds_u32 khi, klo, pay;                        // sort 1
     lds_u32 key2;                                 // sort 2
     lds_i32 seg;                                  // cluster starts, S+1
+    lds_f32 rwin;                                 // merge rounds: window copy + seed records (PHD_RWIN_BYTES), behind khi/klo/pay
     LDS_T(u64)* srow;                             // merge_small: [256][4] closeness to earlier positions
     LDS_T(u64)* scol;                             // merge_small: [256][4] members of the cluster seeded at a position
     LDS_T(u64)* sseed;                            // merge_small: [4] seed mask
@@ -86,7 +96,7 @@ struct Lds {
     lds_u32 zok;                      // MM
     lds_f32 bgeo;                     // 5*MM: birth mean and covariance per measurement
     lds_u32 part;                     // 4*64 row parts of the window closeness matrix
-    lds_f32 win;                      // 7*64: the window's candidates (pos, mx, my, tr, xx, xy, yy)
+    lds_f32 win;                      // 7*64 floats: with `part` the candidate list of pass 1 / 2
     lds_f32 red;                      // PHD_NW + 4
     lds_i32 ctr;                      // 32 counters
 };
@@ -98,6 +108,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.w = (lds_f32)(base + o.w); L.mx = (lds_f32)(base + o.mx); L.my = (lds_f32)(base + o.my);
     L.xx = (lds_f32)(base + o.xx); L.xy = (lds_f32)(base + o.xy); L.yy = (lds_f32)(base + o.yy);
     L.tr = (lds_f32)(base + o.tr); L.u = (lds_i32)(base + o.u);
+    L.gA = (LDS_T(v4f)*)(base + o.w); L.gB = (LDS_T(v4f)*)(base + o.xy);
     u32 f = o.alias;
     L.f_a = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
     L.f_c = (LDS_T(v2f)*)(base + f); f += align16u(8u * (u32)C);
@@ -111,6 +122,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.pay = (lds_u32)(base + o.alias + 2u * sv);
     L.key2 = (lds_u32)(base + o.alias);
     L.seg = (lds_i32)(base + o.alias + sv);
+    L.rwin = (lds_f32)(base + o.alias + 3u * sv);
     L.srow = (LDS_T(u64)*)(base + o.alias);
     L.scol = (LDS_T(u64)*)(base + o.alias + PHD_SMALL_S * 32u);
     L.sseed = (LDS_T(u64)*)(base + o.alias + 2u * PHD_SMALL_S * 32u);

@@ -372,14 +372,17 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     if (S == 0) { __syncthreads(); return; }
     if (S <= PHD_SMALL_S) { merge_small<HELLINGER, STAMPS>(L, S_cap, S, cfg, out_slab, cap, tid, st, n_update); return; }
 
-    // ---- sort 1: (weight desc, slab index asc) ------------------------------------------------
+    // ---- sort 1: (weight desc, slab index asc); leaves the survivors as the float4 arrays gA / gB ----
     int n_pad = 2;
     while (n_pad < S) n_pad <<= 1;
-    if (bucket_sort_survivors(L, S, S_cap, tid, lane, wave, n_update)) { /* counting sort did it */ }
-    else if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid, n_update);
-    else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid, n_update, packed);
-    else if (n_pad <= 4 * PHD_T) sort_survivors<4>(L, S, n_pad, tid, n_update, packed);
-    else sort_survivors<8>(L, S, n_pad, tid, n_update, packed);
+    if (bucket_sort_survivors(L, S, S_cap, tid, lane, wave, n_update, Tpre, HELLINGER)) { /* counting sort did it */ }
+    else {
+        if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid, n_update);
+        else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid, n_update, packed);
+        else if (n_pad <= 4 * PHD_T) sort_survivors<4>(L, S, n_pad, tid, n_update, packed);
+        else sort_survivors<8>(L, S, n_pad, tid, n_update, packed);
+        planes_to_aos(L, S, tid, Tpre, HELLINGER);
+    }
     STAMP(6);
 
     // ---- rounds: 64 live candidates at a time ---------------------------------------------------
@@ -387,18 +390,19 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // them form the window: their pairwise closeness decides which are seeds (a candidate is a seed
     // iff no earlier seed is close to it), every later survivor is assigned to the first seed it is
     // close to, and the list is compacted.  Exactly the reference's greedy loop, 64 seeds at a time.
-    lds_i32 assign = L.u;
+    //
+    // Far-pair filter (filter_term(), phd_sort.h): pair (a, b) is a candidate iff E_a + E_b - 2 ma.mb < 0.  One side
+    // of every test is wave-uniform (a window column / a seed) and sits in scalar registers, so a pair costs one
+    // packed add, two packed FMAs for TWO pairs, and one v_alignbit per pair that shifts the sign bit into the mask.
+    LDS_T(v4f)* const gA = L.gA;
+    LDS_T(v4f)* const gB = L.gB;
+    LDS_T(int)* const asg = (LDS_T(int)*)L.gB;           // cluster assignment of survivor i: asg[4 i + 3]
     lds_u16 ul_a = (lds_u16)L.pay, ul_b = ul_a + S_cap;  // two u16 lists in the (free) sort-payload region
-    LDS_T(u64)* cmask = (LDS_T(u64)*)L.khi;              // candidate-seed mask per listed survivor (khi+klo)
-#if PHD_NW == 4
-    typedef u16 cmw_t;
-#else
-    typedef unsigned char cmw_t;
-#endif
-    LDS_T(cmw_t)* cmw = (LDS_T(cmw_t)*)L.khi;
-    lds_i32 wpos = (lds_i32)L.win;
-    lds_f32 wmx = L.win + 64, wmy = L.win + 128, wtr = L.win + 192, wxx = L.win + 256, wxy = L.win + 320,
-            wyy = L.win + 384;
+    lds_i32 wpos = (lds_i32)L.rwin;
+    LDS_T(v4f)* const wA = (LDS_T(v4f)*)(L.rwin + 64);         // the window's copy of gA / gB
+    LDS_T(v4f)* const wB = (LDS_T(v4f)*)(L.rwin + 64 + 256);
+    LDS_T(v4f)* const sF = (LDS_T(v4f)*)(L.rwin + 64 + 512);          // the round's seeds in order: (-2 mx, -2 my, E, survivor index)
+    LDS_T(v4f)* const sG = sF + 72;                                  //                             (cov xx, xy, yy, -)
     for (int i = tid; i < S; i += PHD_T) ul_a[i] = (u16)i;
     int n_u = S;
     lds_u16 cur = ul_a, nxt = ul_b;
@@ -412,34 +416,50 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         if (tid < 64) {
             const int i = cur[tid < nwin ? tid : nwin - 1];
             wpos[tid] = i;
-            wmx[tid] = L.mx[i]; wmy[tid] = L.my[i]; wtr[tid] = (tid < nwin) ? L.tr[i] : -INFINITY;
-            wxx[tid] = L.xx[i]; wxy[tid] = L.xy[i]; wyy[tid] = L.yy[i];
+            v4f a = gA[i];
+            if (tid >= nwin) a.z = INFINITY;               // padding: never a candidate
+            wA[tid] = a;
+            wB[tid] = gB[i];
         }
         __syncthreads();
+        // every wave holds the window in registers, lane l <-> candidate l; a column's terms reach the scalar
+        // registers through v_readlane
+        const v4f ka = wA[lane];
+        const float kx = ka.x, ky = ka.y, kE = ka.z;
+        const float m2x = -2.f * kx, m2y = -2.f * ky;
         // (1) closeness matrix rows: lane = candidate k, wave = column block [COLS*wave, COLS*(wave+1)).
-        //     A cheap conservative filter (d >= 2|dm|^2/(tr Pa + tr Pb) for SPD covariances, 1 % guard
-        //     band) marks candidate columns; the exact test runs on the marked bits only.
+        //     The filter marks candidate columns; the exact test runs on the marked bits only.
+#ifdef PHD_DUP_MATRIX
+        for (int dup_ = 0; dup_ <= PHD_DUP_MATRIX; ++dup_)
+#endif
         {
+#ifdef PHD_DUP_MATRIX
+            asm volatile("" ::: "memory");
+#endif
             const int k = lane;
-            const bool kvalid = k < nwin;
-            const float kmx = wmx[k], kmy = wmy[k], ktr = wtr[k];
             u32 cand = 0;
-#pragma unroll 4
-            for (int c = 0; c < PHD_COLS; ++c) {
+            const v2f kE2 = (v2f){kE, kE}, kx2 = (v2f){kx, kx}, ky2 = (v2f){ky, ky};
+#pragma unroll
+            for (int c = PHD_COLS - 2; c >= 0; c -= 2) {      // descending: v_alignbit shifts the mask left
                 const int l = wave * PHD_COLS + c;
-                const float dx = wmx[l] - kmx, dy = wmy[l] - kmy;
-                const bool near = HELLINGER || !(2.f * (dx * dx + dy * dy) >= Tpre * (wtr[l] + ktr));
-                if (kvalid && l < k && near) cand |= (1u << c);
+                v2f t = (v2f){lane_f(kE, l), lane_f(kE, l + 1)} + kE2;
+                t = __builtin_elementwise_fma((v2f){lane_f(m2x, l), lane_f(m2x, l + 1)}, kx2, t);
+                t = __builtin_elementwise_fma((v2f){lane_f(m2y, l), lane_f(m2y, l + 1)}, ky2, t);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(t.y), 31);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(t.x), 31);
             }
+            // only earlier candidates count (l < k), and only rows of real candidates
+            const int nlt = k - wave * PHD_COLS;
+            cand &= (k >= nwin || nlt <= 0) ? 0u : (nlt >= PHD_COLS ? ((1u << PHD_COLS) - 1u) : ((1u << nlt) - 1u));
             u32 bits = 0;
             if (cand) {
-                const float kxx = wxx[k], kxy = wxy[k], kyy = wyy[k];
+                const v4f kb = wB[k];
                 while (cand) {
                     const int c = __builtin_ctz(cand);
                     cand &= cand - 1;
                     const int l = wave * PHD_COLS + c;
-                    if (is_close<HELLINGER>(wmx[l], wmy[l], wxx[l], wxy[l], wyy[l], kmx, kmy, kxx, kxy, kyy, T))
-                        bits |= (1u << c);
+                    const v4f la = wA[l], lb = wB[l];
+                    if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, kx, ky, kb.x, kb.y, kb.z, T)) bits |= (1u << c);
                 }
             }
             L.part[wave * 64 + k] = bits;
@@ -464,81 +484,82 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             }
             if (wave == 0 && lane < nwin) {
                 const int owner = ((seeds >> lane) & 1ull) ? lane : __builtin_ctzll(row & seeds);
-                assign[wpos[lane]] = wpos[owner];
+                asg[4 * wpos[lane] + 3] = wpos[owner];
             }
         }
         if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
-        // (3a) cheap filter for the survivors after the window: wave w owns the window's candidates
-        //      [COLS*w, COLS*(w+1)) and sweeps all listed survivors, 64 (one per lane) at a time ->
-        //      COLS candidate-seed bits per (survivor, wave), stored as one field of the survivor's u64
+        // (3) the survivors after the window.  The round's SEEDS (typically 40 of the 64 candidates) are listed in
+        //     order as records (-2 mx, -2 my, E, window index); every wave writes the same list (identical values), so
+        //     it needs no barrier before reading it back.  The listed survivors are dealt to the waves in blocks of 64,
+        //     one survivor per lane: the lane tests its survivor against ALL seeds (records by LDS broadcast, two seeds
+        //     per packed operation, the sign bit of E_s + E_e - 2 ms.me shifted into a 64-bit mask whose ascending bits
+        //     are ascending seed order) and, in the same pass, takes the exact decision on the marked seeds until the
+        //     first hit.  One trip through LDS per survivor and round.
+        const int nseeds = __popcll(seeds);
         {
-            const u32 myseeds = (u32)(seeds >> (PHD_COLS * wave)) & ((1u << PHD_COLS) - 1u);
-            // the wave's candidates are the same for the whole sweep: read them once and keep them in scalar registers
-            // (the sweep is bound by LDS return bandwidth — a broadcast read still returns a full wave of data)
-            float smx[PHD_COLS], smy[PHD_COLS], str[PHD_COLS];
-#pragma unroll
-            for (int c = 0; c < PHD_COLS; ++c) {
-                const int l = PHD_COLS * wave + c;
-                smx[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wmx[l])));
-                smy[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wmy[l])));
-                // the filter's right-hand side Tpre (tr_l + tr_e) / 2 is split into a per-candidate and a per-survivor half
-                // (it is a conservative bound with a 1 % guard band: the rounding of the split is immaterial)
-                str[c] = 0.5f * Tpre * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wtr[l])));
+            const int rank = __popcll(seeds & lanemask_lt());
+            if ((seeds >> lane) & 1ull) {
+                sF[rank] = (v4f){m2x, m2y, kE, __int_as_float(wpos[lane])};
+                sG[rank] = wB[lane];
             }
-            for (int e0 = 0; e0 < nrest; e0 += 64) {
-                const int e = e0 + lane;
-                u32 mbits = 0;
-                if (myseeds) {
-                    float emx = 0, emy = 0, etr = -INFINITY; // -inf trace: the filter rejects
-                    if (e < nrest) { const int i = cur[64 + e]; emx = L.mx[i]; emy = L.my[i]; etr = L.tr[i]; }
-                    const float eth = 0.5f * Tpre * etr;
-#pragma unroll
-                    for (int g = 0; g < PHD_COLS / 4; ++g) {
-                        if (!((myseeds >> (4 * g)) & 0xFu)) continue; // uniform
-#pragma unroll
-                        for (int q = 0; q < 4; q += 2) { // two candidates per step: packed arithmetic
-                            const int c = 4 * g + q;
-                            const v2f dx = (v2f){smx[c], smx[c + 1]} - (v2f){emx, emx};
-                            const v2f dy = (v2f){smy[c], smy[c + 1]} - (v2f){emy, emy};
-                            const v2f lhs = dx * dx + dy * dy;
-                            const v2f rhs = (v2f){str[c], str[c + 1]} + (v2f){eth, eth};
-                            const bool near0 = HELLINGER ? (etr > -INFINITY) : !(lhs.x >= rhs.x);
-                            const bool near1 = HELLINGER ? (etr > -INFINITY) : !(lhs.y >= rhs.y);
-                            mbits |= (near0 ? (1u << c) : 0u) | (near1 ? (2u << c) : 0u);
-                        }
-                    }
-                    mbits &= myseeds;
-                }
-                if (e < nrest) cmw[e * PHD_NW + wave] = (cmw_t)mbits;
-            }
+            if (lane < 8) sF[nseeds + lane] = (v4f){0.f, 0.f, INFINITY, 0.f};   // pad to a multiple of 8: never a candidate
         }
-        __syncthreads();
-        // (3b) exact test on the candidates only, in seed order, until the first hit; then the ordered
-        //      compaction of the list (thread t owns the contiguous entries [t*per, (t+1)*per))
-        {
-            const int per = (nrest + PHD_T - 1) / PHD_T;
-            const int e_lo = tid * per, e_hi = (e_lo + per < nrest) ? e_lo + per : nrest;
-            int kept = 0;
-            for (int e = e_lo; e < e_hi; ++e) {
-                const int i = cur[64 + e];
-                u64 m = cmask[e];
-                bool merged = false;
-                if (m) {
-                    const float fmx = L.mx[i], fmy = L.my[i], fxx = L.xx[i], fxy = L.xy[i], fyy = L.yy[i];
-                    while (m) {
-                        const int l = __builtin_ctzll(m);
-                        m &= m - 1;
-                        if (is_close<HELLINGER>(wmx[l], wmy[l], wxx[l], wxy[l], wyy[l], fmx, fmy, fxx, fxy, fyy, T)) {
-                            assign[i] = wpos[l];
-                            merged = true;
-                            break;
-                        }
+        const int per = (nrest + PHD_T - 1) / PHD_T;           // entries per thread
+        int kept = 0;
+        u32 keepbits = 0;                                       // bit q: this thread's q-th entry stays listed
+#ifdef PHD_DUP_ASSIGN
+        for (int dup_ = 0; dup_ <= PHD_DUP_ASSIGN; ++dup_) { kept = 0; keepbits = 0; asm volatile("" ::: "memory");
+#endif
+        for (int q = 0; q < per; ++q) {
+            // thread t owns the contiguous entries [t per, (t + 1) per) of the list (what the ordered compaction needs)
+            const int e = tid * per + q;
+            const bool ev = e < nrest;
+            if (__ballot(ev) == 0ull) break;                    // uniform: nothing left for this wave
+            const int i = ev ? cur[64 + e] : 0;
+            v4f ea = gA[i];
+            const v4f fb = gB[i];
+            if (!ev) ea.z = INFINITY;
+            const v2f eE2 = (v2f){ea.z, ea.z}, ex2 = (v2f){ea.x, ea.x}, ey2 = (v2f){ea.y, ea.y};
+            u32 mlo = 0, mhi = 0;
+            // eight seeds per trip, their records requested together (LDS broadcast reads), descending: v_alignbit
+            // shifts the mask left
+#define PHD_SEED_PAIR(M, f0, f1) do {                                                                  \
+                v2f t_ = (v2f){(f0).z, (f1).z} + eE2;                                                    \
+                t_ = __builtin_elementwise_fma((v2f){(f0).x, (f1).x}, ex2, t_);                          \
+                t_ = __builtin_elementwise_fma((v2f){(f0).y, (f1).y}, ey2, t_);                          \
+                M = __builtin_amdgcn_alignbit(M, __float_as_uint(t_.y), 31);                             \
+                M = __builtin_amdgcn_alignbit(M, __float_as_uint(t_.x), 31); } while (0)
+#define PHD_SEED_OCTET(M, r) do {                                                                      \
+                const v4f f0 = sF[(r) + 0], f1 = sF[(r) + 1], f2 = sF[(r) + 2], f3 = sF[(r) + 3],        \
+                          f4 = sF[(r) + 4], f5 = sF[(r) + 5], f6 = sF[(r) + 6], f7 = sF[(r) + 7];        \
+                PHD_SEED_PAIR(M, f6, f7); PHD_SEED_PAIR(M, f4, f5); PHD_SEED_PAIR(M, f2, f3); PHD_SEED_PAIR(M, f0, f1); } while (0)
+            const int ntop = (nseeds + 7) & ~7;
+            for (int r = ntop - 8; r >= 32; r -= 8) PHD_SEED_OCTET(mhi, r);
+            for (int r = (ntop < 32 ? ntop : 32) - 8; r >= 0; r -= 8) PHD_SEED_OCTET(mlo, r);
+#undef PHD_SEED_OCTET
+#undef PHD_SEED_PAIR
+            u64 m = ((u64)mhi << 32) | mlo;
+            m &= (nseeds == 64) ? ~0ull : ((1ull << nseeds) - 1ull);   // (inf - inf in the padding has no defined sign)
+            bool merged = false;
+            if (ev) {
+                while (m) {
+                    const int r = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const v4f f = sF[r], g = sG[r];             // the seed's mean is -(−2 m)/2, exactly
+                    if (is_close<HELLINGER>(-0.5f * f.x, -0.5f * f.y, g.x, g.y, g.z, ea.x, ea.y, fb.x, fb.y, fb.z, T)) {
+                        asg[4 * i + 3] = __float_as_int(f.w);
+                        merged = true;
+                        break;
                     }
                 }
-                if (!merged) kept++;
-                cmask[e] = merged ? 0ull : 1ull; // reuse as the keep flag of the compaction
             }
-            // exclusive scan of `kept` over the workgroup (wave shuffle scan + wave totals)
+            if (ev && !merged) { kept++; keepbits |= 1u << q; }
+        }
+#ifdef PHD_DUP_ASSIGN
+        }
+#endif
+        // ordered compaction of the list: exclusive scan of `kept` over the workgroup (wave scan + wave totals)
+        {
             const int incl = (int)wave_incl_scan((u32)kept);
             if (lane == 63) L.ctr[CTR_TMP + wave] = incl;
             __syncthreads();
@@ -550,8 +571,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 total += c;
             }
             int o = woff + incl - kept;
-            for (int e = e_lo; e < e_hi; ++e)
-                if (cmask[e]) nxt[o++] = cur[64 + e];
+            for (int q = 0; q < per; ++q)
+                if ((keepbits >> q) & 1u) nxt[o++] = cur[64 + tid * per + q];
             n_u = total;
             __syncthreads();
             lds_u16 t2 = cur; cur = nxt; nxt = t2;
@@ -575,7 +596,13 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         lds_u32 cnt = L.pay;                    // per seed: member count -> packed exclusive prefix
         for (int i = tid; i < S; i += PHD_T) { cnt[i] = 0u; cursor[i] = 0u; }
         __syncthreads();
-        for (int i = tid; i < S; i += PHD_T) atomicAdd((u32*)&cnt[assign[i]], 1u);
+        int sreg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + e * PHD_T;
+            sreg[e] = 0;
+            if (i < S) { sreg[e] = asg[4 * i + 3]; atomicAdd((u32*)&cnt[sreg[e]], 1u); }
+        }
         __syncthreads();
         const int per = (S + PHD_T - 1) / PHD_T; // <= 4 (S <= 2048)
         u32 total;
@@ -585,7 +612,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int sd = lo + e;
-                v[e] = (e < per && sd < S) ? (cnt[sd] | ((assign[sd] == sd) ? 0x10000u : 0u)) : 0u;
+                v[e] = (e < per && sd < S) ? (cnt[sd] | ((asg[4 * sd + 3] == sd) ? 0x10000u : 0u)) : 0u;
                 local += v[e];
             }
             const u32 incl = wave_incl_scan(local);
@@ -607,16 +634,11 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             }
         }
         __syncthreads();
-        int sreg[4], pos[4];
+        int pos[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = tid + e * PHD_T;
-            sreg[e] = 0;
-            if (i < S) {
-                const int sd = assign[i];
-                sreg[e] = sd;
-                members[(cnt[sd] & 0xFFFFu) + atomicAdd((u32*)&cursor[sd], 1u)] = (u32)i;
-            }
+            if (i < S) members[(cnt[sreg[e]] & 0xFFFFu) + atomicAdd((u32*)&cursor[sreg[e]], 1u)] = (u32)i;
         }
         __syncthreads();
 #pragma unroll
@@ -635,7 +657,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         for (int e = 0; e < 4; ++e) {
             const int i = tid + e * PHD_T;
             if (i < S) {
-                L.key2[pos[e]] = ((u32)sreg[e] << 16) | (u32)i;                    // key2 aliases cursor
+                // the grouped list holds the member's BYTE OFFSET into gA / gB (16 i < 2^15): one ds_read_u16 away
+                L.key2[pos[e]] = ((u32)sreg[e] << 16) | ((u32)i << 4);             // key2 aliases cursor
                 if (sreg[e] == i) L.seg[cnt[i] >> 16] = (int)(cnt[i] & 0xFFFFu);   // seg aliases members
             }
         }
@@ -647,26 +670,43 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     STAMP(9);
 
     // ---- moment matching: one lane per cluster, sequential in (weight desc) order ----------------
-    // (two trips over the lanes' clusters: first find where the reference's loop would stop)
+    // (src/gm_reduce.cpp:103-118's order; the loads of four members are issued together, the sums stay sequential)
     if (tid == 0) atomicMin((int*)&L.ctr[CTR_KOUT], n_clusters);   // as in merge_small
+    const LDS_T(u16)* const koff = (const LDS_T(u16)*)L.key2;      // low half of entry j: koff[2 j]
+    const LDS_T(unsigned char)* const gAb = (const LDS_T(unsigned char)*)gA;
+    const LDS_T(unsigned char)* const gBb = (const LDS_T(unsigned char)*)gB;
+#define PHD_GA(off) (*(const LDS_T(v4f)*)(gAb + (off)))
+#define PHD_GB(off) (*(const LDS_T(v4f)*)(gBb + (off)))
+#ifdef PHD_DUP_MOMENTS
+    for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
+#endif
     for (int c0 = 0; c0 < n_clusters; c0 += PHD_T) {
 #pragma clang fp contract(off)
+#ifdef PHD_DUP_MOMENTS
+        asm volatile("" ::: "memory");
+#endif
         const int c = c0 + tid;
         if (c < n_clusters) {
             const int b = L.seg[c], e = L.seg[c + 1];
-            const int sp = (int)(L.key2[b] & 0xFFFFu); // the seed (first in sorted order)
-            const float smx = L.mx[sp], smy = L.my[sp], sxx = L.xx[sp], sxy = L.xy[sp], syy = L.yy[sp];
+            const v4f sa = PHD_GA(koff[2 * b]), sb = PHD_GB(koff[2 * b]); // the seed (first in sorted order)
+            const float smx = sa.x, smy = sa.y, sxx = sb.x, sxy = sb.y, syy = sb.z;
             float dself = HELLINGER ? hellinger_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy)
                                     : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
             const bool selfok = dself < T;
             const int b0 = selfok ? b : b + 1; // a seed that is not close to itself is not in its own cluster
             float W = 0.f, sx = 0.f, sy = 0.f;
-            for (int i = b0; i < e; ++i) {
-                const int p = (int)(L.key2[i] & 0xFFFFu);
-                const float w = L.w[p];
-                W += w;
-                sx += w * L.mx[p];
-                sy += w * L.my[p];
+            int i = b0;
+            for (; i + 4 <= e; i += 4) {
+                const u32 o0 = koff[2 * i], o1 = koff[2 * i + 2], o2 = koff[2 * i + 4], o3 = koff[2 * i + 6];
+                const v4f a0 = PHD_GA(o0), a1 = PHD_GA(o1), a2 = PHD_GA(o2), a3 = PHD_GA(o3);
+                W += a0.w; sx += a0.w * a0.x; sy += a0.w * a0.y;
+                W += a1.w; sx += a1.w * a1.x; sy += a1.w * a1.y;
+                W += a2.w; sx += a2.w * a2.x; sy += a2.w * a2.y;
+                W += a3.w; sx += a3.w * a3.x; sy += a3.w * a3.y;
+            }
+            for (; i < e; ++i) {
+                const v4f a0 = PHD_GA(koff[2 * i]);
+                W += a0.w; sx += a0.w * a0.x; sy += a0.w * a0.y;
             }
             // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked
             // and then yields W == 0
@@ -677,15 +717,22 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             if (W != 0.f && c < cap) {
                 const float mx = sx / W, my = sy / W;
                 float cxx = 0.f, cxy = 0.f, cyy = 0.f;
-                for (int i = b0; i < e; ++i) {
-                    const int p = (int)(L.key2[i] & 0xFFFFu);
-                    const float w = L.w[p];
-                    const float d0 = mx - L.mx[p];
-                    const float d1 = my - L.my[p];
-                    cxx += w * (L.xx[p] + d0 * d0);
-                    cxy += w * (L.xy[p] + d0 * d1);
-                    cyy += w * (L.yy[p] + d1 * d1);
+#define PHD_COV_ACC(a, bq) do { const float d0 = mx - (a).x, d1 = my - (a).y;                 \
+                                cxx += (a).w * ((bq).x + d0 * d0); cxy += (a).w * ((bq).y + d0 * d1); \
+                                cyy += (a).w * ((bq).z + d1 * d1); } while (0)
+                i = b0;
+                for (; i + 4 <= e; i += 4) {
+                    const u32 o0 = koff[2 * i], o1 = koff[2 * i + 2], o2 = koff[2 * i + 4], o3 = koff[2 * i + 6];
+                    const v4f a0 = PHD_GA(o0), a1 = PHD_GA(o1), a2 = PHD_GA(o2), a3 = PHD_GA(o3);
+                    const v4f q0 = PHD_GB(o0), q1 = PHD_GB(o1), q2 = PHD_GB(o2), q3 = PHD_GB(o3);
+                    PHD_COV_ACC(a0, q0); PHD_COV_ACC(a1, q1); PHD_COV_ACC(a2, q2); PHD_COV_ACC(a3, q3);
                 }
+                for (; i < e; ++i) {
+                    const u32 o0 = koff[2 * i];
+                    const v4f a0 = PHD_GA(o0), q0 = PHD_GB(o0);
+                    PHD_COV_ACC(a0, q0);
+                }
+#undef PHD_COV_ACC
                 out_slab[0 * cap + c] = W;
                 out_slab[1 * cap + c] = mx;
                 out_slab[2 * cap + c] = my;
@@ -695,6 +742,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             }
         }
     }
+#undef PHD_GA
+#undef PHD_GB
     __syncthreads();
     STAMP(10);
 }

@@ -227,7 +227,44 @@ __device__ __forceinline__ void rank_sort_survivors(const Lds& L, int S, int tid
 // survivor's rank is its bucket's start plus the number of larger keys in its own bucket.  A quarter of the
 // instructions of the register bitonic sort.  Returns false (uniformly, before anything the network needs is
 // touched) when a bucket is crowded — many equal weights — and the network is the better tool.
-__device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S_cap, int tid, int lane, int wave, int n_update)
+// the far-pair filter's per-Gaussian term (see Lds::gA): pair (a, b) can be within the merge distance only if
+//   |ma - mb|^2 < 0.505 T (tr Pa + tr Pb)   <=>   E_a + E_b - 2 ma.mb < 0,   E = |m|^2 - 0.505 T tr P
+// (d >= 2 |dm|^2 / (tr Pa + tr Pb) for SPD covariances; 1 % guard band).  The expanded form costs one add and two FMAs
+// per pair; its cancellation error is below 8 eps (|ma|^2 + |mb|^2), covered by shrinking |m|^2 by 2e-6.  Not SPD:
+// tr = +inf -> E = -inf -> always a candidate.  Tpre = 1.01 T, or -1 when T <= 0 (never a candidate, like the exact test).
+__device__ __forceinline__ float filter_term(float mx, float my, float xx, float xy, float yy, float Tpre, bool hellinger)
+{
+    const bool spd = (xx > 0.f) && (yy > 0.f) && (xx * yy - xy * xy > 0.f);
+    const float tr = spd ? (xx + yy) : INFINITY;
+    if (hellinger) return -INFINITY;                    // the Hellinger metric has no cheap filter: every pair is a candidate
+    return (mx * mx + my * my) * (1.f - 2e-6f) - 0.5f * Tpre * tr;
+}
+
+// sorted SoA planes (what the fall-back sorts leave) -> the float4 arrays gA / gB, in place
+__device__ __forceinline__ void planes_to_aos(const Lds& L, int S, int tid, float Tpre, bool hellinger)
+{
+    float rw[4], rmx[4], rmy[4], rxx[4], rxy[4], ryy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        rw[e] = rmx[e] = rmy[e] = rxx[e] = rxy[e] = ryy[e] = 0.f;
+        if (i < S) { rw[e] = L.w[i]; rmx[e] = L.mx[i]; rmy[e] = L.my[i]; rxx[e] = L.xx[i]; rxy[e] = L.xy[i]; ryy[e] = L.yy[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + e * PHD_T;
+        if (i < S) {
+            L.gA[i] = (v4f){rmx[e], rmy[e], filter_term(rmx[e], rmy[e], rxx[e], rxy[e], ryy[e], Tpre, hellinger), rw[e]};
+            L.gB[i] = (v4f){rxx[e], rxy[e], ryy[e], __int_as_float(-1)};
+        }
+    }
+    __syncthreads();
+}
+
+// (writes the sorted survivors as the float4 arrays gA / gB — see Lds)
+__device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S_cap, int tid, int lane, int wave, int n_update,
+                                                      float Tpre, bool hellinger)
 {
     lds_u32 cntc = L.pay;             // per bucket: count -> (placed << 16) | start
     lds_u32 members = (lds_u32)L.u;   // bucket segments in arrival order (the slab indices live in the keys by then)
@@ -347,11 +384,8 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
         const int i = tid + e * PHD_T;
         if (i < S) {
             const int k = rank[e];
-            L.w[k] = rw[e]; L.mx[k] = rmx[e]; L.my[k] = rmy[e];
-            L.xx[k] = rxx[e]; L.xy[k] = rxy[e]; L.yy[k] = ryy[e];
-            const bool spd = (rxx[e] > 0.f) && (ryy[e] > 0.f) && (rxx[e] * ryy[e] - rxy[e] * rxy[e] > 0.f);
-            L.tr[k] = spd ? (rxx[e] + ryy[e]) : INFINITY;
-            L.u[k] = -1; // unassigned
+            L.gA[k] = (v4f){rmx[e], rmy[e], filter_term(rmx[e], rmy[e], rxx[e], rxy[e], ryy[e], Tpre, hellinger), rw[e]};
+            L.gB[k] = (v4f){rxx[e], rxy[e], ryy[e], __int_as_float(-1)}; // unassigned
         }
     }
     __syncthreads();
