@@ -40,6 +40,7 @@
 #include "phd_lane.h"
 #include "phd_math.h"
 #include "phd_lds.h"
+#include "phd_pass1.h"
 #include "phd_sort.h"
 #include "phd_merge.h"
 #include "phd_predict.h"
@@ -276,54 +277,15 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const bool sparse2 = cfg.minFeatureWeight > 0.f && (n_in * M <= 0xFFFF);
     const float c0m = CPHD ? safe_log(cfg.minFeatureWeight) + safe_log(cfg.birthWeight) - 5e-2f
                            : safe_log(cfg.minFeatureWeight) + safe_log(cfg.clutterDensity + cfg.birthWeight) - 1e-3f;
-    int ncw = 0; // terms listed by this wave
-    // ---- pass 1: normalisers ----------------------------------------------------------------------
-#ifdef PHD_DUP_PASS1   // throughput experiment (tools/ab_bench.sh): the phase runs PHD_DUP_PASS1 extra times, same results
-    for (int dup_ = 0; dup_ <= PHD_DUP_PASS1; ++dup_) { ncw = 0; __builtin_amdgcn_sched_barrier(0);
-#endif
-    for (int mt = 0; mt < m_tiles; ++mt) {
-        const int m = mt * 64 + lm;
-        const bool mvalid = (m < M) && L.zok[m < M ? m : 0];
-        const float zr = L.z_r[m < M ? m : 0], zb = L.z_b[m < M ? m : 0];
-        float acc = 0.f;
-        for (int jb = wave * JS; jb < n_in; jb += PHD_NW * JS) {
-            const int j = jb + js;
-            const int jj = j < n_in ? j : n_in - 1;
-            const v4f fa = L.f_a[jj];
-            const v2f fc = L.f_c[jj];
-            const float i0 = zr - fa.x;
-            const float i1 = wrap_angle(zb - fa.y);
-            const float dist = i0 * i0 * fa.z + i0 * i1 * fa.w + i1 * i1 * fc.x;                       // :1908-1910
-            const float lw = fc.y - 0.5f * dist;
-            const float e = __expf(lw);                                                               // :2205
-            acc += (mvalid && j < n_in) ? e : 0.f;
-            if (sparse2) {
-                // every wave fills its own segment of the list: positions from a ballot, no atomics in the loop
-                const bool cnd = mvalid && (j < n_in) && !(lw < c0m);   // NaN stays a candidate, as in the dense test
-                const u64 bal = __ballot(cnd);
-                const int pos = ncw + __popcll(bal & lanemask_lt());
-                if (cnd && pos < PHD_CAND_SEG) clist[wave * PHD_CAND_SEG + pos] = (u16)(m * n_in + j);
-                ncw += __popcll(bal);
-            }
-        }
-        for (int off = Mp; off < 64; off <<= 1) acc += xor_lane(acc, off);
-        if (js == 0 && m < M) L.zpart[wave * A.MM + m] = acc;
-    }
-#ifdef PHD_DUP_PASS1
-    }
-#endif
-    if (sparse2 && lane == 0) L.ctr[CTR_TMP + wave] = ncw; // the per-wave slots are free between the classification and the merge
+    // ---- pass 1: normalisers (phd_pass1.h) -----------------------------------------------------------
+    const Pass1Grid p1g = pass1_grid(M);
+    pass1_normalisers(L, n_in, M, A.MM, tid, sparse2, c0m);
     __syncthreads();
     float lz_local = 0.f;
     if (CPHD) {
         // roots Xi_m = (lambda/kappa)(sum_j pd w_j g_jm + birthWeight) (.bak:1205-1222)
         const float rat = cfg.clutterRate / cfg.clutterDensity;
-        for (int m = tid; m < M; m += PHD_T) {
-            float sum = L.zpart[0 * A.MM + m];
-#pragma unroll
-            for (int wv = 1; wv < PHD_NW; ++wv) sum += L.zpart[wv * A.MM + m];
-            Q.lxi[m] = (sum + cfg.birthWeight) * rat;
-        }
+        for (int m = tid; m < M; m += PHD_T) Q.lxi[m] = (pass1_feature_sum(L, p1g, m, A.MM) + cfg.birthWeight) * rat;
         const float pdw = block_sum(pdw_local, L.red, tid);
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
@@ -374,9 +336,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         }
     } else {
     for (int m = tid; m < M; m += PHD_T) {
-        float sum = L.zpart[0 * A.MM + m];
-#pragma unroll
-        for (int wv = 1; wv < PHD_NW; ++wv) sum += L.zpart[wv * A.MM + m];
+        float sum = pass1_feature_sum(L, p1g, m, A.MM);
         sum += cfg.clutterDensity;                                                                    // :2213
         sum += cfg.birthWeight;                                                                       // :2214
         const float lz = safe_log(sum);                                                               // :2217
@@ -412,30 +372,13 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // ---- pass 2: final weights; prune before store --------------------------------------------------
     STAMP(3);
     // detection terms
-    int n_cand = 0, seg_max = 0;
-    if (sparse2) {
-#pragma unroll
-        for (int wv = 0; wv < PHD_NW; ++wv) {
-            const int c = L.ctr[CTR_TMP + wv];
-            n_cand += c;
-            seg_max = c > seg_max ? c : seg_max;
-        }
-    }
-    if (sparse2 && seg_max <= PHD_CAND_SEG) {
+    const int n_cand = sparse2 ? L.ctr[CTR_NCAND] : 0;
+    if (sparse2 && n_cand <= PHD_CAND_CAP) {
         const float rcp_nin = 1.0f / (float)(n_in > 0 ? n_in : 1);
         for (int t0 = 0; t0 < n_cand; t0 += PHD_T) {
             const int t = t0 + tid;
             const bool tv = t < n_cand;
-            // entry t of the concatenated segments
-            int sw = 0, so = tv ? t : 0;
-#pragma unroll
-            for (int wv = 0; wv < PHD_NW - 1; ++wv) {
-                const int c = L.ctr[CTR_TMP + wv];
-                const bool next = (sw == wv) && (so >= c);
-                so = next ? so - c : so;
-                sw = next ? wv + 1 : sw;
-            }
-            const int idx = tv ? clist[sw * PHD_CAND_SEG + so] : 0;
+            const int idx = tv ? clist[t] : 0;
             const int m = (int)(((float)idx + 0.5f) * rcp_nin);      // idx = m * n_in + j < 2^16: exact
             const int j = idx - m * n_in;
             const v4f fa = L.f_a[j];

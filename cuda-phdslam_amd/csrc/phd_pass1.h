@@ -1,0 +1,155 @@
+// phd_pass1.h — pass 1 of the PHD update: per-measurement normalisers and the list of terms that can survive the prune.
+// Part of the one translation unit phd_kernels.hip (device code, namespace phd); see that file for the overview.
+#pragma once
+#include "phd_defs.h"
+#include "phd_lane.h"
+#include "phd_math.h"
+#include "phd_lds.h"
+
+namespace phd {
+
+// wrap_angle() for |a| < 2 pi, branch-free (same operations, same bits)
+__device__ __forceinline__ float wrap_angle_small(float a)
+{
+    const float TWO_PI_F = 6.2831855f;
+    const float PI_F = 3.14159274f;
+    const float B = -1.7484555e-7f; // 2*pi - float(2*pi)
+    const float hi = (a - TWO_PI_F) - B, lo = (a + TWO_PI_F) + B;
+    float r = (a <= -PI_F) ? lo : a;
+    r = (a >= PI_F) ? hi : r;
+    return r;
+}
+
+// Eight per-lane accumulators summed over the wave in ~20 instructions instead of eight 6-step butterflies: every level
+// halves the number of values a lane carries (v_permlane32_swap / v_permlane16_swap exchange half of one register
+// against half of another, so one swap and one add serve two values), the last three levels are plain DPP adds.
+// Returns, in lane l, the wave total of a[l >> 3].  The tree is fixed: results are deterministic.
+__device__ __forceinline__ float reduce8_over_wave(float (&a)[8], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // lanes < 32 go on with values 0..3, lanes >= 32 with 4..7
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 4]), false, false);
+        a[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // even rows of 16 lanes: value i, odd rows: value i + 2
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 2]), false, false);
+        a[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    const bool hi8 = (lane & 8) != 0;
+    const float keep = hi8 ? a[1] : a[0], send = hi8 ? a[0] : a[1];
+    float v = keep + __uint_as_float(dpp_mov<0x128, 0xF>(__float_as_uint(send), __float_as_uint(send)));   // row_ror:8
+    v += __uint_as_float(dpp_mov<0x141, 0xF>(__float_as_uint(v), __float_as_uint(v)));                     // row_half_mirror: l <-> 7 - l
+    v += __uint_as_float(dpp_mov<0x1B, 0xF>(__float_as_uint(v), __float_as_uint(v)));                      // quad_perm [3,2,1,0]
+    v += __uint_as_float(dpp_mov<0xB1, 0xF>(__float_as_uint(v), __float_as_uint(v)));                      // quad_perm [1,0,3,2]
+    return v;
+}
+
+// how the (measurement chunk, feature group) grid of pass 1 is dealt to the 8 waves: chunks of 8 measurements;
+// NC = waves side by side over chunks (power of two <= 8), NF = 8 / NC waves over feature groups of 64
+struct Pass1Grid { int nchunks, NC, NF; };
+__device__ __forceinline__ Pass1Grid pass1_grid(int M)
+{
+    Pass1Grid g;
+    g.nchunks = (M + 7) >> 3;
+    g.NC = 1;
+    while (g.NC < g.nchunks && g.NC < PHD_NW) g.NC <<= 1;
+    g.NF = PHD_NW / g.NC;
+    return g;
+}
+
+// Z_m's feature sum: the partial sums of the NF waves that own measurement m's chunk
+__device__ __forceinline__ float pass1_feature_sum(const Lds& L, const Pass1Grid& g, int m, int MM)
+{
+    const int cg = (m >> 3) & (g.NC - 1);
+    float s = L.zpart[cg * MM + m];
+    for (int fg = 1; fg < g.NF; ++fg) s += L.zpart[(fg * g.NC + cg) * MM + m];
+    return s;
+}
+
+#define PHD_CAND_CAP ((4 * PHD_NW * 64 + 4 * 7 * 64) / 2)   // u16 entries of the candidate list (the part + win arrays)
+
+// ---- pass 1 ------------------------------------------------------------------------------------------------
+// For every measurement m: sum_j exp(lw_jm) over the in-range features (src/phdfilter.cu:2190-2223), and the list of
+// the terms with lw >= c0m (the only ones that can survive the prune, see phd_kernels.hip).
+//
+// Lanes <-> features, a wave's chunk of 8 measurements in registers: the feature's terms (r, b, S, folded log-weight)
+// are loaded ONCE, the measurement is wave-uniform, the eight sums are private accumulators, and the per-pair work is
+// the arithmetic alone — no LDS traffic, no bounds tests (a lane past the last feature carries log-weight -inf), no
+// cross-lane step.  The wave totals come from one transposing reduction per chunk.  Candidates: one bit per pair in a
+// lane register, listed with one wave scan and one LDS atomic per 8 x 64 pairs.
+template <bool FASTWRAP>
+__device__ __forceinline__ u32 pass1_octet(const float (&zr)[8], const float (&zb)[8], u32 vm, const v4f fa, const v2f fc,
+                                           float c0m, float (&acc)[8])
+{
+    u32 bits = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if ((vm >> q) & 1u) {                                     // uniform: measurement in range of M, label accepted
+            const float i0 = zr[q] - fa.x;
+            const float a = zb[q] - fa.y;
+            const float i1 = FASTWRAP ? wrap_angle_small(a) : wrap_angle(a);
+            const float dist = i0 * i0 * fa.z + i0 * i1 * fa.w + i1 * i1 * fc.x;                       // :1908-1910
+            const float lw = fc.y - 0.5f * dist;
+            acc[q] += __expf(lw);                                                                     // :2205
+            bits |= !(lw < c0m) ? (1u << q) : 0u;                 // NaN stays a candidate, as in the dense test
+        }
+    }
+    return bits;
+}
+
+__device__ __forceinline__ void pass1_normalisers(const Lds& L, int n_in, int M, int MM, int tid, bool sparse2, float c0m)
+{
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Pass1Grid g = pass1_grid(M);
+    const int cg = wave & (g.NC - 1), fg = wave / g.NC;
+    lds_u16 clist = (lds_u16)L.part;
+    for (int c = cg; c < g.nchunks; c += g.NC) {
+        const int m0 = 8 * c;
+        // the chunk's measurements (LDS broadcast reads: the same address in every lane)
+        float zr[8], zb[8];
+        u32 vmv = 0, slow = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = m0 + q, mm = m < M ? m : M - 1;
+            zr[q] = L.z_r[mm];
+            zb[q] = L.z_b[mm];
+            const bool ok = (m < M) && L.zok[mm];
+            vmv |= ok ? (1u << q) : 0u;
+            // the features' bearings lie in [-pi, pi] (wrap_angle's range): |z_b| < pi keeps every difference below 2 pi
+            slow |= (ok && !(fabsf(zb[q]) < 3.14159274f)) ? 1u : 0u;
+        }
+        const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)vmv);
+        const bool fast = __builtin_amdgcn_readfirstlane((int)slow) == 0;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int jb = fg * 64; jb < n_in; jb += g.NF * 64) {
+            const int j = jb + lane;
+            const int jj = j < n_in ? j : n_in - 1;
+            const v4f fa = L.f_a[jj];
+            v2f fc = L.f_c[jj];
+            if (j >= n_in) fc.y = -INFINITY;                      // contributes exp(-inf) = 0, never a candidate
+            u32 bits = fast ? pass1_octet<true>(zr, zb, vm, fa, fc, c0m, acc) : pass1_octet<false>(zr, zb, vm, fa, fc, c0m, acc);
+            if (sparse2) {
+                const int np = __popc(bits);
+                const int incl = (int)wave_incl_scan((u32)np);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                if (tot) {                                        // uniform
+                    int base = 0;
+                    if (lane == 63) base = atomicAdd((int*)&L.ctr[CTR_NCAND], tot);
+                    int pos = __builtin_amdgcn_readlane(base, 63) + incl - np;
+                    while (bits) {
+                        const int q = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (pos < PHD_CAND_CAP) clist[pos] = (u16)((m0 + q) * n_in + j);
+                        ++pos;
+                    }
+                }
+            }
+        }
+        const float tot = reduce8_over_wave(acc, lane);
+        const int m = m0 + (lane >> 3);
+        if ((lane & 7) == 0 && m < M) L.zpart[wave * MM + m] = tot;
+    }
+}
+
+} // namespace phd
