@@ -703,8 +703,8 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     }
     if (f->want_stamps) {
         if (!f->stamps) {
-            HIPCHK(dalloc(&f->stamps, (size_t)f->n_max * 16 + 8));
-            HIPCHK(hipMemsetAsync(f->stamps, 0, ((size_t)f->n_max * 16 + 8) * 8, f->stream));
+            HIPCHK(dalloc(&f->stamps, (size_t)f->n_max * PHD_STAMP_ROW + 8));
+            HIPCHK(hipMemsetAsync(f->stamps, 0, ((size_t)f->n_max * PHD_STAMP_ROW + 8) * 8, f->stream));
         }
         a.stamps = f->stamps;
     }
@@ -770,7 +770,7 @@ static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms,
     w.parent_in = f->parent[f->pcur];
     w.parent_out = f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1];
     w.n_weight_norm = f->n_global;
-    if (f->want_stamps && f->stamps) w.wstamps = f->stamps + (size_t)f->n * 16;
+    if (f->want_stamps && f->stamps) w.wstamps = f->stamps + (size_t)f->n * PHD_STAMP_ROW;
 }
 
 static void commit_weights(phd_filter* f, int mode, int free_pose)
@@ -1537,7 +1537,7 @@ extern "C" int phd_debug_get_stamps(phd_filter* f, uint64_t* out)
 {
     CHECK_F(f);
     if (!f->stamps || !out) return fail(PHD_ERR_INVALID_ARG, "phd_debug_get_stamps: enable stamps with phd_debug_enable(f, 2) and run an update first");
-    HIPCHK(hipMemcpyAsync(out, f->stamps, ((size_t)f->n * 16 + 8) * 8, hipMemcpyDeviceToHost, f->stream)); // + 8 stamps of the weights kernel
+    HIPCHK(hipMemcpyAsync(out, f->stamps, ((size_t)f->n * PHD_STAMP_ROW + 8) * 8, hipMemcpyDeviceToHost, f->stream)); // + 8 stamps of the weights kernel
     HIPCHK(hipStreamSynchronize(f->stream));
     return PHD_OK;
 }

@@ -27,6 +27,7 @@ struct DevConfig {
     int labeledMeasurements;
 };
 
+#define PHD_STAMP_ROW 32   // u64 phase stamps per particle of the diagnostic instantiation
 enum { PHD_STATUS_MAP_OVERFLOW = 1u, PHD_STATUS_SURVIVOR_OVERFLOW = 2u, PHD_STATUS_TAIL_TIMEOUT = 4u };
 
 // Map slab layout in HBM: particle-major, then 6 SoA planes of `cap` floats:
@@ -82,7 +83,7 @@ struct UpdateArgs {
     int* dbg_u;                 // [n][S_cap]
     int* dbg_n;                 // [n]
     int* dbg_nin;               // [n]
-    unsigned long long* stamps; // [n][16] phase stamps (diagnostic instantiation) or NULL
+    unsigned long long* stamps; // [n][PHD_STAMP_ROW] phase stamps (diagnostic instantiation) or NULL
     // fused vehicle predict (phd_step_dev): pose <- f(pose, control, noise) before the update
     int do_predict;
     phd_ackerman_control control;

@@ -131,9 +131,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         else draw_noise(A.seed, A.counter, p, cfg, n_alpha, n_encoder);
         pose = predict_pose(pose, A.control, n_alpha, n_encoder, cfg);
     }
-    u64* st = STAMPS ? (A.stamps + (size_t)p * 16) : nullptr;
+    u64* st = STAMPS ? (A.stamps + (size_t)p * PHD_STAMP_ROW) : nullptr;
     u64 cq[5] = {0, 0, 0, 0, 0};
-    if (STAMPS && tid == 0) { st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0; }
+    if (STAMPS && tid == 0) { for (int k = 12; k < PHD_STAMP_ROW; ++k) st[k] = 0; }
     STAMP(0);
 
     if (tid < 32) L.ctr[tid] = 0;

@@ -406,22 +406,25 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     for (int i = tid; i < S; i += PHD_T) ul_a[i] = (u16)i;
     int n_u = S;
     lds_u16 cur = ul_a, nxt = ul_b;
+    // the first window: broadcast-friendly copy of the first 64 survivors (later windows are written by the compaction
+    // of the round before: the first 64 entries it keeps ARE the next window)
+    if (tid < 64) {
+        const int i = tid < S ? tid : S - 1;
+        wpos[tid] = i;
+        v4f a = gA[i];
+        if (tid >= S) a.z = INFINITY;                      // padding: never a candidate
+        wA[tid] = a;
+        wB[tid] = gB[i];
+    }
     __syncthreads();
     while (n_u > 0) {
         u64 tq0 = 0, tq1 = 0, tq2 = 0;
         if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
         const int nwin = n_u < 64 ? n_u : 64;
         const int nrest = n_u - nwin;
-        // (0) window buffer: broadcast-friendly copy of the candidates
-        if (tid < 64) {
-            const int i = cur[tid < nwin ? tid : nwin - 1];
-            wpos[tid] = i;
-            v4f a = gA[i];
-            if (tid >= nwin) a.z = INFINITY;               // padding: never a candidate
-            wA[tid] = a;
-            wB[tid] = gB[i];
-        }
-        __syncthreads();
+        u64 tf[6] = {0, 0, 0, 0, 0, 0};
+#define RSTAMP(k) do { if (STAMPS && tid == 0) tf[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+        RSTAMP(0);
         // every wave holds the window in registers, lane l <-> candidate l; a column's terms reach the scalar
         // registers through v_readlane
         const v4f ka = wA[lane];
@@ -451,6 +454,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             // only earlier candidates count (l < k), and only rows of real candidates
             const int nlt = k - wave * PHD_COLS;
             cand &= (k >= nwin || nlt <= 0) ? 0u : (nlt >= PHD_COLS ? ((1u << PHD_COLS) - 1u) : ((1u << nlt) - 1u));
+            RSTAMP(1);
             u32 bits = 0;
             if (cand) {
                 const v4f kb = wB[k];
@@ -505,6 +509,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             if (lane < 8) sF[nseeds + lane] = (v4f){0.f, 0.f, INFINITY, 0.f};   // pad to a multiple of 8: never a candidate
         }
         const int per = (nrest + PHD_T - 1) / PHD_T;           // entries per thread
+        RSTAMP(2);
         int kept = 0;
         u32 keepbits = 0;                                       // bit q: this thread's q-th entry stays listed
 #ifdef PHD_DUP_ASSIGN
@@ -540,6 +545,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 #undef PHD_SEED_PAIR
             u64 m = ((u64)mhi << 32) | mlo;
             m &= (nseeds == 64) ? ~0ull : ((1ull << nseeds) - 1ull);   // (inf - inf in the padding has no defined sign)
+            if (q == 0) RSTAMP(2);
             bool merged = false;
             if (ev) {
                 while (m) {
@@ -558,11 +564,13 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 #ifdef PHD_DUP_ASSIGN
         }
 #endif
+        RSTAMP(3);
         // ordered compaction of the list: exclusive scan of `kept` over the workgroup (wave scan + wave totals)
         {
             const int incl = (int)wave_incl_scan((u32)kept);
             if (lane == 63) L.ctr[CTR_TMP + wave] = incl;
             __syncthreads();
+            RSTAMP(4);
             int woff = 0, total = 0;
 #pragma unroll
             for (int w = 0; w < PHD_NW; ++w) {
@@ -572,7 +580,12 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             }
             int o = woff + incl - kept;
             for (int q = 0; q < per; ++q)
-                if ((keepbits >> q) & 1u) nxt[o++] = cur[64 + tid * per + q];
+                if ((keepbits >> q) & 1u) {
+                    const int i = cur[64 + tid * per + q];
+                    if (o < 64) { wpos[o] = i; wA[o] = gA[i]; wB[o] = gB[i]; }   // the next round's window
+                    nxt[o++] = (u16)i;
+                }
+            if (tid >= total && tid < 64) ((LDS_T(float)*)&wA[tid])[2] = INFINITY; // padding: never a candidate
             n_u = total;
             __syncthreads();
             lds_u16 t2 = cur; cur = nxt; nxt = t2;
@@ -580,7 +593,12 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         if (STAMPS && tid == 0) {
             const u64 tq3 = __builtin_amdgcn_s_memrealtime();
             st[12] += tq1 - tq0; st[13] += tq2 - tq1; st[14] += tq3 - tq2; st[15] += 1;
+            // finer (thread 0's wave): - | matrix filter | matrix exact + barrier | (resolve: st[13]) | seed records + first pass
+            // of the filter over the seeds | exact decisions (+ later passes) | wait for the slowest wave | compaction
+            st[16] += tf[0] - tq0; st[17] += tf[1] - tf[0]; st[18] += tq1 - tf[1];
+            st[19] += tf[2] - tq2; st[20] += tf[3] - tf[2]; st[21] += tf[4] - tf[3]; st[22] += tq3 - tf[4];
         }
+#undef RSTAMP
     }
 
     STAMP(7);

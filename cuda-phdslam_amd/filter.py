@@ -285,11 +285,12 @@ class PhdFilter:
         check(lib().phd_debug_enable(self._h, int(enable)), "phd_debug_enable")
 
     def stamps(self):
-        """phase stamps of the last update (after debug(2)): [n, 16] ticks of 10 ns"""
-        out = np.zeros(self.n * 16 + 8, np.uint64)
+        """phase stamps of the last update (after debug(2)): [n, 32] ticks of 10 ns (0..11 phase boundaries, 12..15 merge-round
+        sums, 16.. finer sums inside the rounds and pass 1)"""
+        out = np.zeros(self.n * 32 + 8, np.uint64)
         check(lib().phd_debug_get_stamps(self._h, ptr(out)), "phd_debug_get_stamps")
-        self.weight_stamps = out[self.n * 16:]     # phases of the weights/resample kernel
-        return out[:self.n * 16].reshape(self.n, 16)
+        self.weight_stamps = out[self.n * 32:]     # phases of the weights/resample kernel
+        return out[:self.n * 32].reshape(self.n, 32)
 
     def survivors(self, particle):
         """pruned update components (+ nearly-in-range features) of one particle in slab order"""

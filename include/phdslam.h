@@ -343,7 +343,7 @@ int phd_timing_reset(phd_filter* f);
  * Also the per-particle log-weight increments of the last update (src/phdfilter.cu:2260-2263).
  * ---------------------------------------------------------------------------------- */
 int phd_debug_enable(phd_filter* f, int enable); /* bit 0: survivor inspection, bit 1: phase stamps, bit 2: staged launches only (no fused weights tail) */
-/* phase stamps of the last update (diagnostic kernel instantiation): out[n_particles][16], 100 MHz ticks */
+/* phase stamps of the last update (diagnostic kernel instantiation): out[n_particles][32] (+ 8 of the weights routine), 100 MHz ticks */
 int phd_debug_get_stamps(phd_filter* f, uint64_t* out);
 int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, int32_t* slab_index_out,
                             int capacity, int32_t* n_out);

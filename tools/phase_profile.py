@@ -44,3 +44,7 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
             continue
         print("   rounds: %.1f per particle; matrix %.2f us, resolve %.2f us, assign %.2f us (sums over rounds)" %
               (r[:, 3].mean(), r[:, 0].mean() * 0.01, r[:, 1].mean() * 0.01, r[:, 2].mean() * 0.01))
+        fz = st[:, 16:23].astype(np.float64).mean(axis=0) * 0.01
+        if fz.sum() > 0:
+            print("   inside the rounds (us, sums over rounds, thread 0's wave): window copy %.2f | matrix filter %.2f, exact + barrier %.2f | "
+                  "seed records + filter %.2f, exact decisions %.2f, wait for the slowest wave %.2f, compaction %.2f" % tuple(fz))
