@@ -45,13 +45,32 @@ __device__ __forceinline__ float reduce8_over_wave(float (&a)[8], int lane)
     return v;
 }
 
-// how the (measurement chunk, feature group) grid of pass 1 is dealt to the 8 waves: chunks of 8 measurements;
-// NC = waves side by side over chunks (power of two <= 8), NF = 8 / NC waves over feature groups of 64
-struct Pass1Grid { int nchunks, NC, NF; };
+// the same for four accumulators: lane l ends with the wave total of a[l >> 4]
+__device__ __forceinline__ float reduce4_over_wave(float (&a)[4], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 2]), false, false);
+        a[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
+    float v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    v += __uint_as_float(dpp_mov<0x128, 0xF>(__float_as_uint(v), __float_as_uint(v)));                     // row_ror:8
+    v += __uint_as_float(dpp_mov<0x141, 0xF>(__float_as_uint(v), __float_as_uint(v)));                     // row_half_mirror
+    v += __uint_as_float(dpp_mov<0x1B, 0xF>(__float_as_uint(v), __float_as_uint(v)));                      // quad_perm [3,2,1,0]
+    v += __uint_as_float(dpp_mov<0xB1, 0xF>(__float_as_uint(v), __float_as_uint(v)));                      // quad_perm [1,0,3,2]
+    return v;
+}
+
+// how the (measurement chunk, feature group) grid of pass 1 is dealt to the 8 waves: chunks of 2^csh measurements (8, or
+// 4 for small scans so that every wave has a chunk); NC = waves side by side over chunks (power of two <= 8), NF = 8 / NC
+// waves over feature groups of 64
+struct Pass1Grid { int csh, nchunks, NC, NF; };
 __device__ __forceinline__ Pass1Grid pass1_grid(int M)
 {
     Pass1Grid g;
-    g.nchunks = (M + 7) >> 3;
+    g.csh = (M <= 32) ? 2 : 3;
+    g.nchunks = (M + (1 << g.csh) - 1) >> g.csh;
     g.NC = 1;
     while (g.NC < g.nchunks && g.NC < PHD_NW) g.NC <<= 1;
     g.NF = PHD_NW / g.NC;
@@ -61,7 +80,7 @@ __device__ __forceinline__ Pass1Grid pass1_grid(int M)
 // Z_m's feature sum: the partial sums of the NF waves that own measurement m's chunk
 __device__ __forceinline__ float pass1_feature_sum(const Lds& L, const Pass1Grid& g, int m, int MM)
 {
-    const int cg = (m >> 3) & (g.NC - 1);
+    const int cg = (m >> g.csh) & (g.NC - 1);
     float s = L.zpart[cg * MM + m];
     for (int fg = 1; fg < g.NF; ++fg) s += L.zpart[(fg * g.NC + cg) * MM + m];
     return s;
@@ -78,13 +97,13 @@ __device__ __forceinline__ float pass1_feature_sum(const Lds& L, const Pass1Grid
 // the arithmetic alone — no LDS traffic, no bounds tests (a lane past the last feature carries log-weight -inf), no
 // cross-lane step.  The wave totals come from one transposing reduction per chunk.  Candidates: one bit per pair in a
 // lane register, listed with one wave scan and one LDS atomic per 8 x 64 pairs.
-template <bool FASTWRAP>
-__device__ __forceinline__ u32 pass1_octet(const float (&zr)[8], const float (&zb)[8], u32 vm, const v4f fa, const v2f fc,
-                                           float c0m, float (&acc)[8])
+template <bool FASTWRAP, int CH>
+__device__ __forceinline__ u32 pass1_octet(const float (&zr)[CH], const float (&zb)[CH], u32 vm, const v4f fa, const v2f fc,
+                                           float c0m, float (&acc)[CH])
 {
     u32 bits = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < CH; ++q) {
         if ((vm >> q) & 1u) {                                     // uniform: measurement in range of M, label accepted
             const float i0 = zr[q] - fa.x;
             const float a = zb[q] - fa.y;
@@ -98,19 +117,19 @@ __device__ __forceinline__ u32 pass1_octet(const float (&zr)[8], const float (&z
     return bits;
 }
 
-__device__ __forceinline__ void pass1_normalisers(const Lds& L, int n_in, int M, int MM, int tid, bool sparse2, float c0m)
+template <int CH>
+__device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, int n_in, int M, int MM, int lane, int wave,
+                                             bool sparse2, float c0m)
 {
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Pass1Grid g = pass1_grid(M);
     const int cg = wave & (g.NC - 1), fg = wave / g.NC;
     lds_u16 clist = (lds_u16)L.part;
     for (int c = cg; c < g.nchunks; c += g.NC) {
-        const int m0 = 8 * c;
+        const int m0 = CH * c;
         // the chunk's measurements (LDS broadcast reads: the same address in every lane)
-        float zr[8], zb[8];
+        float zr[CH], zb[CH];
         u32 vmv = 0, slow = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < CH; ++q) {
             const int m = m0 + q, mm = m < M ? m : M - 1;
             zr[q] = L.z_r[mm];
             zb[q] = L.z_b[mm];
@@ -121,14 +140,16 @@ __device__ __forceinline__ void pass1_normalisers(const Lds& L, int n_in, int M,
         }
         const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)vmv);
         const bool fast = __builtin_amdgcn_readfirstlane((int)slow) == 0;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float acc[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) acc[q] = 0.f;
         for (int jb = fg * 64; jb < n_in; jb += g.NF * 64) {
             const int j = jb + lane;
             const int jj = j < n_in ? j : n_in - 1;
             const v4f fa = L.f_a[jj];
             v2f fc = L.f_c[jj];
             if (j >= n_in) fc.y = -INFINITY;                      // contributes exp(-inf) = 0, never a candidate
-            u32 bits = fast ? pass1_octet<true>(zr, zb, vm, fa, fc, c0m, acc) : pass1_octet<false>(zr, zb, vm, fa, fc, c0m, acc);
+            u32 bits = fast ? pass1_octet<true, CH>(zr, zb, vm, fa, fc, c0m, acc) : pass1_octet<false, CH>(zr, zb, vm, fa, fc, c0m, acc);
             if (sparse2) {
                 const int np = __popc(bits);
                 const int incl = (int)wave_incl_scan((u32)np);
@@ -146,10 +167,20 @@ __device__ __forceinline__ void pass1_normalisers(const Lds& L, int n_in, int M,
                 }
             }
         }
-        const float tot = reduce8_over_wave(acc, lane);
-        const int m = m0 + (lane >> 3);
-        if ((lane & 7) == 0 && m < M) L.zpart[wave * MM + m] = tot;
+        float tot;
+        int m;
+        if (CH == 8) { tot = reduce8_over_wave((float (&)[8])acc, lane); m = m0 + (lane >> 3); }
+        else { tot = reduce4_over_wave((float (&)[4])acc, lane); m = m0 + (lane >> 4); }
+        if ((lane & (64 / CH - 1)) == 0 && m < M) L.zpart[wave * MM + m] = tot;
     }
+}
+
+__device__ __forceinline__ void pass1_normalisers(const Lds& L, int n_in, int M, int MM, int tid, bool sparse2, float c0m)
+{
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Pass1Grid g = pass1_grid(M);
+    if (g.csh == 3) pass1_chunks<8>(L, g, n_in, M, MM, lane, wave, sparse2, c0m);
+    else pass1_chunks<4>(L, g, n_in, M, MM, lane, wave, sparse2, c0m);
 }
 
 } // namespace phd
