@@ -125,6 +125,8 @@ SYMBOLS = {
     "phd_global_resample_begin": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "phd_step_local_dev": (_i, [_vp, Control, _vp, _vp, _i]),
     "phd_global_resample_end": (_i, [_vp, _vp]),
+    "phd_global_resample_launch": (_i, [_vp, _vp, _d, _vp]),
+    "phd_global_resample_plan": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "phd_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "phd_step_report_get": (_i, [_vp, _vp]),
     "phd_set_particle_count": (_i, [_vp, _i]),

@@ -6,7 +6,11 @@
 // resident on the device, and writes state_estimate%05d.log (README:31-39 5-line format, or HEAD's
 // 7-line writeLog with --log7) and loopTime.log.
 //
-//   phdslam <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7]
+//   phdslam <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--devices N [--shards S]]
+//
+// --devices N: ONE filter sharded over N GPUs of this process (include/phdslam_multi.h: one shard and one stream per
+// device, RCCL all-gather of the log-weights, global resample, particle migration over xGMI).  --shards S > N puts several
+// shards on a device (exchange by device copies; for boxes with fewer GPUs than shards).  Same files in, same logs out.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,6 +25,7 @@
 #include <vector>
 
 #include "phdfilter_compat.h"
+#include "phdslam_multi.h"
 
 static void die(const char* where)
 {
@@ -32,12 +37,12 @@ static void die(const char* where)
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7]\n", argv[0]);
+        fprintf(stderr, "usage: %s <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--devices N [--shards S]]\n", argv[0]);
         return 2;
     }
     std::string out_dir = ".";
     uint64_t seed = 1;
-    int capacity = 0, max_steps = -1;
+    int capacity = 0, max_steps = -1, n_devices = 0, n_shards = 0;
     bool log7 = false;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "synth")) continue;
@@ -47,6 +52,8 @@ int main(int argc, char** argv)
         else if (i + 1 < argc && !strcmp(argv[i], "--seed")) seed = strtoull(argv[++i], nullptr, 10);
         else if (i + 1 < argc && !strcmp(argv[i], "--capacity")) capacity = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--steps")) max_steps = atoi(argv[++i]);
+        else if (i + 1 < argc && !strcmp(argv[i], "--devices")) n_devices = atoi(argv[++i]);
+        else if (i + 1 < argc && !strcmp(argv[i], "--shards")) n_shards = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     char data_dir[4096];
@@ -96,6 +103,102 @@ int main(int argc, char** argv)
 
     int max_m = 1;
     for (size_t k = 0; k < n_meas_steps; ++k) max_m = sizes[k] > max_m ? sizes[k] : max_m;
+    if (n_devices > 0 || n_shards > 0) {
+        // ---- the sharded filter (run_synth's loop, src/main.cpp:1178-1312, over include/phdslam_multi.h) ----
+        if (config.followTrajectory || config.nPredictParticles > 1 || config.filterType == 1 || log7) {
+            fprintf(stderr, "--devices: follow_trajectory, n_predict_particles > 1, filter_type = 1 and --log7 run on a single device\n");
+            return 2;
+        }
+        if (n_devices <= 0) n_devices = 1;
+        if (n_shards <= 0) n_shards = n_devices;
+        std::vector<int32_t> devs((size_t)n_shards);
+        for (int k = 0; k < n_shards; ++k) devs[k] = k % n_devices;
+        phd_multi_options mo = {};
+        mo.n_shards = n_shards;
+        mo.devices = devs.data();
+        mo.map_capacity = capacity > 0 ? capacity : 512;
+        mo.max_measurements = max_m < PHD_MAX_MEASUREMENTS ? max_m : PHD_MAX_MEASUREMENTS;
+        phd_multi* m = nullptr;
+        CHK(phd_multi_create(&config, &mo, &m));
+        const int N = config.n_particles;
+        printf("sharded filter: %d particles over %d shards on %d device(s), transport %s, exchange %s\n", N, n_shards, n_devices,
+               phd_multi_uses_rccl(m) ? "RCCL" : "device copies", phd_multi_exchange_is_gathered(m) ? "whole-shard all-gather" : "all-to-all");
+        std::vector<phd_pose> poses((size_t)N);
+        std::vector<float> logw((size_t)N);
+        std::vector<phd_gaussian2d> map((size_t)mo.map_capacity), eap(4 * (size_t)mo.map_capacity);
+        std::vector<phd_ackerman_noise> noise((size_t)N);
+        const std::string timefile = out_dir + "/loopTime.log";
+        printf("STARTING SIMULATION\n");
+        size_t z_idx = 0, c_idx = 0;
+        float last_time = 0, current_time = 0;
+        phd_ackerman_control current_control = {0, 0};
+        for (int n = 0; n < nSteps; ++n) {
+            timeval t0, t1;
+            gettimeofday(&t0, nullptr);
+            const phd_measurement* Z = nullptr;
+            int M = 0;
+            if (has_timestamps) {                                                            // :1189-1229
+                if (z_idx >= n_mt || c_idx >= n_ct) { printf("no more timestamps\n"); break; }
+                const bool meas_first = mtimes[z_idx] < ctimes[c_idx], both = mtimes[z_idx] == ctimes[c_idx];
+                last_time = current_time;
+                current_time = ctimes[c_idx];
+                config.dt = current_time - last_time;
+                CHK(phd_multi_set_config(m, &config));
+                if (meas_first) { Z = meas.data() + moff[z_idx]; M = sizes[z_idx]; z_idx++; }
+                else if (both) { current_control = controls[c_idx++]; Z = meas.data() + moff[z_idx]; M = sizes[z_idx]; z_idx++; }
+                else current_control = controls[c_idx++];
+            } else {                                                                         // :1231-1237 lock-step
+                Z = meas.data() + moff[n]; M = sizes[n];
+                if (n > 0) {
+                    if ((size_t)(n - 1) >= n_ctrl) { fprintf(stderr, "not enough controls\n"); break; }
+                    current_control = controls[n - 1];
+                }
+            }
+            if (n > 0) {                                                                     // no motion at step 0 (:1244)
+                // (subdivide_predict > 1: the extra predicts carry no scan)
+                const int sub = config.subdividePredict > 0 ? config.subdividePredict : 1;
+                for (int s = 0; s < sub; ++s) {
+                    for (int i = 0; i < N; ++i) {                                            // phdfilter.cu:1147-1152
+                        noise[i].n_alpha = (float)(config.stdAlpha * randn());
+                        noise[i].n_encoder = (float)(config.stdEncoder * randn());
+                    }
+                    const bool last = s == sub - 1;
+                    CHK(phd_multi_update(m, &current_control, noise.data(), last ? Z : nullptr, last ? M : 0));
+                }
+            } else {
+                CHK(phd_multi_update(m, nullptr, nullptr, Z, M));                            // step 0: the scan alone
+            }
+            phd_pose expected;
+            int32_t n_map = 0, who = 0;
+            phd_step_report rep;
+            {
+                const int rc = phd_multi_state_snapshot(m, &expected, map.data(), (int)map.size(), &n_map, &who, poses.data(), logw.data(), &rep);
+                if (rc == PHD_ERR_NAN) { printf("nan weights detected! exiting...\n"); break; }
+                if (rc != PHD_OK) die("phd_multi_state_snapshot");
+            }
+            if ((config.mapEstimate & 2) && N > 1) {                                         // :363-379
+                int32_t n_eap = 0;
+                int rc = phd_multi_expected_map(m, eap.data(), (int)eap.size(), &n_eap);
+                if (rc == PHD_ERR_CAPACITY && n_eap > (int)eap.size()) { eap.resize((size_t)n_eap); rc = phd_multi_expected_map(m, eap.data(), (int)eap.size(), &n_eap); }
+                if (rc != PHD_OK) die("phd_multi_expected_map");
+                if (!(config.mapEstimate & 1)) {
+                    if ((size_t)n_eap > map.size()) map.resize((size_t)n_eap);
+                    std::copy(eap.begin(), eap.begin() + n_eap, map.begin());
+                    n_map = n_eap;
+                }
+            }
+            const double u = randu01();
+            const int did = (M > 0 && rep.neff <= config.resampleThresh) ? 1 : 0;            // :1286
+            if (did) CHK(phd_multi_resample(m, u));
+            CHK(phd_write_state_log(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), N, config.maxCardinality));
+            gettimeofday(&t1, nullptr);
+            const double elapsed = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_usec - t0.tv_usec) / 1000.0;
+            if (FILE* tf = fopen(timefile.c_str(), "a")) { fprintf(tf, "%g\n", elapsed); fclose(tf); }
+            printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", n, nSteps, M, N, n_map, did, elapsed);
+        }
+        phd_multi_destroy(m);
+        return 0;
+    }
     phd_options opt = {};
     opt.n_particles = config.n_particles;
     opt.map_capacity = capacity > 0 ? capacity : 512;

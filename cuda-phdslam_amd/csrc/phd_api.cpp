@@ -158,6 +158,7 @@ static void fill_devcfg(const phd_slam_config& c, DevConfig& d)
     d.subdividePredict = c.subdividePredict > 0 ? c.subdividePredict : 1;
     d.distanceMetric = c.distanceMetric;
     d.labeledMeasurements = c.labeledMeasurements ? 1 : 0;
+    d.particleOffset = 0;
 }
 
 static int check_supported(const phd_slam_config& c)
@@ -214,6 +215,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     f->MM = o.max_measurements > 0 ? std::min(o.max_measurements, PHD_MAX_MEASUREMENTS) : PHD_MAX_MEASUREMENTS;
     f->n_global = o.global_particles > 0 ? o.global_particles : f->n;
     f->global_offset = o.global_offset;
+    f->dcfg.particleOffset = o.global_offset;
     if (f->n <= 0) { delete f; return fail(PHD_ERR_INVALID_ARG, "phd_create: n_particles <= 0"); }
     if (f->cap > 65535) { delete f; return fail(PHD_ERR_INVALID_ARG, "phd_create: map_capacity > 65535"); }
     int S = o.survivor_capacity > 0 ? o.survivor_capacity : (f->cap + 8 * f->MM);
@@ -342,6 +344,7 @@ extern "C" int phd_set_config(phd_filter* f, const phd_slam_config* cfg)
     if (rc) return rc;
     f->cfg = *cfg;
     fill_devcfg(*cfg, f->dcfg); // kernel argument from now on; nothing to upload
+    f->dcfg.particleOffset = f->global_offset;
     return PHD_OK;
 }
 
@@ -1329,43 +1332,44 @@ static int ensure_send_buffer(phd_filter* f, size_t need)
 //          destination rank in the order the destination's slots appear
 //   [caller: all_to_all_single(recv, send, recv_counts, send_counts) over RCCL]
 //   end:   local parents gathered, received particles imported into their slots, weights <- -log N
-extern "C" int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_logw, double uniform, int world, int rank,
-                                         int32_t* send_counts, int32_t* recv_counts, void** d_send_buffer, int32_t* idx_out)
+// phd_global_resample_begin in two halves, for a host that drives SEVERAL shards (phd_multi.cpp): every shard enqueues
+// the launch; the indices — identical on every shard — are downloaded ONCE and every shard plans from the same host copy.
+//   launch: normalise the gathered raw weights (d_all_raw_logw != NULL) and draw the global indices on the device, no sync
+//   plan:   this shard's part of the migration from host indices + export of what other shards need
+extern "C" int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_logw, double uniform, int32_t** d_idx_out)
+{
+    CHECK_F(f);
+    const int ng = f->n_global;
+    WeightArgs w;
+    memset(&w, 0, sizeof(w));
+    w.u0 = uniform;
+    w.logw_in = d_all_raw_logw ? d_all_raw_logw : f->logw_scratch;
+    w.logw = f->logw_scratch;
+    w.n = ng;
+    w.n_new = ng;
+    w.mode = (d_all_raw_logw ? WM_NORMALIZE : 0) | WM_RESAMPLE_FORCE;
+    w.uniforms = f->d_uniforms;
+    w.n_uniforms = 1;
+    w.cdf = f->cdf;
+    w.idx_out = f->idx;
+    w.neff_out = f->neff;
+    w.did_resample = f->did;
+    w.n_weight_norm = ng;
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights(w, f->stream));
+    t_end(f);
+    if (d_idx_out) *d_idx_out = f->idx;
+    return PHD_OK;
+}
+
+extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int world, int rank, int32_t* send_counts,
+                                        int32_t* recv_counts, void** d_send_buffer)
 {
     CHECK_F(f);
     if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
-        return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_begin: world/rank do not match the filter's shard");
-    if (!send_counts || !recv_counts || !d_send_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_begin: null output");
-    const int ng = f->n_global, n = f->n, off = rank * n;
-    f->plan_idx.resize(ng);
-    int rc;
-    if (d_all_raw_logw) {
-        // gathered un-normalised weights: normalise and draw the indices in one launch (forced resample)
-        WeightArgs w;
-        memset(&w, 0, sizeof(w));
-        w.u0 = uniform;
-        w.logw_in = d_all_raw_logw;
-        w.logw = f->logw_scratch;
-        w.n = ng;
-        w.n_new = ng;
-        w.mode = WM_NORMALIZE | WM_RESAMPLE_FORCE;
-        w.uniforms = f->d_uniforms;
-        w.n_uniforms = 1;
-        w.cdf = f->cdf;
-        w.idx_out = f->idx;
-        w.neff_out = f->neff;
-        w.did_resample = f->did;
-        w.n_weight_norm = ng;
-        t_begin(f, PHD_K_WEIGHTS);
-        HIPCHK(launch_weights(w, f->stream));
-        t_end(f);
-        HIPCHK(hipMemcpyAsync(f->plan_idx.data(), f->idx, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, f->stream));
-        HIPCHK(hipStreamSynchronize(f->stream));
-    } else {
-        rc = phd_global_resample_indices(f, nullptr, ng, &uniform, 1, f->plan_idx.data());
-        if (rc) return rc;
-    }
-    const int32_t* idx = f->plan_idx.data();
+        return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_plan: world/rank do not match the filter's shard");
+    if (!idx || !send_counts || !recv_counts || !d_send_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_plan: null argument");
+    const int n = f->n, off = rank * n;
     f->plan_local_parent.assign(n, -1);
     f->plan_send.clear();
     f->plan_recv_slots.clear();
@@ -1379,14 +1383,39 @@ extern "C" int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_l
         for (int j = 0; j < n; ++j)                                 // what this rank needs from rank r, in slot order
             if (idx[off + j] / n == r) { f->plan_recv_slots.push_back(j); ++recv_counts[r]; }
     }
-    rc = ensure_send_buffer(f, std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f));
+    int rc = ensure_send_buffer(f, std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f));
     if (rc) return rc;
     if (!f->plan_send.empty()) {
         rc = phd_export_particles_dev(f, f->plan_send.data(), (int)f->plan_send.size(), f->send_buf);
         if (rc) return rc;
     }
     *d_send_buffer = f->send_buf;
-    if (idx_out) memcpy(idx_out, idx, (size_t)ng * sizeof(int32_t));
+    return PHD_OK;
+}
+
+extern "C" int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_logw, double uniform, int world, int rank,
+                                         int32_t* send_counts, int32_t* recv_counts, void** d_send_buffer, int32_t* idx_out)
+{
+    CHECK_F(f);
+    if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
+        return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_begin: world/rank do not match the filter's shard");
+    if (!send_counts || !recv_counts || !d_send_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_begin: null output");
+    const int ng = f->n_global;
+    f->plan_idx.resize(ng);
+    int rc;
+    if (d_all_raw_logw) {
+        // gathered un-normalised weights: normalise and draw the indices in one launch (forced resample)
+        rc = phd_global_resample_launch(f, d_all_raw_logw, uniform, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(f->plan_idx.data(), f->idx, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    } else {
+        rc = phd_global_resample_indices(f, nullptr, ng, &uniform, 1, f->plan_idx.data());
+        if (rc) return rc;
+    }
+    rc = phd_global_resample_plan(f, f->plan_idx.data(), world, rank, send_counts, recv_counts, d_send_buffer);
+    if (rc) return rc;
+    if (idx_out) memcpy(idx_out, f->plan_idx.data(), (size_t)ng * sizeof(int32_t));
     return PHD_OK;
 }
 

@@ -25,6 +25,7 @@ struct DevConfig {
     int subdividePredict;
     int distanceMetric;
     int labeledMeasurements;
+    int particleOffset;         // index of this shard's first particle in the global ordering (device noise generator)
 };
 
 #define PHD_STAMP_ROW 32   // u64 phase stamps per particle of the diagnostic instantiation

@@ -1,0 +1,622 @@
+// phd_multi.cpp — one GM-PHD-SLAM filter sharded over the GPUs of one process: the C++ multi-device host of
+// include/phdslam_multi.h over the single-shard C-ABI (include/phdslam.h) and RCCL.
+//
+// One host thread enqueues everything: per shard one HIP stream, per step
+//   local step (ONE launch per shard) -> RCCL all-gather -> global normalise / indices (one launch per shard)
+//   -> [index download, once] -> plan + export -> ncclSend/ncclRecv pairs -> import
+// or, for small shards, local step into export rows -> ONE all-gather of whole shards -> normalise + indices + import.
+// The reference has no counterpart (single GPU, src/main.cpp:1449); the loop body mirrored is src/main.cpp:1244-1297.
+//
+// Shards that share a device cannot form an RCCL communicator (one rank per GPU): they exchange by stream-ordered
+// device copies behind the same two transport functions (all_gather, all_to_all) — what the one-GPU tests run.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "phdslam.h"
+#include "phdslam_multi.h"
+
+extern "C" int phd_internal_set_error(int code, const char* msg);
+
+namespace {
+
+int fail(int code, const std::string& msg) { return phd_internal_set_error(code, msg.c_str()); }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(PHD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define NCCLCHK(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) return fail(PHD_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+#define PHDCHK(expr)                                                                                   \
+    do {                                                                                                \
+        int rc_ = (expr);                                                                               \
+        if (rc_ != PHD_OK) return rc_;                                                                  \
+    } while (0)
+
+struct Shard {
+    int device = 0;
+    phd_filter* f = nullptr;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    float* allw = nullptr;              // [N] gathered raw log-weights
+    unsigned char* recv = nullptr;      // [n][pack] all-to-all receive buffer
+    unsigned char* allrows = nullptr;   // [N][pack] gathered shards (small-shard exchange), allocated on first use
+    phd_measurement* d_z = nullptr;     // [MM] this step's scan
+    phd_ackerman_noise* d_noise = nullptr; // [n] this step's control noise
+    hipEvent_t ready = nullptr;         // peer copies: this shard's outgoing data is complete
+    hipEvent_t done = nullptr;          //              this shard has consumed its peers' data
+    bool done_pending = false;
+    std::vector<int32_t> sc, rc;        // all-to-all counts
+    void* send_buf = nullptr;
+};
+
+} // namespace
+
+struct phd_multi {
+    phd_slam_config cfg;
+    int world = 0, N = 0, n = 0, cap = 0, MM = 0;
+    size_t pack = 0, gathered_limit = 32u << 20;
+    bool rccl = false, gathered = false, frozen = false;
+    std::vector<Shard> sh;
+    int32_t* h_idx = nullptr;           // pinned: the global resample indices (downloaded once per step from shard 0)
+    int n_meas = 0;                     // of the resident inputs
+    bool have_noise = false;
+};
+
+namespace {
+
+// stream-ordered hand-off for the peer-copy transport: every consumer stream waits for every producer's `ready`
+int peer_publish(phd_multi* m)
+{
+    for (auto& s : m->sh) {
+        HIPCHK(hipSetDevice(s.device));
+        HIPCHK(hipEventRecord(s.ready, s.stream));
+    }
+    return PHD_OK;
+}
+int peer_consumed(phd_multi* m)
+{
+    for (auto& s : m->sh) {
+        HIPCHK(hipSetDevice(s.device));
+        HIPCHK(hipEventRecord(s.done, s.stream));
+        s.done_pending = true;
+    }
+    return PHD_OK;
+}
+// before a shard overwrites data its peers read in the previous exchange
+int peer_wait_consumed(phd_multi* m)
+{
+    if (m->rccl) return PHD_OK;
+    for (auto& s : m->sh) {
+        HIPCHK(hipSetDevice(s.device));
+        for (auto& o : m->sh)
+            if (&o != &s && o.done_pending) HIPCHK(hipStreamWaitEvent(s.stream, o.done, 0));
+    }
+    return PHD_OK;
+}
+
+// every shard's `count` bytes at src[k] -> dst[k] + j * count for all (k, j): dst of shard k = [world][count]
+int all_gather(phd_multi* m, const std::vector<const void*>& src, const std::vector<void*>& dst, size_t bytes)
+{
+    if (m->rccl) {
+        NCCLCHK(ncclGroupStart());
+        for (int k = 0; k < m->world; ++k)
+            NCCLCHK(ncclAllGather(src[k], dst[k], bytes, ncclChar, m->sh[k].comm, m->sh[k].stream));
+        NCCLCHK(ncclGroupEnd());
+        return PHD_OK;
+    }
+    PHDCHK(peer_publish(m));
+    for (int k = 0; k < m->world; ++k) {
+        Shard& s = m->sh[k];
+        HIPCHK(hipSetDevice(s.device));
+        for (int j = 0; j < m->world; ++j) {
+            if (j != k) HIPCHK(hipStreamWaitEvent(s.stream, m->sh[j].ready, 0));
+            HIPCHK(hipMemcpyAsync((unsigned char*)dst[k] + (size_t)j * bytes, src[j], bytes, hipMemcpyDeviceToDevice, s.stream));
+        }
+    }
+    return peer_consumed(m);
+}
+
+// packed particles: shard j's send buffer is grouped by destination (ascending, self skipped), shard k's receive
+// buffer by source (ascending, self skipped); recv_counts_k[j] == send_counts_j[k]
+int all_to_all(phd_multi* m)
+{
+    const size_t pack = m->pack;
+    if (m->rccl) {
+        NCCLCHK(ncclGroupStart());
+        for (int j = 0; j < m->world; ++j) {
+            Shard& s = m->sh[j];
+            size_t so = 0, ro = 0;
+            for (int r = 0; r < m->world; ++r) {
+                if (r == j) continue;
+                if (s.sc[r]) NCCLCHK(ncclSend((const unsigned char*)s.send_buf + so * pack, (size_t)s.sc[r] * pack, ncclChar, r, s.comm, s.stream));
+                if (s.rc[r]) NCCLCHK(ncclRecv(s.recv + ro * pack, (size_t)s.rc[r] * pack, ncclChar, r, s.comm, s.stream));
+                so += s.sc[r];
+                ro += s.rc[r];
+            }
+        }
+        NCCLCHK(ncclGroupEnd());
+        return PHD_OK;
+    }
+    PHDCHK(peer_publish(m));
+    for (int k = 0; k < m->world; ++k) {
+        Shard& d = m->sh[k];
+        HIPCHK(hipSetDevice(d.device));
+        size_t ro = 0;
+        for (int j = 0; j < m->world; ++j) {
+            if (j == k) continue;
+            const Shard& s = m->sh[j];
+            size_t so = 0;
+            for (int r = 0; r < k; ++r)
+                if (r != j) so += s.sc[r];
+            if (d.rc[j]) {
+                HIPCHK(hipStreamWaitEvent(d.stream, s.ready, 0));
+                HIPCHK(hipMemcpyAsync(d.recv + ro * pack, (const unsigned char*)s.send_buf + so * pack, (size_t)d.rc[j] * pack,
+                                      hipMemcpyDeviceToDevice, d.stream));
+            }
+            ro += d.rc[j];
+        }
+    }
+    return peer_consumed(m);
+}
+
+int ensure_allrows(phd_multi* m)
+{
+    for (auto& s : m->sh)
+        if (!s.allrows) {
+            HIPCHK(hipSetDevice(s.device));
+            HIPCHK(hipMalloc((void**)&s.allrows, (size_t)m->N * m->pack));
+        }
+    return PHD_OK;
+}
+
+
+// global resample + migration.  from_raw: the gathered UN-normalised weights sit in allw (forced resample straight after
+// the update: normalisation and indices come from one launch); otherwise the indices come from the normalised global vector
+// phd_global_normalize left on every shard.
+int resample_stage(phd_multi* m, double uniform, bool from_raw)
+{
+    const int W = m->world;
+    std::vector<const void*> src(W);
+    std::vector<void*> dst(W);
+    if (m->gathered && !from_raw) {
+        // small shards: whole shards travel, nothing waits for the host
+        PHDCHK(ensure_allrows(m));
+        PHDCHK(peer_wait_consumed(m));
+        for (int k = 0; k < W; ++k) {
+            void* rows = nullptr;
+            PHDCHK(phd_export_shard_dev(m->sh[k].f, &rows, nullptr));
+            src[k] = rows;
+            dst[k] = m->sh[k].allrows;
+        }
+        PHDCHK(all_gather(m, src, dst, (size_t)m->n * m->pack));
+        for (int k = 0; k < W; ++k)
+            PHDCHK(phd_global_resample_gathered(m->sh[k].f, m->sh[k].allrows, uniform, W, k, 0, nullptr));
+        return PHD_OK;
+    }
+    // indices on every shard (identical), downloaded ONCE; every shard plans from the same host copy
+    int32_t* d_idx0 = nullptr;
+    for (int k = 0; k < W; ++k) {
+        int32_t* d_idx = nullptr;
+        PHDCHK(phd_global_resample_launch(m->sh[k].f, from_raw ? m->sh[k].allw : nullptr, uniform, &d_idx));
+        if (k == 0) d_idx0 = d_idx;
+    }
+    HIPCHK(hipSetDevice(m->sh[0].device));
+    HIPCHK(hipMemcpyAsync(m->h_idx, d_idx0, (size_t)m->N * sizeof(int32_t), hipMemcpyDeviceToHost, m->sh[0].stream));
+    HIPCHK(hipStreamSynchronize(m->sh[0].stream));
+    PHDCHK(peer_wait_consumed(m));
+    for (int k = 0; k < W; ++k)
+        PHDCHK(phd_global_resample_plan(m->sh[k].f, m->h_idx, W, k, m->sh[k].sc.data(), m->sh[k].rc.data(), &m->sh[k].send_buf));
+    PHDCHK(all_to_all(m));
+    for (int k = 0; k < W; ++k) PHDCHK(phd_global_resample_end(m->sh[k].f, m->sh[k].recv));
+    return PHD_OK;
+}
+
+// local predict + update on every shard, the raw weights of all shards gathered on every shard
+int update_stage(phd_multi* m, const phd_ackerman_control* u)
+{
+    const int W = m->world, M = m->n_meas;
+    std::vector<const void*> src(W);
+    std::vector<void*> dst(W);
+    for (int k = 0; k < W; ++k) {
+        if (u) PHDCHK(phd_step_local_dev(m->sh[k].f, *u, m->have_noise ? m->sh[k].d_noise : nullptr, m->sh[k].d_z, M));
+        else PHDCHK(phd_update_local_dev(m->sh[k].f, m->sh[k].d_z, M));                // no motion (step 0, src/main.cpp:1244)
+        float* raw = nullptr;
+        PHDCHK(phd_raw_logweights_dev(m->sh[k].f, &raw));
+        src[k] = raw;
+        dst[k] = m->sh[k].allw;
+    }
+    return all_gather(m, src, dst, (size_t)m->n * sizeof(float));
+}
+
+} // namespace
+
+extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_options* opt, phd_multi** out)
+{
+    if (!cfg || !out) return fail(PHD_ERR_INVALID_ARG, "phd_multi_create: null argument");
+    phd_multi_options o;
+    memset(&o, 0, sizeof(o));
+    if (opt) o = *opt;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PHD_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+    const int world = o.n_shards > 0 ? o.n_shards : ndev;
+    if (cfg->n_particles <= 0 || cfg->n_particles % world)
+        return fail(PHD_ERR_INVALID_ARG, "phd_multi_create: n_particles must be a positive multiple of the shard count");
+    if (cfg->nPredictParticles > 1)
+        return fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: the particle shotgun (n_predict_particles > 1) is single-device");
+    phd_multi* m = new phd_multi();
+    m->cfg = *cfg;
+    m->world = world;
+    m->N = cfg->n_particles;
+    m->n = m->N / world;
+    if (o.gathered_limit_bytes) m->gathered_limit = o.gathered_limit_bytes;
+    m->sh.resize(world);
+    bool distinct = true;
+    for (int k = 0; k < world; ++k) {
+        m->sh[k].device = o.devices ? o.devices[k] : k % ndev;
+        if (m->sh[k].device < 0 || m->sh[k].device >= ndev) { delete m; return fail(PHD_ERR_INVALID_ARG, "phd_multi_create: bad device ordinal"); }
+        for (int j = 0; j < k; ++j) distinct = distinct && m->sh[j].device != m->sh[k].device;
+    }
+    if (o.transport == PHD_TRANSPORT_RCCL && !distinct) { delete m; return fail(PHD_ERR_INVALID_ARG, "phd_multi_create: RCCL needs one device per shard"); }
+    m->rccl = o.transport == PHD_TRANSPORT_RCCL || (o.transport == PHD_TRANSPORT_AUTO && distinct);
+    int rc = PHD_OK;
+    for (int k = 0; k < world && rc == PHD_OK; ++k) {
+        Shard& s = m->sh[k];
+        if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(PHD_ERR_HIP, "phd_multi_create: stream creation failed");
+            break;
+        }
+        phd_options po;
+        memset(&po, 0, sizeof(po));
+        po.n_particles = m->n;
+        po.map_capacity = o.map_capacity;
+        po.max_measurements = o.max_measurements;
+        po.survivor_capacity = o.survivor_capacity;
+        po.device = s.device;
+        po.stream = s.stream;
+        po.global_particles = m->N;
+        po.global_offset = k * m->n;
+        rc = phd_create(cfg, &po, &s.f);
+        if (rc) break;
+        s.sc.assign(world, 0);
+        s.rc.assign(world, 0);
+    }
+    if (rc == PHD_OK) {
+        m->cap = phd_map_capacity(m->sh[0].f);
+        m->MM = o.max_measurements > 0 ? std::min(o.max_measurements, PHD_MAX_MEASUREMENTS) : PHD_MAX_MEASUREMENTS;
+        m->pack = phd_particle_pack_bytes(m->sh[0].f);
+        m->gathered = o.exchange == PHD_EXCHANGE_GATHERED ||
+                      (o.exchange == PHD_EXCHANGE_AUTO && (size_t)m->N * m->pack <= m->gathered_limit);
+        for (auto& s : m->sh) {
+            hipError_t e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipMalloc((void**)&s.allw, (size_t)m->N * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void**)&s.recv, (size_t)std::max(m->n, 1) * m->pack);
+            if (e == hipSuccess) e = hipMalloc((void**)&s.d_z, (size_t)m->MM * sizeof(phd_measurement));
+            if (e == hipSuccess) e = hipMalloc((void**)&s.d_noise, (size_t)m->n * sizeof(phd_ackerman_noise));
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+            if (e != hipSuccess) { rc = fail(PHD_ERR_HIP, std::string("phd_multi_create: ") + hipGetErrorString(e)); break; }
+        }
+    }
+    if (rc == PHD_OK && hipHostMalloc((void**)&m->h_idx, (size_t)m->N * sizeof(int32_t)) != hipSuccess)
+        rc = fail(PHD_ERR_HIP, "phd_multi_create: pinned allocation failed");
+    if (rc == PHD_OK && m->rccl) {
+        std::vector<int> devs(world);
+        std::vector<ncclComm_t> comms(world);
+        for (int k = 0; k < world; ++k) devs[k] = m->sh[k].device;
+        ncclResult_t r = ncclCommInitAll(comms.data(), world, devs.data());
+        if (r != ncclSuccess) rc = fail(PHD_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        else for (int k = 0; k < world; ++k) m->sh[k].comm = comms[k];
+    }
+    if (rc != PHD_OK) {
+        const std::string keep = phd_last_error();
+        phd_multi_destroy(m);
+        return fail(rc, keep);
+    }
+    *out = m;
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_destroy(phd_multi* m)
+{
+    if (!m) return PHD_OK;
+    for (auto& s : m->sh) {
+        (void)hipSetDevice(s.device);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.comm) (void)ncclCommDestroy(s.comm);
+        if (s.f) phd_destroy(s.f);
+        (void)hipFree(s.allw); (void)hipFree(s.recv); (void)hipFree(s.allrows); (void)hipFree(s.d_z); (void)hipFree(s.d_noise);
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    if (m->h_idx) (void)hipHostFree(m->h_idx);
+    delete m;
+    return PHD_OK;
+}
+
+#define CHECK_M(m) do { if (!(m)) return fail(PHD_ERR_INVALID_ARG, "null multi-device handle"); } while (0)
+
+extern "C" int phd_multi_n_shards(const phd_multi* m) { return m ? m->world : PHD_ERR_INVALID_ARG; }
+extern "C" int phd_multi_n_particles(const phd_multi* m) { return m ? m->N : PHD_ERR_INVALID_ARG; }
+extern "C" int phd_multi_uses_rccl(const phd_multi* m) { return m ? (m->rccl ? 1 : 0) : PHD_ERR_INVALID_ARG; }
+extern "C" int phd_multi_exchange_is_gathered(const phd_multi* m) { return m ? (m->gathered ? 1 : 0) : PHD_ERR_INVALID_ARG; }
+extern "C" phd_filter* phd_multi_shard(phd_multi* m, int k) { return (m && k >= 0 && k < m->world) ? m->sh[k].f : nullptr; }
+
+extern "C" int phd_multi_seed(phd_multi* m, uint64_t seed)
+{
+    CHECK_M(m);
+    for (auto& s : m->sh) PHDCHK(phd_seed(s.f, seed));   // one stream of draws, indexed by the global particle index
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_set_config(phd_multi* m, const phd_slam_config* cfg)
+{
+    CHECK_M(m);
+    if (!cfg) return fail(PHD_ERR_INVALID_ARG, "null config");
+    if (cfg->n_particles != m->N) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_config: n_particles cannot change");
+    for (auto& s : m->sh) PHDCHK(phd_set_config(s.f, cfg));
+    m->cfg = *cfg;
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_set_frozen(phd_multi* m, int freeze)
+{
+    CHECK_M(m);
+    for (auto& s : m->sh) PHDCHK(phd_set_frozen(s.f, freeze));
+    m->frozen = freeze != 0;
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_sync(phd_multi* m)
+{
+    CHECK_M(m);
+    for (auto& s : m->sh) PHDCHK(phd_sync(s.f));
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_set_particles(phd_multi* m, const phd_pose* poses, const float* log_weights, int n)
+{
+    CHECK_M(m);
+    if (n != m->N) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_particles: n != n_particles");
+    for (int k = 0; k < m->world; ++k)
+        PHDCHK(phd_set_particles(m->sh[k].f, poses ? poses + (size_t)k * m->n : nullptr,
+                                 log_weights ? log_weights + (size_t)k * m->n : nullptr, m->n));
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_get_particles(phd_multi* m, phd_pose* poses_out, float* log_weights_out)
+{
+    CHECK_M(m);
+    for (int k = 0; k < m->world; ++k)
+        PHDCHK(phd_get_particles(m->sh[k].f, poses_out ? poses_out + (size_t)k * m->n : nullptr,
+                                 log_weights_out ? log_weights_out + (size_t)k * m->n : nullptr));
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_set_maps(phd_multi* m, const phd_gaussian2d* concat, const int32_t* sizes)
+{
+    CHECK_M(m);
+    if (!sizes) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_maps: null sizes");
+    size_t off = 0;
+    for (int k = 0; k < m->world; ++k) {
+        PHDCHK(phd_set_maps(m->sh[k].f, concat ? concat + off : nullptr, sizes + (size_t)k * m->n));
+        for (int p = 0; p < m->n; ++p) off += (size_t)sizes[(size_t)k * m->n + p];
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_get_map_sizes(phd_multi* m, int32_t* sizes_out)
+{
+    CHECK_M(m);
+    if (!sizes_out) return fail(PHD_ERR_INVALID_ARG, "null output");
+    for (int k = 0; k < m->world; ++k) PHDCHK(phd_get_map_sizes(m->sh[k].f, sizes_out + (size_t)k * m->n));
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_get_maps(phd_multi* m, phd_gaussian2d* concat_out, size_t concat_capacity, int32_t* sizes_out)
+{
+    CHECK_M(m);
+    std::vector<int32_t> sizes((size_t)m->N);
+    PHDCHK(phd_multi_get_map_sizes(m, sizes.data()));
+    if (sizes_out) memcpy(sizes_out, sizes.data(), sizes.size() * sizeof(int32_t));
+    if (!concat_out) return PHD_OK;
+    size_t off = 0;
+    for (int k = 0; k < m->world; ++k) {
+        size_t tot = 0;
+        for (int p = 0; p < m->n; ++p) tot += (size_t)sizes[(size_t)k * m->n + p];
+        if (off + tot > concat_capacity) return fail(PHD_ERR_CAPACITY, "phd_multi_get_maps: output buffer too small");
+        PHDCHK(phd_get_maps(m->sh[k].f, concat_out + off, concat_capacity - off, nullptr));
+        off += tot;
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_upload_inputs(phd_multi* m, const phd_ackerman_noise* noise, const phd_measurement* z, int n_meas)
+{
+    CHECK_M(m);
+    const int M = std::min(std::max(n_meas, 0), m->MM);
+    if (M > 0 && !z) return fail(PHD_ERR_INVALID_ARG, "phd_multi_upload_inputs: null measurements");
+    PHDCHK(peer_wait_consumed(m));
+    for (int k = 0; k < m->world; ++k) {
+        Shard& s = m->sh[k];
+        HIPCHK(hipSetDevice(s.device));
+        if (M > 0) HIPCHK(hipMemcpyAsync(s.d_z, z, (size_t)M * sizeof(phd_measurement), hipMemcpyHostToDevice, s.stream));
+        if (noise) HIPCHK(hipMemcpyAsync(s.d_noise, noise + (size_t)k * m->n, (size_t)m->n * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, s.stream));
+    }
+    m->n_meas = M;
+    m->have_noise = noise != nullptr;
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_step_resident(phd_multi* m, phd_ackerman_control u, double uniform, int force_resample,
+                                       int32_t* did_resample_out)
+{
+    CHECK_M(m);
+    const int W = m->world, M = m->n_meas;
+    if (did_resample_out) *did_resample_out = 0;
+    PHDCHK(peer_wait_consumed(m));
+    if (M <= 0) {                                       // no scan: predict only (src/main.cpp:1244-1260); no resample (:1286)
+        for (auto& s : m->sh) PHDCHK(phd_step_local_dev(s.f, u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
+        return PHD_OK;
+    }
+    if (m->gathered && force_resample) {
+        // small shards, forced resample: nothing waits for the host
+        PHDCHK(ensure_allrows(m));
+        std::vector<const void*> src(W);
+        std::vector<void*> dst(W);
+        for (int k = 0; k < W; ++k) {
+            void* rows = nullptr;
+            PHDCHK(phd_step_local_rows_dev(m->sh[k].f, u, m->have_noise ? m->sh[k].d_noise : nullptr, m->sh[k].d_z, M, &rows, nullptr));
+            src[k] = rows;
+            dst[k] = m->sh[k].allrows;
+        }
+        PHDCHK(all_gather(m, src, dst, (size_t)m->n * m->pack));
+        for (int k = 0; k < W; ++k)
+            PHDCHK(phd_global_resample_gathered(m->sh[k].f, m->sh[k].allrows, uniform, W, k, 1, nullptr));
+        if (did_resample_out) *did_resample_out = 1;
+        return PHD_OK;
+    }
+    // local step, then the raw weights of all shards on every shard
+    PHDCHK(update_stage(m, &u));
+    bool resample = force_resample != 0;
+    if (!resample) {
+        // the reference's trigger: global normalisation (adopted by every shard), nEff read back from shard 0 only
+        float neff = 0.f;
+        for (int k = W - 1; k >= 0; --k)
+            PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->N, k == 0 ? &neff : nullptr));
+        resample = neff <= m->cfg.resampleThresh;                                    // src/main.cpp:1286
+        if (!resample) return PHD_OK;
+    }
+    if (did_resample_out) *did_resample_out = 1;
+    return resample_stage(m, uniform, force_resample != 0);
+}
+
+extern "C" int phd_multi_step(phd_multi* m, phd_ackerman_control u, const phd_ackerman_noise* noise, const phd_measurement* z,
+                              int n_meas, double uniform, int force_resample, int32_t* did_resample_out)
+{
+    CHECK_M(m);
+    PHDCHK(phd_multi_upload_inputs(m, noise, z, n_meas));
+    return phd_multi_step_resident(m, u, uniform, force_resample, did_resample_out);
+}
+
+extern "C" int phd_multi_state_snapshot(phd_multi* m, phd_pose* expected_out, phd_gaussian2d* map_out, int capacity,
+                                        int32_t* n_map_out, int32_t* particle_out, phd_pose* poses_out, float* log_weights_out,
+                                        phd_step_report* report_out)
+{
+    CHECK_M(m);
+    if (!expected_out || !map_out || !n_map_out) return fail(PHD_ERR_INVALID_ARG, "phd_multi_state_snapshot: null output");
+    std::vector<phd_pose> pp;
+    std::vector<float> lw;
+    phd_pose* poses = poses_out;
+    float* logw = log_weights_out;
+    if (!poses) { pp.resize((size_t)m->N); poses = pp.data(); }
+    if (!logw) { lw.resize((size_t)m->N); logw = lw.data(); }
+    PHDCHK(phd_multi_get_particles(m, poses, logw));
+    // src/main.cpp:331-356: weighted-mean pose, arg-max weight (first maximum)
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    float best = -3.4028235e38f;
+    int bi = -1;
+    for (int i = 0; i < m->N; ++i) {
+        const double w = exp((double)logw[i]);
+        acc[0] += w * poses[i].px; acc[1] += w * poses[i].py; acc[2] += w * poses[i].ptheta;
+        acc[3] += w * poses[i].vx; acc[4] += w * poses[i].vy; acc[5] += w * poses[i].vtheta;
+        if (logw[i] > best) { best = logw[i]; bi = i; }
+    }
+    if (bi < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
+    if (m->N == 1) *expected_out = poses[0];                                           // src/main.cpp:381-384
+    else {
+        expected_out->px = (float)acc[0]; expected_out->py = (float)acc[1]; expected_out->ptheta = (float)acc[2];
+        expected_out->vx = (float)acc[3]; expected_out->vy = (float)acc[4]; expected_out->vtheta = (float)acc[5];
+    }
+    if (particle_out) *particle_out = bi;
+    PHDCHK(phd_get_map(m->sh[bi / m->n].f, bi % m->n, map_out, capacity, n_map_out));
+    if (report_out) {
+        phd_step_report tot;
+        memset(&tot, 0, sizeof(tot));
+        int rc_all = PHD_OK;
+        for (int k = 0; k < m->world; ++k) {
+            phd_step_report r;
+            memset(&r, 0, sizeof(r));
+            const int rc = phd_step_report_get(m->sh[k].f, &r);
+            if (rc != PHD_OK && rc_all == PHD_OK) rc_all = rc;
+            tot.status |= r.status;
+            tot.max_survivors = std::max(tot.max_survivors, r.max_survivors);
+            tot.max_map = std::max(tot.max_map, r.max_map);
+            if (k == 0) { tot.neff = r.neff; tot.did_resample = r.did_resample; }
+        }
+        *report_out = tot;
+        if (rc_all != PHD_OK) return rc_all;
+        if (tot.neff != tot.neff) return fail(PHD_ERR_NAN, "nan weights detected");
+    }
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_expected_map(phd_multi* m, phd_gaussian2d* out, int capacity, int32_t* n_out)
+{
+    CHECK_M(m);
+    // every shard concatenates its weighted maps on its device; shard 0 collects the planes in global particle order
+    std::vector<float*> planes((size_t)m->world, nullptr);
+    std::vector<int64_t> tot((size_t)m->world, 0);
+    int64_t T = 0;
+    for (int k = 0; k < m->world; ++k) {
+        PHDCHK(phd_expected_map_concat_dev(m->sh[k].f, &planes[k], &tot[k]));     // synchronises shard k's stream
+        T += tot[k];
+    }
+    if (T == 0) { if (n_out) *n_out = 0; return PHD_OK; }
+    if (m->world == 1) return phd_gm_reduce_dev(m->sh[0].f, planes[0], T, 6, m->cfg.minSeparation, out, capacity, n_out);
+    Shard& s0 = m->sh[0];
+    HIPCHK(hipSetDevice(s0.device));
+    float* all = nullptr;
+    HIPCHK(hipMalloc((void**)&all, (size_t)6 * T * sizeof(float)));
+    int64_t off = 0;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < m->world && e == hipSuccess; ++k) {
+        for (int pl = 0; pl < 6 && e == hipSuccess && tot[k] > 0; ++pl)
+            e = hipMemcpyPeerAsync(all + (size_t)pl * T + off, s0.device, planes[k] + (size_t)pl * tot[k], m->sh[k].device,
+                                   (size_t)tot[k] * sizeof(float), s0.stream);
+        off += tot[k];
+    }
+    int rc = e == hipSuccess ? phd_gm_reduce_dev(s0.f, all, T, 6, m->cfg.minSeparation, out, capacity, n_out)
+                             : fail(PHD_ERR_HIP, hipGetErrorString(e));
+    (void)hipStreamSynchronize(s0.stream);
+    (void)hipFree(all);
+    return rc;
+}
+
+// run_synth's order with the state log between update and resample (src/main.cpp:1260-1297): phd_multi_update = phdPredict +
+// phdUpdateSynth + the global weight normalisation (every shard adopts its slice; the global nEff lands in the step report);
+// phd_multi_resample = resampleParticles over the global set (the caller decides: nEff <= threshold and the step had
+// measurements, :1286)
+extern "C" int phd_multi_update(phd_multi* m, const phd_ackerman_control* u, const phd_ackerman_noise* noise,
+                                const phd_measurement* z, int n_meas)
+{
+    CHECK_M(m);
+    PHDCHK(phd_multi_upload_inputs(m, noise, z, n_meas));
+    PHDCHK(peer_wait_consumed(m));
+    if (m->n_meas <= 0) {
+        if (u) for (auto& s : m->sh) PHDCHK(phd_step_local_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
+        return PHD_OK;
+    }
+    PHDCHK(update_stage(m, u));
+    for (int k = m->world - 1; k >= 0; --k) PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->N, nullptr));
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_resample(phd_multi* m, double uniform)
+{
+    CHECK_M(m);
+    return resample_stage(m, uniform, false);
+}

@@ -27,7 +27,8 @@ __device__ __forceinline__ u64 splitmix64(u64 x)
 __device__ __forceinline__ void draw_noise(u64 seed, u64 counter, int i, const DevConfig& cfg, float& n_alpha,
                                            float& n_encoder)
 {
-    u64 a = splitmix64(seed ^ splitmix64(counter * 0x100000001B3ull + (u64)i * 2ull));
+    // the GLOBAL particle index: a sharded filter draws what the single filter draws
+    u64 a = splitmix64(seed ^ splitmix64(counter * 0x100000001B3ull + (u64)(i + cfg.particleOffset) * 2ull));
     u64 b = splitmix64(a);
     float u1 = ((float)((a >> 40) + 1)) * (1.0f / 16777216.0f);
     float u2 = ((float)(b >> 40)) * (1.0f / 16777216.0f);

@@ -297,6 +297,13 @@ int phd_finish_resample(phd_filter* f); /* weights <- -log(global_particles) */
 int phd_global_resample_begin(phd_filter* f, const float* d_all_raw_logw, double uniform, int world, int rank,
                               int32_t* send_counts, int32_t* recv_counts, void** d_send_buffer, int32_t* idx_out);
 int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer);
+/* phd_global_resample_begin in two halves, for a host that drives several shards from one thread (libphdslam_multi.so):
+ * every shard enqueues _launch (normalise — when d_all_raw_logw is given — and draw the global indices, no
+ * synchronisation; *d_idx_out = the device copy of the indices); the host downloads the indices ONCE (they are identical on
+ * every shard) and every shard plans its part of the migration and exports from that host copy with _plan. */
+int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_logw, double uniform, int32_t** d_idx_out);
+int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int world, int rank, int32_t* send_counts,
+                             int32_t* recv_counts, void** d_send_buffer);
 /* The same exchange for small shards with no host round trip ("gathered" exchange): phd_export_shard_dev packs the
  * whole shard (n rows of phd_particle_pack_bytes; header word 7 = the particle's un-normalised log-weight) into the
  * library's send buffer; the caller all-gathers the shards in rank order (one fixed-size RCCL all-gather);

@@ -27,6 +27,34 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(P._lib.SYMBOLS), declared ^ set(P._lib.SYMBOLS)
 
 
+def test_multi_library_exports_every_declared_symbol():
+    """include/phdslam_multi.h (the C++ multi-device host): libphdslam_multi.so loads without a GPU and exports what the
+    header declares; the ctypes binding covers exactly the header"""
+    import importlib
+    MM = importlib.import_module("cuda-phdslam_amd.multi")
+    M = MM.mlib()
+    hdr = open(os.path.join(ROOT, "include", "phdslam_multi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(phd_multi_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(M, name), "libphdslam_multi.so does not export %s" % name
+    assert declared == set(MM.MULTI_SYMBOLS), declared ^ set(MM.MULTI_SYMBOLS)
+    # no device here: creation fails loudly, like phd_create
+    P = pkg()
+    if not P_has_gpu():
+        with pytest.raises(P.PhdError):
+            MM.MultiFilter(P.default_config(n_particles=64), n_shards=2, devices=[0, 0])
+
+
+def P_has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
 def test_pod_layouts_match_the_reference():
     """sizes/offsets measured from the reference's src/slamtypes.h with the reference header itself"""
     P = pkg()

@@ -286,3 +286,31 @@ int main(int argc, char** argv) {
     for i in range(N):
         t = out[2 + 2 * N * k + i].split()
         assert int(t[2]) == idx[i] and int(t[3]) == sizes_after[i]
+
+
+@pytest.mark.parametrize("extra", [["--devices", "1"], ["--devices", "1", "--shards", "3"]])
+def test_driver_sharded_equals_single_device(tmp_path, extra):
+    """phdslam --devices N [--shards S] (the C++ multi-device host: RCCL on a one-rank communicator / three shards sharing the
+    GPU through device copies) writes the logs the single-device run writes: maps, weights and poses character for
+    character; the expected pose (summed on the host in double by the sharded host) to the log's 6 digits"""
+    d = str(tmp_path)
+    cfg_path = write_dataset(d, n_steps=6, n_particles=48)
+    outs = []
+    for name, args in (("one", []), ("multi", extra)):
+        o = os.path.join(d, name)
+        os.makedirs(o)
+        r = subprocess.run([os.path.join(PKG, "bin", "phdslam"), cfg_path, "synth", "--out", o, "--seed", "9", "--capacity", "256"] + args,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append((o, r.stdout))
+    assert "sharded filter: 48 particles" in outs[1][1]
+    resampled = 0
+    for n in range(6):
+        a = open(os.path.join(outs[0][0], "state_estimate%05d.log" % n)).read().split("\n")
+        b = open(os.path.join(outs[1][0], "state_estimate%05d.log" % n)).read().split("\n")
+        assert a[1:] == b[1:], n                                   # map, weights, poses, cardinality line
+        assert np.allclose([float(x) for x in a[0].split()], [float(x) for x in b[0].split()], rtol=2e-5, atol=1e-6), n
+    for line_a, line_b in zip(outs[0][1].split("\n"), outs[1][1].split("\n")[1:]):
+        if "resampled=1" in line_a:
+            resampled += 1
+    assert resampled >= 1

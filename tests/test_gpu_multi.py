@@ -1,0 +1,122 @@
+"""The C++ multi-device host (include/phdslam_multi.h, libphdslam_multi.so) on hardware: one filter sharded over several
+shards must equal a single filter BIT FOR BIT — particles, weights, maps — whatever the shard count, the transport (RCCL on a
+one-rank communicator; stream-ordered device copies when shards share the one GPU of a test box) and the exchange form
+(whole-shard all-gather / all-to-all of the migrants), with forced and nEff-triggered resampling, host noise and the
+device generator (which draws by GLOBAL particle index)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from parity_utils import pkg, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def mod():
+    return importlib.import_module("cuda-phdslam_amd.multi")
+
+
+def run_single(cfg, w, steps, cap, M, device_rng, force_pattern):
+    P = pkg()
+    out = []
+    with P.PhdFilter(cfg, n_particles=w["N"], map_capacity=cap, max_measurements=M) as f:
+        f.seed(77)
+        f.set_particles(w["poses"], w["logw"])
+        f.set_maps(w["maps"], w["sizes"])
+        for k in range(steps):
+            f.predict((2.0, 0.05 - 0.01 * k), None if device_rng else w["noise"][k])
+            f.update(w["z"][k])
+            if force_pattern[k]:
+                f.resample(w["uniform"][k])
+                did = True
+            else:
+                did, _ = f.resample_if_needed(w["uniform"][k], had_measurements=True)
+            p, lw = f.get_particles()
+            out.append((did, p, lw, f.get_maps()))
+        f.status()
+    return out
+
+
+@pytest.mark.parametrize("shards,exchange", [(1, "gathered"), (1, "alltoall"), (2, "gathered"), (2, "alltoall"),
+                                             (4, "alltoall"), (8, "gathered")])
+@pytest.mark.parametrize("device_rng", [False, True])
+def test_sharded_filter_equals_one_filter(shards, exchange, device_rng):
+    P, S, MM = pkg(), synthetic(), mod()
+    N, G, M, steps = 64, 14, 9, 5
+    w = S.make_workload(N, G, M, seed=300 + shards, n_meas_sets=steps)
+    # a skewed weight vector so that the nEff trigger fires on some steps and not on others
+    w["logw"] = (w["logw"] + np.linspace(0, 3.0, N).astype(np.float32)).astype(np.float32)
+    cfg = P.default_config(n_particles=N, resampleThresh=0.6)
+    force = [True, False, False, True, False]
+    ref = run_single(cfg, w, steps, 96, 16, device_rng, force)
+    with MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=96, max_measurements=16,
+                        exchange=MM.EXCHANGE_GATHERED if exchange == "gathered" else MM.EXCHANGE_ALLTOALL) as m:
+        assert m.n_shards == shards and m.n == N
+        assert m.uses_rccl == (shards == 1)              # one shard: a one-rank RCCL communicator; more on one GPU: device copies
+        assert m.gathered == (exchange == "gathered")
+        m.seed(77)
+        m.set_particles(w["poses"], w["logw"])
+        m.set_maps(w["maps"], w["sizes"])
+        fired = []
+        for k in range(steps):
+            did = m.step((2.0, 0.05 - 0.01 * k), None if device_rng else w["noise"][k], w["z"][k], w["uniform"][k],
+                         force_resample=force[k])
+            fired.append(did)
+            p, lw = m.get_particles()
+            maps = m.get_maps()
+            rdid, rp, rlw, rmaps = ref[k]
+            assert did == rdid, (k, did, rdid)
+            assert np.array_equal(p, rp), k
+            assert np.array_equal(lw, rlw), (k, np.abs(lw - rlw).max())
+            for a, b in zip(maps, rmaps):
+                assert np.array_equal(a, b), k
+        assert any(f and not fo for f, fo in zip(fired, force)) or any((not f) for f in fired)   # the trigger was exercised
+        e, gmap, who, poses, lw = m.state_snapshot()
+        assert m.last_report.status == 0
+    # the snapshot against the single filter's state extraction (pose accumulated on the host in double here)
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=96, max_measurements=16) as f:
+        f.set_particles(ref[-1][1], ref[-1][2])
+        f.set_maps(np.zeros((N, 0), P.GAUSSIAN), np.zeros(N, np.int32))
+        e1 = f.expected_pose()
+    for fld in ("px", "py", "ptheta"):
+        assert abs(e[fld] - e1[fld]) < 1e-5
+    assert who == int(np.argmax(ref[-1][2])) and np.array_equal(gmap, ref[-1][3][who])
+
+
+def test_frozen_steps_and_expected_map():
+    """the bench protocol on the sharded filter (frozen: every step restarts from the same snapshot), and the EAP map of the
+    global set reduced on shard 0 == the single filter's"""
+    P, S, MM = pkg(), synthetic(), mod()
+    N = 48
+    w = S.make_workload(N, 12, 8, seed=17)
+    cfg = P.default_config(n_particles=N)
+    with MM.MultiFilter(cfg, n_shards=3, devices=[0, 0, 0], map_capacity=64, max_measurements=16) as m, \
+            P.PhdFilter(cfg, n_particles=N, map_capacity=64, max_measurements=16) as f:
+        for x in (m, f):
+            x.set_particles(w["poses"], w["logw"])
+            x.set_maps(w["maps"], w["sizes"])
+        assert len(m.expected_map()) == len(f.expected_map())
+        assert np.array_equal(m.expected_map(), f.expected_map())
+        m.set_frozen(True)
+        m.upload_inputs(w["noise"][0], w["z"][0])
+        for _ in range(3):
+            m.step_resident((2.0, 0.05), 0.4, force_resample=True)
+        m.sync()
+        p, lw = m.get_particles()
+        assert np.array_equal(p, w["poses"]) and np.array_equal(lw, w["logw"])
+        for a, b in zip(m.get_maps(), [w["maps"][q] for q in range(N)]):
+            assert np.array_equal(a, b)
+        m.set_frozen(False)
+        m.step_resident((2.0, 0.05), 0.4, force_resample=True)
+        assert not np.array_equal(m.get_particles()[0], w["poses"])
+
+
+def test_rejects_what_it_cannot_shard():
+    P, MM = pkg(), mod()
+    with pytest.raises(P.PhdError):
+        MM.MultiFilter(P.default_config(n_particles=50), n_shards=4, devices=[0] * 4)             # 50 % 4 != 0
+    with pytest.raises(P.PhdError):
+        MM.MultiFilter(P.default_config(n_particles=64, nPredictParticles=2), n_shards=2, devices=[0, 0])
+    with pytest.raises(P.PhdError):
+        MM.MultiFilter(P.default_config(n_particles=64), n_shards=2, devices=[0, 0], transport=MM.TRANSPORT_RCCL)
