@@ -499,6 +499,43 @@ def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, loca
     return res
 
 
+def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, n_shards, preroll_ms):
+    """the N > 1 step driven by the C++ multi-device host (libphdslam_multi.so, include/phdslam_multi.h) inside THIS process:
+    n_shards = 1 is a one-rank RCCL communicator (what the collective path costs before any link is involved); more shards
+    on this one GPU exchange by device copies (a dry run of the sharding logic, not a measurement of links)"""
+    MM = importlib.import_module("cuda-phdslam_amd.multi")
+    c = S.CONFIGS[cfg_id]
+    N, G, M = c["N"], c["G"], c["M"]
+    w = S.make_workload(N, G, M, seed=0x5EED0000 + cfg_id, clustered=c["clustered"])
+    cfg = P.default_config(n_particles=N)
+    ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "gathered": MM.EXCHANGE_GATHERED}.get(os.environ.get("PHD_BENCH_EXCHANGE", ""), MM.EXCHANGE_AUTO)
+    m = MM.MultiFilter(cfg, n_shards=n_shards, devices=[0] * n_shards, map_capacity=2 * G, max_measurements=M, exchange=ex)
+    m.set_particles(w["poses"], w["logw"])
+    m.set_maps(w["maps"], w["sizes"])
+    m.set_frozen(True)
+    m.upload_inputs(w["noise"][0], w["z"][0])
+    u = float(np.random.default_rng(0x5EED0000 + cfg_id).random())
+    control = (2.0, 0.05)
+
+    def step():
+        m.step_resident(control, u, force_resample=True)
+
+    def sync():
+        m.sync()
+
+    ts = torch.cuda.current_stream()
+    # (the shards run on their own streams: the event-based percentiles of timed_loop do not see them; wall clock only)
+    elapsed, _, _, preroll = timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms)
+    res = {"value": steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "preroll_steps": preroll,
+           "config": {"workload": "C++ multi-device host (libphdslam_multi.so): config %d (%d x %d x %d) as ONE filter over %d shard(s) on "
+                                  "this GPU, transport %s, exchange %s, forced resample, frozen snapshot" %
+                                  (cfg_id, N, G, M, n_shards, "RCCL (one-rank communicator)" if m.uses_rccl else "device copies",
+                                   "gathered" if m.gathered else "alltoall"),
+                      "cpp_multi_host": True, "n_shards": n_shards, "rccl": m.uses_rccl}}
+    m.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -550,6 +587,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     secondary = []
+    if os.environ.get("PHD_BENCH_CPP_MULTI") and world == 1:
+        # diagnostic: the multi-device step through the C++ host in this process (labelled in config; not the N = 1 headline)
+        torch.cuda.set_device(0)
+        res = run_cpp_multi(P, S, torch, args.config or 2, args.steps, args.warmup, int(os.environ["PHD_BENCH_CPP_MULTI"]),
+                            args.preroll_ms)
+        print(json.dumps({"metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas", "value": res["value"], "unit": "steps/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "preroll_steps": res["preroll_steps"],
+                          "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic", "config": res["config"], "roofline": None, "cpu_baseline": None}))
+        return
     if not multi:
         cfg_id = args.config or 3
         res = run_single(P, S, torch, cfg_id, args.steps, args.warmup, 0.0 if args.bare else args.cpu_seconds, dev, local_rank,

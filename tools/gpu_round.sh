@@ -32,6 +32,11 @@ for ex in gathered alltoall; do
   PHD_BENCH_EXCHANGE=$ex PHD_BENCH_ONE_RANK_RCCL=1 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 2> /dev/null | grep metric > gpurun_out/bench_cfg2_onerank_${ex}_$tag.json
   cut -c1-200 gpurun_out/bench_cfg2_onerank_${ex}_$tag.json
 done
+# the same N > 1 step driven by the C++ multi-device host (libphdslam_multi.so): one-rank RCCL, both exchange forms
+for ex in gathered alltoall; do
+  PHD_BENCH_EXCHANGE=$ex PHD_BENCH_CPP_MULTI=1 python bench.py --config 2 --steps 2000 --warmup 100 2> /dev/null | grep metric > gpurun_out/bench_cfg2_cpp_multi_onerank_${ex}_$tag.json
+  cut -c1-200 gpurun_out/bench_cfg2_cpp_multi_onerank_${ex}_$tag.json
+done
 cd /tmp && export TMPDIR=/tmp
 for cfg in 3 2 5; do
   st=50; wu=40; [ $cfg = 2 ] && st=2000 && wu=200
