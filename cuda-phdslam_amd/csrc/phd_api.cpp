@@ -67,6 +67,12 @@ struct phd_filter {
     int n_base = 0, n_max = 0;
     float* logw_alt = nullptr; // second log-weight buffer (shotgun predict writes out of place)
     int cap = 0, MM = 0, S_cap = 0, device = 0;
+    // spill path: survivor lists longer than the LDS capacity (created with survivor_capacity > 2048): records in HBM and the
+    // plain global-memory merge of phd_spill.h for the particles that need it
+    int spill_cap = 0;
+    float* spill_rec = nullptr;
+    int* spill_meta = nullptr;
+    unsigned short* spill_out = nullptr;
     int n_global = 0, global_offset = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -222,6 +228,9 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     S = next_pow2(std::max(S, 256)); // the register sorts own 256*E slots
     if (S > 2048) S = 2048; // register-staged permutation in merge_in_lds handles <= 2048
     f->S_cap = S;
+    // a request beyond what LDS holds: the spill list (every particle can then carry up to survivor_capacity survivors;
+    // those with more than 2048 take the global-memory merge of phd_spill.h — slower, but no PHD_ERR_CAPACITY)
+    if (o.survivor_capacity > 2048) f->spill_cap = std::min((o.survivor_capacity + 511) / 512 * 512, 32768);
     f->lds_bytes = update_lds_bytes(f->S_cap, f->cap, f->MM);
     if (cfg->filterType == 1) {
         f->cphd = true;
@@ -262,6 +271,11 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->d_tmp_int, f->n_max));
     A(dalloc(&f->ticket, 1));
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
+    if (f->spill_cap) {
+        A(dalloc(&f->spill_rec, (size_t)f->n_max * 2 * f->spill_cap * 8));
+        A(dalloc(&f->spill_meta, (size_t)f->n_max * 4));
+        A(dalloc(&f->spill_out, (size_t)f->n_max * f->cap));
+    }
     if (f->cphd) {
         A(dalloc(&f->cn[0], (size_t)f->n_max * f->cn_len)); A(dalloc(&f->cn[1], (size_t)f->n_max * f->cn_len));
         A(dalloc(&f->d_lfact, f->lfact_len));
@@ -317,6 +331,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
+    hipFree(f->spill_rec); hipFree(f->spill_meta); hipFree(f->spill_out);
     gm_workspace_destroy(f->gm);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     delete f;
@@ -643,8 +658,9 @@ extern "C" int phd_predict_ackerman(phd_filter* f, phd_ackerman_control u, const
 static int ensure_debug(phd_filter* f)
 {
     if (f->dbg_surv) return PHD_OK;
-    HIPCHK(dalloc(&f->dbg_surv, (size_t)f->n_max * 6 * f->S_cap));
-    HIPCHK(dalloc(&f->dbg_u, (size_t)f->n_max * f->S_cap));
+    const int dc = f->spill_cap ? f->spill_cap : f->S_cap;
+    HIPCHK(dalloc(&f->dbg_surv, (size_t)f->n_max * 6 * dc));
+    HIPCHK(dalloc(&f->dbg_u, (size_t)f->n_max * dc));
     HIPCHK(dalloc(&f->dbg_n, f->n_max));
     HIPCHK(dalloc(&f->dbg_nin, f->n_max));
     return PHD_OK;
@@ -703,6 +719,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         int rc = ensure_debug(f);
         if (rc) return rc;
         a.dbg_surv = f->dbg_surv; a.dbg_u = f->dbg_u; a.dbg_n = f->dbg_n; a.dbg_nin = f->dbg_nin;
+        a.dbg_cap = f->spill_cap ? f->spill_cap : f->S_cap;
     }
     if (f->want_stamps) {
         if (!f->stamps) {
@@ -724,6 +741,9 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         a.lfact_len = f->lfact_len;
         a.cphd_scratch = f->cphd_scratch;
     }
+    if (f->spill_cap) {
+        a.spill_rec = f->spill_rec; a.spill_meta = f->spill_meta; a.spill_out = f->spill_out; a.spill_cap = f->spill_cap;
+    }
     a.cfg = f->dcfg;
     int free_pose = 0;
     if (fw) {
@@ -733,6 +753,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     }
     t_begin(f, PHD_K_UPDATE_MERGE);
     HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream));
+    HIPCHK(launch_merge_spill(a, f->n, f->stream));   // (a no-op without a spill list) particles whose survivors outgrew LDS
     t_end(f);
     f->last_M = M;
     if (!f->frozen) {
@@ -1580,10 +1601,11 @@ extern "C" int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian
     int n = 0, nin = 0;
     HIPCHK(hipMemcpyAsync(&n, f->dbg_n + particle, sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(&nin, f->dbg_nin + particle, sizeof(int), hipMemcpyDeviceToHost, f->stream));
-    std::vector<float> s((size_t)6 * f->S_cap);
-    std::vector<int> u(f->S_cap);
-    HIPCHK(hipMemcpyAsync(s.data(), f->dbg_surv + (size_t)particle * 6 * f->S_cap, s.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(u.data(), f->dbg_u + (size_t)particle * f->S_cap, u.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    const int dc = f->spill_cap ? f->spill_cap : f->S_cap;
+    std::vector<float> s((size_t)6 * dc);
+    std::vector<int> u(dc);
+    HIPCHK(hipMemcpyAsync(s.data(), f->dbg_surv + (size_t)particle * 6 * dc, s.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(u.data(), f->dbg_u + (size_t)particle * dc, u.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
     if (n_out) *n_out = n;
     if (!out) return PHD_OK;
@@ -1596,13 +1618,13 @@ extern "C" int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian
     int n_near = 0;
     for (int k = 0; k < n; ++k) {
         const int i = order[k];
-        out[k].weight = s[0 * f->S_cap + i];
-        out[k].mean[0] = s[1 * f->S_cap + i];
-        out[k].mean[1] = s[2 * f->S_cap + i];
-        out[k].cov[0] = s[3 * f->S_cap + i];
-        out[k].cov[1] = s[4 * f->S_cap + i];
-        out[k].cov[2] = s[4 * f->S_cap + i];
-        out[k].cov[3] = s[5 * f->S_cap + i];
+        out[k].weight = s[0 * dc + i];
+        out[k].mean[0] = s[1 * dc + i];
+        out[k].mean[1] = s[2 * dc + i];
+        out[k].cov[0] = s[3 * dc + i];
+        out[k].cov[1] = s[4 * dc + i];
+        out[k].cov[2] = s[4 * dc + i];
+        out[k].cov[3] = s[5 * dc + i];
         if (slab_index_out) slab_index_out[k] = (u[i] >= 0x40000000) ? (n_update + n_near++) : u[i];
     }
     return PHD_OK;

@@ -80,10 +80,11 @@ struct UpdateArgs {
     int cap;
     int S_cap;
     // inspection (NULL when disabled)
-    float* dbg_surv;            // [n][6][S_cap]
-    int* dbg_u;                 // [n][S_cap]
+    float* dbg_surv;            // [n][6][dbg_cap]
+    int* dbg_u;                 // [n][dbg_cap]
     int* dbg_n;                 // [n]
     int* dbg_nin;               // [n]
+    int dbg_cap;                // survivors per particle the inspection buffers hold (S_cap, or the spill capacity)
     unsigned long long* stamps; // [n][PHD_STAMP_ROW] phase stamps (diagnostic instantiation) or NULL
     // fused vehicle predict (phd_step_dev): pose <- f(pose, control, noise) before the update
     int do_predict;
@@ -106,6 +107,11 @@ struct UpdateArgs {
     const float* lfact;         // log factorials 0..lfact_len-1 (initCphdConstants, src/phdfilter.cu.bak:421-425)
     int lfact_len;
     float2* cphd_scratch;       // [n][MM][MM] (mantissa, exponent) rows of the ESF backward sweep
+    // spill path (survivor lists longer than S_cap; NULL / 0 when not enabled): see phd_spill.h
+    float* spill_rec;           // [n][2][spill_cap][8] survivor records, and the sorted copy phd_merge_spill_kernel works on
+    int* spill_meta;            // [n][4]: survivor count (0: the LDS merge handled the particle), n_update, n_out0, -
+    unsigned short* spill_out;  // [n][cap] indices of the untouched out-of-range features
+    int spill_cap;              // records per particle
     DevConfig cfg;
 };
 
@@ -118,6 +124,7 @@ hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, c
 int update_fuse_max_particles();
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
+hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st);   // no-op unless a.spill_rec
 hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman_control u,
                           const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,
                           hipStream_t st);

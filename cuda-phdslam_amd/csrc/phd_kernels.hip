@@ -46,6 +46,7 @@
 #include "phd_predict.h"
 #include "phd_cphd.h"
 #include "phd_weights.h"
+#include "phd_spill.h"
 
 namespace phd {
 
@@ -122,6 +123,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const unsigned rows_stride = FUSEW ? 0u : A.out_stride; // rows mode belongs to the multi-GPU step (never the fused tail)
     float* __restrict__ out = A.map_out + (size_t)p * (rows_stride ? rows_stride : (size_t)6 * cap);
     const int n_map = A.count_in[src];
+    // survivors past the LDS capacity go to this particle's record list in HBM (when the filter was created with one)
+    const SpillRef sp = {A.spill_rec ? A.spill_rec + (size_t)p * 2 * A.spill_cap * 8 : nullptr, A.spill_cap};
+    if (A.spill_meta && tid == 0) A.spill_meta[(size_t)p * 4] = 0;
     phd_pose pose = A.pose[p];
     if (A.do_predict) {
         // fused vehicle predict: every lane computes the same pose (no broadcast needed); lane 0 stores it after the
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                 const bool keep = (cls == 2) || (cls == 1 && !(wnd < cfg.minFeatureWeight));
                 const int slot = alloc_slots(keep, L.ctr);
                 if (keep) store_survivor(L, slot, S_cap, cls == 2 ? w : wnd, mx, my, pxx, pxy, pyy,
-                                         cls == 2 ? NEAR_U_BASE + i : nd_j);
+                                         cls == 2 ? NEAR_U_BASE + i : nd_j, sp);
             }
             n_in += tot_in; n_out0 += tot_out;
             __syncthreads();
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const bool keep = mv && !(wb < cfg.minFeatureWeight);
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
-                                     L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m);
+                                     L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp);
         }
         // missed detections of the in-range features: w (1 - pd) r1 (.bak:1445-1460)
         for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const bool keep = jv && !(wnd < cfg.minFeatureWeight);
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) store_survivor(L, slot, S_cap, wnd, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i], in[4 * cap + i],
-                                     in[5 * cap + i], j);
+                                     in[5 * cap + i], j, sp);
         }
         // nearly-in-range features (pD = 0): weight w r1, join the merge unpruned like HEAD (:3242-3257)
         const int n_near = L.ctr[CTR_NNEAR];
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const int i = L.out_idx[cap - 1 - (kv ? k : 0)];
             const int slot = alloc_slots(kv, L.ctr);
             if (kv) store_survivor(L, slot, S_cap, in[0 * cap + i] * r1, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i],
-                                   in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i);
+                                   in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i, sp);
         }
         if (tid == 0) {
             if (FUSEW) { // as in the PHD branch below: the last hand-off store, then the ticket
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const bool keep = !(wb < cfg.minFeatureWeight);
         const int slot = alloc_slots(keep, L.ctr);
         if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
-                                 L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m);
+                                 L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp);
     }
     {
         float lz_sum, pdw;
@@ -392,7 +396,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
                 if (slot < S_cap) { L.w[slot] = w; L.u[slot] = n_in + m * n_in + j; }
-                else L.ctr[CTR_OVERFLOW] = 1;
+                else {   // past the LDS capacity: the complete record goes to the spill list (no finalise pass there)
+                    const v4f K = L.f_k[j], Pn = L.f_p[j];
+                    spill_store(sp, L, slot, w, Pn.w + K.x * i0 + K.z * i1, L.f_my[j] + K.y * i0 + K.w * i1, Pn.x, Pn.y, Pn.z,
+                                n_in + m * n_in + j);
+                }
             }
         }
     } else
@@ -417,7 +425,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
                 if (slot < S_cap) { L.w[slot] = w; L.u[slot] = n_in + m * n_in + j; }
-                else L.ctr[CTR_OVERFLOW] = 1;
+                else {
+                    const v4f K = L.f_k[jj], Pn = L.f_p[jj];
+                    spill_store(sp, L, slot, w, Pn.w + K.x * i0 + K.z * i1, L.f_my[jj] + K.y * i0 + K.w * i1, Pn.x, Pn.y, Pn.z,
+                                n_in + m * n_in + j);
+                }
             }
         }
     }
@@ -445,20 +457,68 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     STAMP(5);
     int n_surv = L.ctr[CTR_NSURV];
     unsigned status = 0;
-    if (n_surv > S_cap) { n_surv = S_cap; status |= PHD_STATUS_SURVIVOR_OVERFLOW; }
+    // more survivors than LDS holds: with a spill list (and room in it) the particle's merge is handed to
+    // phd_merge_spill_kernel; without one the list is truncated and the step reports PHD_ERR_CAPACITY
+    const bool spilled = n_surv > S_cap && sp.rec && n_surv <= sp.cap && !L.ctr[CTR_OVERFLOW];
+    const int n_all = n_surv;
+    if (n_surv > S_cap) { n_surv = S_cap; if (!spilled) status |= PHD_STATUS_SURVIVOR_OVERFLOW; }
     if (L.ctr[CTR_OVERFLOW]) status |= PHD_STATUS_SURVIVOR_OVERFLOW;
+    if (spilled) {
+        // the LDS-resident survivors join the records (list position = arrival slot), then the hand-over data
+        for (int i = tid; i < S_cap; i += PHD_T) {
+            float* r = sp.rec + (size_t)i * 8;
+            r[0] = L.w[i]; r[1] = L.mx[i]; r[2] = L.my[i]; r[3] = L.xx[i]; r[4] = L.xy[i]; r[5] = L.yy[i];
+            r[6] = __int_as_float(L.u[i]); r[7] = 0.f;
+        }
+        unsigned short* oi = A.spill_out + (size_t)p * cap;
+        for (int i = tid; i < n_out0; i += PHD_T) oi[i] = L.out_idx[i];
+        if (tid == 0) {
+            int* meta = A.spill_meta + (size_t)p * 4;
+            meta[1] = n_in * (M + 1) + M;
+            meta[2] = n_out0;
+            meta[3] = __float_as_int(CPHD ? Q.scal[CQ_R1] : 1.f);
+            meta[0] = n_all;
+        }
+    }
 
     // optional inspection copy of the survivors (parity tests)
     if (A.dbg_surv) {
-        float* d = A.dbg_surv + (size_t)p * 6 * S_cap;
-        int* du = A.dbg_u + (size_t)p * S_cap;
-        for (int i = tid; i < n_surv; i += PHD_T) {
-            d[0 * S_cap + i] = L.w[i]; d[1 * S_cap + i] = L.mx[i]; d[2 * S_cap + i] = L.my[i];
-            d[3 * S_cap + i] = L.xx[i]; d[4 * S_cap + i] = L.xy[i]; d[5 * S_cap + i] = L.yy[i];
-            du[i] = L.u[i];
+        const int dc = A.dbg_cap;
+        float* d = A.dbg_surv + (size_t)p * 6 * dc;
+        int* du = A.dbg_u + (size_t)p * dc;
+        const int n_dbg = spilled ? (n_all < dc ? n_all : dc) : n_surv;
+        __syncthreads();   // (the records of the spill list written above, by other threads)
+        for (int i = tid; i < n_dbg; i += PHD_T) {
+            if (i < S_cap) {
+                d[0 * dc + i] = L.w[i]; d[1 * dc + i] = L.mx[i]; d[2 * dc + i] = L.my[i];
+                d[3 * dc + i] = L.xx[i]; d[4 * dc + i] = L.xy[i]; d[5 * dc + i] = L.yy[i];
+                du[i] = L.u[i];
+            } else {
+                const float* r = sp.rec + (size_t)i * 8;
+                d[0 * dc + i] = r[0]; d[1 * dc + i] = r[1]; d[2 * dc + i] = r[2];
+                d[3 * dc + i] = r[3]; d[4 * dc + i] = r[4]; d[5 * dc + i] = r[5];
+                du[i] = __float_as_int(r[6]);
+            }
         }
-        if (tid == 0) { A.dbg_n[p] = n_surv; A.dbg_nin[p] = n_in; }
+        if (tid == 0) { A.dbg_n[p] = n_dbg; A.dbg_nin[p] = n_in; }
         __syncthreads(); // the merge permutes the planes the copy reads
+    }
+    if (spilled) {
+        // everything but the merged map: indirection reset, export-row header, status, survivor high-water mark
+        if (tid == 0) {
+            if (!FUSEW && A.parent_reset) A.parent_reset[p] = p;
+            if (rows_stride) {
+                float* h = out - 8;
+                const float* ps = (const float*)(A.do_predict ? &A.pose_out[p] : &A.pose[p]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) h[k] = ps[k];
+                h[7] = A.raw_out[p];
+            }
+            if (status) atomicOr(A.status, status);
+            if (n_all > __hip_atomic_load(A.max_surv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(A.max_surv, n_all);
+        }
+        STAMP(11);
+        return;
     }
 
     // ---- merge ----------------------------------------------------------------------------------------
@@ -759,6 +819,13 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles + 1), dim3(PHD_T), lds_bytes, st, a); // + the weights workgroup
     else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
     else hipLaunchKernelGGL((phd_update_merge_kernel<false, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st)
+{
+    if (!a.spill_rec) return hipSuccess;
+    hipLaunchKernelGGL(phd_merge_spill_kernel, dim3(n_particles), dim3(PHD_T), 0, st, a);
     return hipGetLastError();
 }
 

@@ -159,15 +159,34 @@ __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
     return slot;
 }
 
+// Survivors past the LDS capacity (dense scans of a large map: up to G (M + 1) + M update components, a few per cent of
+// which survive) go to a per-particle record list in HBM — records of 8 floats (w, mx, my, xx, xy, yy, slab index, -), list
+// position = slot — and the particle's merge is done by phd_merge_spill_kernel instead of the LDS merge (phd_spill.h).
+struct SpillRef {
+    float* rec;     // this particle's records (NULL: no spill path — overflow is an error)
+    int cap;        // records the list holds (LDS survivors included: they are copied in before the hand-over)
+};
+
+__device__ __forceinline__ void spill_store(const SpillRef& sp, const Lds& L, int slot, float w, float mx, float my, float xx,
+                                            float xy, float yy, int u)
+{
+    if (sp.rec && slot < sp.cap) {
+        float* r = sp.rec + (size_t)slot * 8;
+        r[0] = w; r[1] = mx; r[2] = my; r[3] = xx; r[4] = xy; r[5] = yy; r[6] = __int_as_float(u); r[7] = 0.f;
+    } else {
+        L.ctr[CTR_OVERFLOW] = 1;
+    }
+}
+
 __device__ __forceinline__ void store_survivor(const Lds& L, int slot, int S, float w, float mx, float my, float xx,
-                                               float xy, float yy, int u)
+                                               float xy, float yy, int u, const SpillRef& sp)
 {
     if (slot < S) {
         L.w[slot] = w; L.mx[slot] = mx; L.my[slot] = my;
         L.xx[slot] = xx; L.xy[slot] = xy; L.yy[slot] = yy;
         L.u[slot] = u;
     } else {
-        L.ctr[CTR_OVERFLOW] = 1;
+        spill_store(sp, L, slot, w, mx, my, xx, xy, yy, u);
     }
 }
 

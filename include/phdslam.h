@@ -133,7 +133,10 @@ typedef struct {
     int32_t n_particles;      /* particles held by THIS filter (a rank's shard); 0 = cfg->n_particles */
     int32_t map_capacity;     /* Gaussians per particle slab; 0 = 256                                   */
     int32_t max_measurements; /* <= PHD_MAX_MEASUREMENTS; 0 = 256                                       */
-    int32_t survivor_capacity;/* pruned update components kept per particle before merging; 0 = auto   */
+    int32_t survivor_capacity;/* pruned update components kept per particle before merging; 0 = auto (map_capacity + 8 max_measurements,
+                               * at most 2048 — what LDS holds).  > 2048 adds a spill list in HBM: particles with more than 2048
+                               * survivors (dense scans of large maps; the reference has no cap) are merged by a plain global-memory
+                               * kernel — slower, same results — instead of failing with PHD_ERR_CAPACITY; at most 32768       */
     int32_t device;           /* HIP device ordinal                                                      */
     void*   stream;           /* hipStream_t to enqueue on; NULL = the filter creates its own            */
     int32_t global_particles; /* total particles over all ranks (for -log N after a global resample); 0 = n_particles */
