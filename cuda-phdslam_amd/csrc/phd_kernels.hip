@@ -284,7 +284,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // ---- pass 1: normalisers (phd_pass1.h) -----------------------------------------------------------
     const Pass1Grid p1g = pass1_grid(M);
     pass1_normalisers(L, n_in, M, A.MM, tid, sparse2, c0m);
+    if (STAMPS && tid == 0) st[23] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
+    if (STAMPS && tid == 0) st[24] = __builtin_amdgcn_s_memrealtime();
     float lz_local = 0.f;
     if (CPHD) {
         // roots Xi_m = (lambda/kappa)(sum_j pd w_j g_jm + birthWeight) (.bak:1205-1222)

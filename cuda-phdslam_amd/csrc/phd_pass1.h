@@ -80,7 +80,7 @@ __device__ __forceinline__ Pass1Grid pass1_grid(int M)
 // Z_m's feature sum: the partial sums of the NF waves that own measurement m's chunk
 __device__ __forceinline__ float pass1_feature_sum(const Lds& L, const Pass1Grid& g, int m, int MM)
 {
-    const int cg = (m >> g.csh) & (g.NC - 1);
+    const int cg = (m % g.nchunks) & (g.NC - 1);           // chunk c holds the measurements c, c + nchunks, c + 2 nchunks, ...
     float s = L.zpart[cg * MM + m];
     for (int fg = 1; fg < g.NF; ++fg) s += L.zpart[(fg * g.NC + cg) * MM + m];
     return s;
@@ -117,6 +117,39 @@ __device__ __forceinline__ u32 pass1_octet(const float (&zr)[CH], const float (&
     return bits;
 }
 
+// The common case — every measurement of the chunk valid, every |z_b| < pi — two measurements per packed instruction
+// (v_pk_add / v_pk_mul / v_pk_fma: one issue slot, two pairs) and no branch between the pairs, so the compiler can
+// interleave them.  wrap_angle's conditional "+- 2 pi" becomes r = fma(-A, k, a), r = fma(-B, k, r) with
+// k = sign(a) [|a| >= pi]: a - A k is formed exactly and rounded once, like the subtraction it replaces (same bits).
+template <int CH>
+__device__ __forceinline__ u32 pass1_octet_packed(const float (&zr)[CH], const float (&zb)[CH], const v4f fa, const v2f fc,
+                                                  float c0m, float (&acc)[CH])
+{
+    const float PI_F = 3.14159274f, TWO_PI_F = 6.2831855f, B = -1.7484555e-7f;
+    const v2f r2 = (v2f){fa.x, fa.x}, b2 = (v2f){fa.y, fa.y}, s00 = (v2f){fa.z, fa.z}, s01 = (v2f){fa.w, fa.w},
+              s11 = (v2f){fc.x, fc.x}, lwb = (v2f){fc.y, fc.y};
+    u32 bits = 0;
+#pragma unroll
+    for (int q = 0; q < CH; q += 2) {
+        const v2f i0 = (v2f){zr[q], zr[q + 1]} - r2;
+        const v2f a = (v2f){zb[q], zb[q + 1]} - b2;
+        v2f k;
+        k.x = (fabsf(a.x) >= PI_F) ? copysignf(1.f, a.x) : 0.f;
+        k.y = (fabsf(a.y) >= PI_F) ? copysignf(1.f, a.y) : 0.f;
+        v2f i1 = __builtin_elementwise_fma((v2f){-TWO_PI_F, -TWO_PI_F}, k, a);
+        i1 = __builtin_elementwise_fma((v2f){-B, -B}, k, i1);
+        v2f dist = (i0 * i0) * s00;                                                                    // :1908-1910
+        dist = __builtin_elementwise_fma(i0 * i1, s01, dist);
+        dist = __builtin_elementwise_fma(i1 * i1, s11, dist);
+        const v2f lw = __builtin_elementwise_fma(dist, (v2f){-0.5f, -0.5f}, lwb);
+        const v2f l2 = lw * (v2f){1.44269504f, 1.44269504f};
+        acc[q] += __builtin_amdgcn_exp2f(l2.x);                                                       // :2205 (= __expf)
+        acc[q + 1] += __builtin_amdgcn_exp2f(l2.y);
+        bits |= (!(lw.x < c0m) ? (1u << q) : 0u) | (!(lw.y < c0m) ? (2u << q) : 0u);                  // NaN stays a candidate
+    }
+    return bits;
+}
+
 template <int CH>
 __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, int n_in, int M, int MM, int lane, int wave,
                                              bool sparse2, float c0m)
@@ -124,13 +157,15 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
     const int cg = wave & (g.NC - 1), fg = wave / g.NC;
     lds_u16 clist = (lds_u16)L.part;
     for (int c = cg; c < g.nchunks; c += g.NC) {
-        const int m0 = CH * c;
+        // chunk c = measurements c, c + nchunks, ...: strided, so that every chunk gets its share of the scan's dense part
+        // (a scan lists what the sensor saw in sensor order: consecutive measurements tend to hit the same piece of map)
+        const int mstep = g.nchunks;
         // the chunk's measurements (LDS broadcast reads: the same address in every lane)
         float zr[CH], zb[CH];
         u32 vmv = 0, slow = 0;
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
-            const int m = m0 + q, mm = m < M ? m : M - 1;
+            const int m = c + q * mstep, mm = m < M ? m : M - 1;
             zr[q] = L.z_r[mm];
             zb[q] = L.z_b[mm];
             const bool ok = (m < M) && L.zok[mm];
@@ -149,7 +184,9 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
             const v4f fa = L.f_a[jj];
             v2f fc = L.f_c[jj];
             if (j >= n_in) fc.y = -INFINITY;                      // contributes exp(-inf) = 0, never a candidate
-            u32 bits = fast ? pass1_octet<true, CH>(zr, zb, vm, fa, fc, c0m, acc) : pass1_octet<false, CH>(zr, zb, vm, fa, fc, c0m, acc);
+            u32 bits = (fast && vm == (1u << CH) - 1u) ? pass1_octet_packed<CH>(zr, zb, fa, fc, c0m, acc)
+                       : fast                          ? pass1_octet<true, CH>(zr, zb, vm, fa, fc, c0m, acc)
+                                                       : pass1_octet<false, CH>(zr, zb, vm, fa, fc, c0m, acc);
             if (sparse2) {
                 const int np = __popc(bits);
                 const int incl = (int)wave_incl_scan((u32)np);
@@ -161,7 +198,7 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
                     while (bits) {
                         const int q = __builtin_ctz(bits);
                         bits &= bits - 1;
-                        if (pos < PHD_CAND_CAP) clist[pos] = (u16)((m0 + q) * n_in + j);
+                        if (pos < PHD_CAND_CAP) clist[pos] = (u16)((c + q * mstep) * n_in + j);
                         ++pos;
                     }
                 }
@@ -169,8 +206,8 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
         }
         float tot;
         int m;
-        if (CH == 8) { tot = reduce8_over_wave((float (&)[8])acc, lane); m = m0 + (lane >> 3); }
-        else { tot = reduce4_over_wave((float (&)[4])acc, lane); m = m0 + (lane >> 4); }
+        if (CH == 8) { tot = reduce8_over_wave((float (&)[8])acc, lane); m = c + (lane >> 3) * mstep; }
+        else { tot = reduce4_over_wave((float (&)[4])acc, lane); m = c + (lane >> 4) * mstep; }
         if ((lane & (64 / CH - 1)) == 0 && m < M) L.zpart[wave * MM + m] = tot;
     }
 }

@@ -36,6 +36,10 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
               (cid, N, G, M, tot.mean(), tot.max(), span, f.status()))
         for k, name in enumerate(NAMES):
             print("   %-20s mean %8.2f us  (%5.1f %%)   max %8.2f" % (name, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean(), d[:, k].max()))
+        if st[:, 23].any():
+            print("   inside 'pass1 normalisers' (thread 0's wave): the (feature x measurement) sweep + candidate list %.2f us, wait for the "
+                  "slowest wave %.2f us, log Z + births + particle weight %.2f us" %
+                  (((st[:, 23] - st[:, 1]) * 0.01).mean(), ((st[:, 24] - st[:, 23]) * 0.01).mean(), ((st[:, 2] - st[:, 24]) * 0.01).mean()))
         r = st[:, 12:16].astype(np.float64)
         if cid == 5:
             print("   CPHD block (inside 'pass1 normalisers'): staging + predicted cardinality + n-sums %.2f us, backward ESF sweep %.2f us, "
