@@ -1,4 +1,4 @@
-"""Build-time guard on the hot kernel's register allocation (no GPU needed: hipcc cross-compiles): the production
+"""Build-time guards on the hot kernel's register allocation (no GPU needed: hipcc cross-compiles): the production
 instantiations of phd_update_merge_kernel must fit four waves per SIMD (<= 128 VGPRs) WITHOUT spilling to scratch —
 a spill turns LDS-resident work into HBM traffic (measured once in round 1: 42 MB -> 168 MB per launch at
 4096 x 256 x 64) and silently costs a few per cent."""
@@ -33,3 +33,44 @@ def test_production_kernels_do_not_spill():
         vgprs, scratch = found[names[0]]
         assert vgprs <= 128, (names[0], vgprs)
         assert scratch == 0, (names[0], scratch)
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+def test_sgpr_spills_stay_out_of_the_inner_loops(tmp_path):
+    """The update kernel keeps ~100 scalar values alive across its phases (35 LDS pointers, 30 kernel-argument pointers,
+    the configuration), more than the 102 SGPRs of a wave: the compiler parks the excess in lanes of a spare VGPR
+    (v_writelane / v_readlane with a constant lane — VALU instructions in a VALU-bound kernel).  VERDICT r1 asked to
+    bring `SGPRs Spill` to 0 or to show from the ISA that the spills sit outside the loops: this test does the latter
+    on every build — no spill reload or store at loop depth >= 2 of the production instantiations, and at most a few
+    dozen at depth 1 (the bodies of the phase loops: once per merge round / measurement chunk, not per pair)."""
+    asm = tmp_path / "k.s"
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+           "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(SRC, "phd_kernels.hip"), "-o", str(asm)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=SRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(asm).read()
+    checked = 0
+    for tag in ("ILb0ELb0ELb0E", "ILb0ELb1ELb0E", "ILb0ELb0ELb1E", "ILb0ELb1ELb1E"):
+        m = re.search(r"^(_ZN3phd23phd_update_merge_kernel" + tag + r"\w*):.*?\.end_amdhsa_kernel", text, re.S | re.M)
+        assert m, tag
+        body = m.group(0).split("\n")
+        # spill slots: VGPR lanes written with v_writelane from an SGPR at a CONSTANT lane index
+        holders = set(re.findall(r"v_writelane_b32 (v\d+), s\d+, \d+", m.group(0)))
+        depth, by_depth = 0, {}
+        for i, line in enumerate(body):
+            if re.match(r"^\.LBB\d+_\d+:|^; %bb\.", line):
+                ctx = line
+                k = i + 1
+                while k < len(body) and body[k].strip().startswith(";"):
+                    ctx += body[k]
+                    k += 1
+                d = re.findall(r"Depth[= ](\d+)", ctx)
+                depth = max(int(x) for x in d) if d else 0
+            sp = re.search(r"v_(?:readlane_b32 s\d+, (v\d+), \d+|writelane_b32 (v\d+), s\d+, \d+)\s*$", line.strip())
+            if sp and (sp.group(1) or sp.group(2)) in holders:
+                by_depth[depth] = by_depth.get(depth, 0) + 1
+        deep = sum(v for d, v in by_depth.items() if d >= 2)
+        assert deep == 0, (tag, by_depth)
+        assert by_depth.get(1, 0) <= 64, (tag, by_depth)
+        checked += 1
+    assert checked == 4
