@@ -287,6 +287,41 @@ __device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2*
         if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
 }
 
+// the same sums with the n-dependent part taken out of the loop: with B_n = log p(n) + log n! + n (log Wq - log W1)
+// (kept in the cnq array, free once the predicted cardinality exists), the term is B_n - log (n-j)! - j log Wq: two LDS
+// reads and one subtraction per term instead of three reads and six operations.  Needs finite log Wq, log W1 (an empty
+// map has Wq = 0: the caller then takes cphd_nsums, whose 0 * (-1e30) products are exact).
+template <int CH>
+__device__ __forceinline__ void cphd_nsums_fast(const CphdLds& Q, int M, int Nmax, int lane, int wave, float lWq)
+{
+#pragma clang fp contract(off)
+    const float LOG0F = -FLT_MAX;
+    for (int j = wave; j <= M + 1; j += PHD_NW) {
+        float tv[CH];
+        float mx = LOG0F;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int n = j + lane + 64 * c;
+            tv[c] = LOG0F;
+            if (n <= Nmax) {
+                tv[c] = Q.cnq[n] - Q.lfact[n - j];
+                mx = fmaxf(mx, tv[c]);
+            }
+        }
+        mx = wave_max_f(mx);
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (j + lane + 64 * c <= Nmax) sacc += __expf(tv[c] - mx);
+        sacc = wave_sum(sacc);
+        if (lane == 0) {
+            const float v = (j <= Nmax) ? (safe_log(sacc) + mx) - (float)j * lWq : LOG0F;
+            if (j <= M) Q.I0[j] = v;
+            if (j >= 1) Q.I1[j - 1] = v;
+        }
+    }
+}
+
 template <int CH>
 __device__ __forceinline__ void cphd_nsums(const CphdLds& Q, int M, int Nmax, int lane, int wave, float lWq, float lW1)
 {
@@ -359,9 +394,18 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // I_1[j] = I_0[j+1] (the same floating-point expression): one family J[j] = I_0[j], j = 0..M+1.
     // Wave per j, lanes over n; the terms stay in registers between the max and the sum pass (n <= 1023).
     // (the chunk count is a compile-time constant per cardinality length: max_cardinality 255 needs 4 of the 16)
-    if (cn_len <= 256) cphd_nsums<4>(Q, M, Nmax, lane, wave, lWq, lW1);
-    else if (cn_len <= 512) cphd_nsums<8>(Q, M, Nmax, lane, wave, lWq, lW1);
-    else cphd_nsums<16>(Q, M, Nmax, lane, wave, lWq, lW1);
+    const bool finite_w = lWq > -1e29f && lW1 > -1e29f;     // (an empty map has Wq = 0, an empty map without births W1 = 0)
+    if (finite_w) {
+        for (int n = tid; n <= Nmax; n += PHD_T) Q.cnq[n] = Q.cnp[n] + Q.lfact[n] + (float)n * (lWq - lW1);   // B_n
+        __syncthreads();
+        if (cn_len <= 256) cphd_nsums_fast<4>(Q, M, Nmax, lane, wave, lWq);
+        else if (cn_len <= 512) cphd_nsums_fast<8>(Q, M, Nmax, lane, wave, lWq);
+        else cphd_nsums_fast<16>(Q, M, Nmax, lane, wave, lWq);
+    } else {
+        if (cn_len <= 256) cphd_nsums<4>(Q, M, Nmax, lane, wave, lWq, lW1);
+        else if (cn_len <= 512) cphd_nsums<8>(Q, M, Nmax, lane, wave, lWq, lW1);
+        else cphd_nsums<16>(Q, M, Nmax, lane, wave, lWq, lW1);
+    }
     __syncthreads();
     // ESFs (.bak:1224-1272).  The .bak runs one full recursion per left-out measurement (O(M^3)); here
     //   e(Xi \ m) = P_m (*) S_{m+1}   (ESFs of the roots before and after m), so
@@ -389,7 +433,21 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     const float lY0 = Q.scal[CQ_LY0];
     for (int m = tid; m < M; m += PHD_T) L.logZ[m] = -((llam - lkap) + Q.lD[m] - lY0);      // .bak:1434-1437
     if (tid == 0) Q.scal[CQ_R1] = expf(Q.scal[CQ_LY1] - lY0);                               // .bak:1452-1455
-    // updated cardinality (.bak:1409-1411)
+    // updated cardinality (.bak:1409-1411): p(n) Y0(n) / <Y0,p>.  With B_n as above and a_j = log e_j + (M-j) log lambda
+    // - lambda - j log Wq (in the cnb array, free by now) the term is B_n + a_j - log (n-j)!: the sum over j costs two LDS
+    // reads and a subtraction per term
+    if (finite_w) {
+        for (int j = tid; j <= M; j += PHD_T) Q.cnb[j] = Q.efull[j] + ((float)(M - j) * llam - lam) - (float)j * lWq;
+        __syncthreads();
+        for (int n = tid; n <= Nmax; n += PHD_T) {
+            const int jmax = n < M ? n : M;
+            float mx = LOG0F;
+            for (int j = 0; j <= jmax; ++j) mx = fmaxf(mx, Q.cnb[j] - Q.lfact[n - j]);
+            float s = 0.f;
+            for (int j = 0; j <= jmax; ++j) s += __expf((Q.cnb[j] - Q.lfact[n - j]) - mx);
+            cn_out[n] = Q.cnq[n] + (safe_log(s) + mx) - lY0;
+        }
+    } else
     for (int n = tid; n <= Nmax; n += PHD_T) {
         const int jmax = n < M ? n : M;
         float mx = LOG0F;
