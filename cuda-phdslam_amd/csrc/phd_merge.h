@@ -547,14 +547,23 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             m &= (nseeds == 64) ? ~0ull : ((1ull << nseeds) - 1ull);   // (inf - inf in the padding has no defined sign)
             if (q == 0) RSTAMP(2);
             bool merged = false;
+#ifdef PHD_ASSIGN_STATS   // (tools/phase_profile.py prints them; global atomics: they distort the stamps)
+            if (STAMPS && ev) { atomicAdd((unsigned long long*)&st[25], (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)&st[28], 1ull); }
+#endif
             if (ev) {
                 while (m) {
                     const int r = __builtin_ctzll(m);
                     m &= m - 1;
+#ifdef PHD_ASSIGN_STATS
+                    if (STAMPS) atomicAdd((unsigned long long*)&st[26], 1ull);
+#endif
                     const v4f f = sF[r], g = sG[r];             // the seed's mean is -(−2 m)/2, exactly
                     if (is_close<HELLINGER>(-0.5f * f.x, -0.5f * f.y, g.x, g.y, g.z, ea.x, ea.y, fb.x, fb.y, fb.z, T)) {
                         asg[4 * i + 3] = __float_as_int(f.w);
                         merged = true;
+#ifdef PHD_ASSIGN_STATS
+                        if (STAMPS) atomicAdd((unsigned long long*)&st[27], 1ull);
+#endif
                         break;
                     }
                 }

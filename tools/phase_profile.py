@@ -48,6 +48,10 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
             continue
         print("   rounds: %.1f per particle; matrix %.2f us, resolve %.2f us, assign %.2f us (sums over rounds)" %
               (r[:, 3].mean(), r[:, 0].mean() * 0.01, r[:, 1].mean() * 0.01, r[:, 2].mean() * 0.01))
+        if st[:, 28].any():
+            c = st[:, 25:29].astype(np.float64).mean(axis=0)
+            print("   assign statistics per particle: %.0f (survivor, round) tests; filter-positive seeds per test %.2f; exact decisions per "
+                  "test %.2f; hits %.0f" % (c[3], c[0] / c[3], c[1] / c[3], c[2]))
         fz = st[:, 16:23].astype(np.float64).mean(axis=0) * 0.01
         if fz.sum() > 0:
             print("   inside the rounds (us, sums over rounds, thread 0's wave): window copy %.2f | matrix filter %.2f, exact + barrier %.2f | "
