@@ -142,7 +142,8 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
 
 enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */,
        CTR_NPAIR = 24 /* merge_small: candidate pairs listed for the exact closeness test */,
-       CTR_NCAND = 25 /* pass 1: terms listed for pass 2 */, CTR_NNEAR = 30 };
+       CTR_NCAND = 25 /* pass 1: terms listed for pass 2 */, CTR_WSYNC = 26 /* CPHD block: arrival counter of waves_sync */,
+       CTR_NNEAR = 30 };
 
 // append one survivor; slot allocation is wave-aggregated (one LDS atomic per wave per call site)
 __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)

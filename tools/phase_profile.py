@@ -42,8 +42,8 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
                   (((st[:, 23] - st[:, 1]) * 0.01).mean(), ((st[:, 24] - st[:, 23]) * 0.01).mean(), ((st[:, 2] - st[:, 24]) * 0.01).mean()))
         r = st[:, 12:16].astype(np.float64)
         if cid == 5:
-            print("   CPHD block (inside 'pass1 normalisers'): staging + predicted cardinality + n-sums %.2f us, backward ESF sweep %.2f us, "
-                  "forward sweep + inner products %.2f us, weights + cardinality update %.2f us"
+            print("   CPHD block (inside 'pass1 normalisers'): staging + birth cardinality %.2f us, forward ESF sweep (wave 0) beside predicted "
+                  "cardinality + n-sums (waves 1-7) %.2f us, backward sweep + inner products %.2f us, weights + cardinality update %.2f us"
                   % tuple(r[:, k].mean() * 0.01 for k in range(4)))
             continue
         print("   rounds: %.1f per particle; matrix %.2f us, resolve %.2f us, assign %.2f us (sums over rounds)" %
