@@ -77,223 +77,23 @@ __device__ __forceinline__ float lse2f(float a, float b)
 
 __device__ __forceinline__ float clamp_log(float x) { return x < -1e30f ? -1e30f : x; }
 
-// the two sweeps of cphd_block for a compile-time number of 64-lane tiles (M <= 64 TILES): with TILES = 1 — every
+// the sweeps of cphd_block are specialised on the number of 64-lane tiles (M <= 64 TILES): with TILES = 1 — every
 // configuration of BASELINE.json — the tile loops and their guards fold away, which halves the instruction count
-// of this single-wave, latency-bound section
-template <int tiles>
-__device__ __forceinline__ void cphd_esf_backward(const CphdLds& Q, float2* __restrict__ T_scratch, int M, int lane, float llam,
-                                                  float lam)
-{
-#pragma clang fp contract(off)
-    const int XF_ZERO_K = -(1 << 28);
-    float tm[4];
-    int tk[4];
-    // T_M[a] = c_a, a = lane + 64 c
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int a = lane + 64 * c;
-        tm[c] = 0.f; tk[c] = XF_ZERO_K;
-        if (c < tiles && a < M) {
-            const float Lg = Q.I1[a] + ((float)(M - 1 - a) * llam - lam);
-            if (Lg > -1e30f) {
-                const double t = (double)Lg * 1.4426950408889634;
-                const double kf = ceil(t);
-                tm[c] = (float)exp2(t - kf);
-                tk[c] = (int)kf;
-            }
-            T_scratch[(size_t)(M - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
-        }
-    }
-    // one tile: the roots sit in a register (lane m holds xi_m) and reach the recursion through v_readlane — an LDS
-    // read per step would put its latency on the critical path of this single-wave chain
-    const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;
-    for (int m = M - 1; m >= 1; --m) {
-        const float x = (tiles == 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m)) : Q.lxi[m];
-        float nm[4];
-        int nk[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            nm[c] = 0.f; nk[c] = XF_ZERO_K;
-            if (c < tiles) {
-                const float dn_m = lane_down1(tm[c]);
-                const int dn_k = lane_down1(tk[c]);
-                const float cm = (c < 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tm[c < 3 ? c + 1 : 3]), 0)) : 0.f;
-                const int ck = (c < 3) ? __builtin_amdgcn_readlane(tk[c < 3 ? c + 1 : 3], 0) : XF_ZERO_K;
-                nm[c] = (lane == 63) ? cm : dn_m;
-                nk[c] = (lane == 63) ? ck : dn_k;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int a = lane + 64 * c;
-            if (c < tiles && a <= m - 1) {
-                const float pr = nm[c] * x;
-                const int k = tk[c] > nk[c] ? tk[c] : nk[c];
-                const float s = ldexpf(tm[c], tk[c] - k) + ldexpf(pr, nk[c] - k);
-                int dk = 0;
-                tm[c] = frexpf(s, &dk);
-                tk[c] = k + dk;
-                T_scratch[(size_t)(m - 1) * M + a] = make_float2(tm[c], __int_as_float(tk[c]));
-            }
-        }
-    }
-    __threadfence(); // the rows are read back by the other waves of this workgroup (after its barrier)
-}
-
-// The forward sweep.  The recursion P_{m+1} = P_m (1 + xi_m x) is a short dependent chain per step; what is long is the
-// dot product D_m = <P_m, T_{m+1}> (two wave reductions and a log) — and nothing depends on it.  So PHD_FW waves of the
-// workgroup run the (cheap) recursion redundantly and each takes the dot products of the steps m = wave (mod PHD_FW) only:
-// PHD_FW dot products in flight instead of one, no data exchanged between the waves (eight waves are no faster than four:
-// the redundant recursion is issue capacity the other resident workgroup can use).
+// of these latency-bound sections
+// PHD_FW waves run the (cheap) backward recursion redundantly and each takes the inner products of every PHD_FW-th step:
+// PHD_FW inner products (two wave reductions and a log each) in flight, no data exchanged between the waves (eight waves
+// are no faster than four: the redundant recursion is issue capacity the other resident workgroup can use)
 #ifndef PHD_FW
 #define PHD_FW 4
 #endif
-template <int tiles>
-__device__ __forceinline__ void cphd_esf_forward(const CphdLds& Q, const float2* __restrict__ T_scratch, int M, int lane, int wave,
-                                                 float llam, float lam)
-{
-#pragma clang fp contract(off)
-    if (wave >= PHD_FW) return;   // the recursion is redundant work: only this many waves take part
-    const float LOG0F = -FLT_MAX;
-    const int XF_ZERO_K = -(1 << 28);
-    // P_m[a], a = lane + 1 + 64 c in registers (P_m[0] = 1 is implicit)
-    float pm[4] = {0.f, 0.f, 0.f, 0.f};
-    int pk[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
-    // this wave's rows come back from L2 / HBM: keep PF of them in flight ahead of the step that uses them
-    constexpr int PF = 4;
-    float2 rbuf[PF][4], r0buf[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int mu = wave + PHD_FW * u;                 // this wave's u-th step
-        const float2* row = T_scratch + (size_t)mu * M;
-        r0buf[u] = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rbuf[u][c] = make_float2(0.f, 0.f);
-        if (mu < M) {
-            r0buf[u] = row[0];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 1 + 64 * c <= mu) rbuf[u][c] = row[lane + 1 + 64 * c];
-        }
-    }
-    const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;   // as in the backward sweep
-    for (int m0 = 0; m0 < M; m0 += PF * PHD_FW) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-    for (int r = 0; r < PHD_FW; ++r) {
-        const int m = m0 + PHD_FW * u + r;
-        if (m < M) {
-        const float x = (tiles == 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m)) : Q.lxi[m];
-        if (r == wave) {
-        // D_m = T_{m+1}[0] + sum_{a=1..m} P_m[a] T_{m+1}[a]
-        float qm[5];
-        int qk[5];
-        int kmax = 2 * XF_ZERO_K;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int a = lane + 1 + 64 * c;
-            qm[c] = 0.f; qk[c] = 2 * XF_ZERO_K;
-            if (c < tiles && a <= m) {
-                const float2 t = rbuf[u][c];
-                qm[c] = pm[c] * t.x;
-                qk[c] = pk[c] + __float_as_int(t.y);
-            }
-            kmax = max(kmax, qk[c]);
-        }
-        {
-            const float2 t0 = r0buf[u];
-            qm[4] = (lane == 0) ? t0.x : 0.f;
-            qk[4] = (lane == 0) ? __float_as_int(t0.y) : 2 * XF_ZERO_K;
-            kmax = max(kmax, qk[4]);
-        }
-        if (m + PF * PHD_FW < M) { // refill this slot with the row of this wave's step PF turns ahead
-            const float2* row = T_scratch + (size_t)(m + PF * PHD_FW) * M;
-            r0buf[u] = row[0];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < tiles && lane + 1 + 64 * c <= m + PF * PHD_FW) rbuf[u][c] = row[lane + 1 + 64 * c];
-        }
-        kmax = wave_max_i(kmax);
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) s += ldexpf(qm[c], qk[c] - kmax);
-        s = wave_sum(s);
-        if (lane == 0) {
-            int dk = 0;
-            const float dm = frexpf(s, &dk);
-            Q.lD[m] = dm > 0.f ? logf(dm) + (float)(kmax + dk) * 0.69314718f : LOG0F;   // log <Y1[Z \ m], p>
-        }
-        } // this wave's step
-        // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
-        float um[4];
-        int uk[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            um[c] = 0.f; uk[c] = XF_ZERO_K;
-            if (c < tiles) {
-                const float up_m = lane_up1(pm[c]);
-                const int up_k = lane_up1(pk[c]);
-                const float cm = (c > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm[c > 0 ? c - 1 : 0]), 63))
-                                         : 0.5f;                                       // P[0] = 1 = 0.5 * 2^1
-                const int ck = (c > 0) ? __builtin_amdgcn_readlane(pk[c > 0 ? c - 1 : 0], 63) : 1;
-                um[c] = (lane == 0) ? cm : up_m;
-                uk[c] = (lane == 0) ? ck : up_k;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < tiles && lane + 64 * c <= m) {
-                const float pr = um[c] * x;
-                const int k = pk[c] > uk[c] ? pk[c] : uk[c];
-                const float s2 = ldexpf(pm[c], pk[c] - k) + ldexpf(pr, uk[c] - k);
-                int dk = 0;
-                pm[c] = frexpf(s2, &dk);
-                pk[c] = k + dk;
-            }
-        } // m < M
-    }
-    }
-    }
-    if (wave != 0) return;
-    // full set: e_j = P_M[j]; <Y0,p> and <Y1,p>
-    float ev[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ev[c] = pm[c] > 0.f ? logf(pm[c]) + (float)pk[c] * 0.69314718f : LOG0F;
-    float t0[5], t1[5];
-    float mx0 = LOG0F, mx1 = LOG0F;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        // c == 4: the j = 0 term (e_0 = 1), carried by lane 0
-        const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
-        const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
-        const float e = (c == 4) ? 0.f : ev[c < 4 ? c : 0];
-        const float kterm = (float)(M - j) * llam - lam;   // (M-j)! p_K(M-j), Poisson clutter (.bak:398-400)
-        t0[c] = ok ? e + Q.I0[ok ? j : 0] + kterm : LOG0F;
-        t1[c] = ok ? e + Q.I1[ok ? j : 0] + kterm : LOG0F;
-        mx0 = fmaxf(mx0, t0[c]); mx1 = fmaxf(mx1, t1[c]);
-    }
-    mx0 = wave_max_f(mx0); mx1 = wave_max_f(mx1);
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        const int j = (c == 4) ? 0 : lane + 1 + 64 * c;
-        const bool ok = (c == 4) ? (lane == 0) : (c < tiles && j <= M);
-        if (ok) { s0 += expf(t0[c] - mx0); s1 += expf(t1[c] - mx1); }
-    }
-    s0 = wave_sum(s0); s1 = wave_sum(s1);
-    if (lane == 0) { Q.scal[CQ_LY0] = safe_log(s0) + mx0; Q.scal[CQ_LY1] = safe_log(s1) + mx1; Q.efull[0] = 0.f; }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (c < tiles && lane + 1 + 64 * c <= M) Q.efull[lane + 1 + 64 * c] = ev[c];
-}
-
 // ------------------------------------------------------------------------------------------
 // The two sweeps in the order that lets the first one run BESIDE the cardinality work: the forward recursion
 // P_{m+1} = P_m (1 + xi_m x) needs only the roots, so one wave runs it — parking the rows P_m[0..m] in the HBM scratch —
 // while the other seven compute the predicted cardinality and the n-sums; the backward recursion T_m = T_{m+1} + xi_m
 // shift(T_{m+1}), T_M = c, needs the n-sums (c_j = exp(I1[j]) lambda^(M-1-j) e^-lambda) and takes the inner products
 // D_m = <P_m, T_{m+1}> against the parked rows on the way (PHD_FW waves run the cheap recursion redundantly, each takes
-// every PHD_FW-th inner product).  Same numbers as cphd_esf_backward / cphd_esf_forward (which park T and carry P).
+// every PHD_FW-th inner product).  (Round 1 parked T and carried P: the same numbers, but both sweeps then had to wait
+// for the n-sums.)
 // ------------------------------------------------------------------------------------------
 template <int tiles>
 __device__ __forceinline__ void cphd_esf_forward_park(const CphdLds& Q, float2* __restrict__ P_scratch, int M, int lane)
