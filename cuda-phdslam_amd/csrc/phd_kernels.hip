@@ -62,7 +62,9 @@ size_t cphd_lds_bytes(int cn_len, int MM)
 // ------------------------------------------------------------------------------------------
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
-template <bool STAMPS, bool FUSEW, bool CPHD>
+// SPILL: the instantiation of filters created with a spill list (survivor_capacity > 2048); without it the spill branches
+// fold away (they cost 0.3 us of the 17.5 us step at 256 x 64 x 32 when merely present)
+template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL>
 __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     float* __restrict__ out = A.map_out + (size_t)p * (rows_stride ? rows_stride : (size_t)6 * cap);
     const int n_map = A.count_in[src];
     // survivors past the LDS capacity go to this particle's record list in HBM (when the filter was created with one)
-    const SpillRef sp = {A.spill_rec ? A.spill_rec + (size_t)p * 2 * A.spill_cap * 8 : nullptr, A.spill_cap};
-    if (A.spill_meta && tid == 0) A.spill_meta[(size_t)p * 4] = 0;
+    const SpillRef sp = {SPILL ? A.spill_rec + (size_t)p * 2 * A.spill_cap * 8 : nullptr, SPILL ? A.spill_cap : 0};
+    if (SPILL && tid == 0) A.spill_meta[(size_t)p * 4] = 0;
     phd_pose pose = A.pose[p];
     if (A.do_predict) {
         // fused vehicle predict: every lane computes the same pose (no broadcast needed); lane 0 stores it after the
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     unsigned status = 0;
     // more survivors than LDS holds: with a spill list (and room in it) the particle's merge is handed to
     // phd_merge_spill_kernel; without one the list is truncated and the step reports PHD_ERR_CAPACITY
-    const bool spilled = n_surv > S_cap && sp.rec && n_surv <= sp.cap && !L.ctr[CTR_OVERFLOW];
+    const bool spilled = SPILL && n_surv > S_cap && n_surv <= sp.cap && !L.ctr[CTR_OVERFLOW];
     const int n_all = n_surv;
     if (n_surv > S_cap) { n_surv = S_cap; if (!spilled) status |= PHD_STATUS_SURVIVOR_OVERFLOW; }
     if (L.ctr[CTR_OVERFLOW]) status |= PHD_STATUS_SURVIVOR_OVERFLOW;
@@ -777,19 +779,24 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-static const void* const k_update_fns[6] = {(const void*)phd_update_merge_kernel<false, false, false>,
-                                            (const void*)phd_update_merge_kernel<true, false, false>,
-                                            (const void*)phd_update_merge_kernel<false, true, false>,
-                                            (const void*)phd_update_merge_kernel<false, false, true>,
-                                            (const void*)phd_update_merge_kernel<true, false, true>,
-                                            (const void*)phd_update_merge_kernel<false, true, true>};
+static const void* const k_update_fns[10] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
+                                             (const void*)phd_update_merge_kernel<true, false, false, false>,
+                                             (const void*)phd_update_merge_kernel<false, true, false, false>,
+                                             (const void*)phd_update_merge_kernel<false, false, true, false>,
+                                             (const void*)phd_update_merge_kernel<true, false, true, false>,
+                                             (const void*)phd_update_merge_kernel<false, true, true, false>,
+                                             (const void*)phd_update_merge_kernel<false, false, false, true>,
+                                             (const void*)phd_update_merge_kernel<false, true, false, true>,
+                                             (const void*)phd_update_merge_kernel<false, false, true, true>,
+                                             (const void*)phd_update_merge_kernel<false, true, true, true>};
+#define PHD_N_UPDATE_FNS 10
 
 // the largest static __shared__ footprint among the instantiations of the update kernel (the fused ones carry the
 // weights routine's arrays): what a launch can use dynamically is 160 KiB minus this
 size_t update_static_lds_bytes()
 {
     size_t mx = 0;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < PHD_N_UPDATE_FNS; ++k) {
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, k_update_fns[k]) == hipSuccess && fa.sharedSizeBytes > mx) mx = fa.sharedSizeBytes;
     }
@@ -806,7 +813,7 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
     if (!attr_set) {
         // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
         const void* const* fns = k_update_fns;
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < PHD_N_UPDATE_FNS; ++k) {
             hipFuncAttributes fa;
             hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
             if (e != hipSuccess) return e;
@@ -815,18 +822,22 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         }
         attr_set = true;
     }
-    if (a.cphd && a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else if (a.cphd && a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, true>), dim3(n_particles + 1), dim3(PHD_T), lds_bytes, st, a);
-    else if (a.cphd) hipLaunchKernelGGL((phd_update_merge_kernel<false, false, true>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else if (a.fuse_weights) hipLaunchKernelGGL((phd_update_merge_kernel<false, true, false>), dim3(n_particles + 1), dim3(PHD_T), lds_bytes, st, a); // + the weights workgroup
-    else if (a.stamps) hipLaunchKernelGGL((phd_update_merge_kernel<true, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
-    else hipLaunchKernelGGL((phd_update_merge_kernel<false, false, false>), dim3(n_particles), dim3(PHD_T), lds_bytes, st, a);
+    const dim3 g1(n_particles), g2(n_particles + 1), b(PHD_T);   // g2: + the weights workgroup of the fused step
+    const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
+#define PHD_LAUNCH(ST, FW, CP, SP, G) hipLaunchKernelGGL((phd_update_merge_kernel<ST, FW, CP, SP>), G, b, lds_bytes, st, a)
+    if (a.cphd && a.stamps) PHD_LAUNCH(true, false, true, false, g1);
+    else if (a.stamps) PHD_LAUNCH(true, false, false, false, g1);
+    else if (a.cphd && a.fuse_weights) { if (sp) PHD_LAUNCH(false, true, true, true, g2); else PHD_LAUNCH(false, true, true, false, g2); }
+    else if (a.cphd) { if (sp) PHD_LAUNCH(false, false, true, true, g1); else PHD_LAUNCH(false, false, true, false, g1); }
+    else if (a.fuse_weights) { if (sp) PHD_LAUNCH(false, true, false, true, g2); else PHD_LAUNCH(false, true, false, false, g2); }
+    else { if (sp) PHD_LAUNCH(false, false, false, true, g1); else PHD_LAUNCH(false, false, false, false, g1); }
+#undef PHD_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st)
 {
-    if (!a.spill_rec) return hipSuccess;
+    if (!a.spill_rec || a.stamps) return hipSuccess;   // (the diagnostic instantiation has no spill variant)
     hipLaunchKernelGGL(phd_merge_spill_kernel, dim3(n_particles), dim3(PHD_T), 0, st, a);
     return hipGetLastError();
 }
