@@ -356,11 +356,8 @@ def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, loca
     off, n = D.shard_range(n_global, world, rank)
     seed = 0x5EED0000 + cfg_id
     if same_set:
-        wf = S.make_workload(n_global, G, M, seed=seed, clustered=c["clustered"])
-        w = {k: (wf[k][off:off + n] if k in ("poses", "logw", "maps", "sizes") else wf[k]) for k in wf}
-        w["noise"] = wf["noise"][:, off:off + n]
+        w = S.shard_workload(S.make_workload(n_global, G, M, seed=seed, clustered=c["clustered"]), world, rank)
         lw = w["logw"]                                   # the global set is normalised as generated
-        del wf
     else:
         w = S.make_workload(n, G, M, seed=seed + 1000 * rank, clustered=c["clustered"])
         shared = S.make_workload(1, G, M, seed=seed, clustered=c["clustered"])

@@ -94,6 +94,25 @@ def config_workload(cfg_id, n_particles=None, **kw):
     return make_workload(N, c["G"], c["M"], seed=0x5EED0000 + cfg_id, clustered=c["clustered"], **kw)
 
 
+def shard_workload(w, world, rank):
+    """rank's contiguous slice [rank n, (rank + 1) n), n = N / world, of ONE generated workload — the split of BASELINE.json
+    configs[3] (bench.py --gpus N): per-particle arrays are sliced, the measurement sets, the resampling uniforms and the
+    truth are the same on every rank.  The log-weights stay those of the global set (they sum to one over all ranks)."""
+    N = w["N"]
+    if N % world:
+        raise ValueError("particle count must be divisible by the world size")
+    n = N // world
+    off = rank * n
+    out = dict(w)
+    for k in ("poses", "logw", "maps", "sizes"):
+        out[k] = w[k][off:off + n]
+    out["noise"] = w["noise"][:, off:off + n]
+    out["N"] = n
+    out["N_global"] = N
+    out["offset"] = off
+    return out
+
+
 def algorithmic_bytes(N, G, M, K=None):
     """B_step of SURVEY.md §8(d): 28 B per Gaussian, U = G(M+1)+M update components per particle."""
     K = G if K is None else K

@@ -173,3 +173,58 @@ def test_plan_migration_properties():
                     assert np.array_equal(plans[q][1][r] + q * n, idx[r * n + recv[q]])
             assert np.all(filled == 1)
             assert np.array_equal(lp[lp >= 0] + r * n, idx[r * n:(r + 1) * n][lp >= 0])
+
+
+# ----------------------------------------------------------------------------------------------
+# the split bench.py --gpus N uses for BASELINE.json configs[3]: ONE generated particle set, rank r takes the contiguous
+# slice [r n, (r + 1) n), the same measurement set and uniform on every rank (synthetic.shard_workload)
+# ----------------------------------------------------------------------------------------------
+def _split_worker(rank, world, port, N, G, M, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    P = importlib.import_module("cuda-phdslam_amd")
+    from parity_utils import oracle_config_from
+    ocfg = oracle_config_from(P.default_config())
+    full = S.make_workload(N, G, M, seed=0x5EED0004, clustered=True)       # every rank generates the same set ...
+    w = S.shard_workload(full, world, rank)                                 # ... and takes its slice
+    off, n = D.shard_range(N, world, rank)
+    assert (w["offset"], w["N"], w["N_global"]) == (off, n, N)
+    # the local step of the shard on the CPU oracle: predict + update of its own particles, raw = logw + dlogw
+    pred = O.predict_ackerman(w["poses"], 0.05, 2.0, w["noise"][0], ocfg)
+    raw = np.array([w["logw"][p] + np.float32(O.update_particle(pred[p], w["maps"][p, :w["sizes"][p]], w["z"][0], ocfg)["dlogw"])
+                    for p in range(n)], np.float32)
+    shard = NumpyShard(np.arange(off, off + n, dtype=np.float32), [np.zeros(0, np.float32)] * n, raw, N)
+    sf = D.ShardedFilter(shard, N, rank, world)
+    sf.gathered_limit = 0
+    allw = sf.gather_logweights()
+    sf.normalize(allw)
+    idx = sf.resample(float(w["uniform"][0]))
+    np.savez(os.path.join(out_dir, "split%d.npz" % rank), raw=raw, allw=allw.numpy(), idx=idx, ids=shard.poses, z=w["z"][0].view(np.uint8),
+             u=w["uniform"][0], first_pose=w["poses"]["px"][:1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_split_of_one_particle_set(tmp_path):
+    world, N, G, M = 2, 32, 16, 8
+    mp.spawn(_split_worker, args=(world, _free_port(), N, G, M, str(tmp_path)), nprocs=world, join=True)
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    P = importlib.import_module("cuda-phdslam_amd")
+    from parity_utils import oracle_config_from
+    ocfg = oracle_config_from(P.default_config())
+    full = S.make_workload(N, G, M, seed=0x5EED0004, clustered=True)
+    pred = O.predict_ackerman(full["poses"], 0.05, 2.0, full["noise"][0], ocfg)
+    ref_raw = np.array([full["logw"][p] + np.float32(O.update_particle(pred[p], full["maps"][p, :G], full["z"][0], ocfg)["dlogw"])
+                        for p in range(N)], np.float32)
+    ref_idx = O.resample(O.normalize_weights(ref_raw), float(full["uniform"][0]))
+    d = [np.load(tmp_path / ("split%d.npz" % r)) for r in range(world)]
+    n = N // world
+    for r in range(world):
+        assert np.array_equal(d[r]["raw"], ref_raw[r * n:(r + 1) * n])           # the shard's step == the same particles of the one filter
+        assert np.array_equal(d[r]["allw"], ref_raw)                               # the gathered vector is the one filter's
+        assert np.array_equal(d[r]["idx"], ref_idx)                                # identical global indices on every rank
+        assert np.array_equal(d[r]["ids"], ref_idx[r * n:(r + 1) * n].astype(np.float32))   # and the right parents arrived
+        assert np.array_equal(d[r]["z"], d[0]["z"]) and d[r]["u"] == d[0]["u"]     # one scan, one uniform
+    assert d[0]["first_pose"][0] == full["poses"]["px"][0] and d[1]["first_pose"][0] == full["poses"]["px"][n]
