@@ -1545,12 +1545,28 @@ extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_row
     w.neff_out = f->neff;
     w.did_resample = f->did;
     w.n_weight_norm = ng;
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3;
+    if (weights_in_rows && !idx_out && ng <= 1024) {
+        // one launch: every import workgroup draws its own parent from the gathered weights (no weights launch to wait for)
+        t_begin(f, PHD_K_WEIGHTS);
+        HIPCHK(launch_gathered_resample(w, f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], d_all_rows, f->cap, pack,
+                                        off, n, f->frozen ? nullptr : f->logw, (float)(-log((double)ng)),
+                                        f->frozen ? nullptr : f->parent[f->pcur], f->cphd ? f->cn[f->cur ^ 1] : nullptr,
+                                        f->cn_len, f->stream));
+        t_end(f);
+        f->rows_pending = false;
+        if (!f->frozen) {
+            f->cur ^= 1;
+            f->pose_cur = (f->pose_cur + 1) % 3;
+            f->parent_dirty = false;
+        }
+        return PHD_OK;
+    }
     t_begin(f, PHD_K_WEIGHTS);
     HIPCHK(launch_weights(w, f->stream));
     t_end(f);
     // copy_particles (src/slamtypes.h:313-333): slot j <- gathered row idx[off + j]; weights <- -log N and the map
     // indirection back to identity in the same launch
-    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3;
     HIPCHK(launch_import(f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], nullptr, d_all_rows, f->cap, pack, n,
                          f->stream, f->idx + off, f->frozen ? nullptr : f->logw, (float)(-log((double)ng)),
                          f->frozen ? nullptr : f->parent[f->pcur]));

@@ -144,6 +144,9 @@ hipError_t launch_state(const phd_pose* poses, const float* logw, int n, float* 
 hipError_t launch_export(const float* slabs, const int* counts, const int* parent, const phd_pose* poses,
                          const int* which, void* buf, int cap, size_t stride, int n, hipStream_t st,
                          const float* raw = nullptr);
+hipError_t launch_gathered_resample(const WeightArgs& a, float* slabs, int* counts, phd_pose* poses, const void* rows, int cap,
+                                    size_t stride, int off, int n, float* logw_fill, float nlw, int* parent_reset,
+                                    float* cn_dst, int cn_len, hipStream_t st);
 hipError_t launch_import(float* slabs, int* counts, phd_pose* poses, const int* which, const void* buf, int cap,
                          size_t stride, int n, hipStream_t st, const int* rowsel = nullptr, float* logw_fill = nullptr,
                          float nlw = 0.f, int* parent_reset = nullptr);

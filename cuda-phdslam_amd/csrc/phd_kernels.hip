@@ -729,6 +729,37 @@ __global__ void phd_import_kernel(float* __restrict__ slabs, int* __restrict__ c
     for (int i = threadIdx.x; i < 6 * cap; i += blockDim.x) s[i] = o[8 + i];
 }
 
+// The gathered multi-GPU resample in ONE launch (phd_global_resample_gathered, forced form): workgroup k of shard `off / n`
+// runs the weights routine on the gathered row headers — every workgroup the whole normalise / fixed-point CDF, so there is
+// no launch-to-launch dependency — draws the parent of ITS slot off + k, and copies that row into slot k
+// (copy_particles, src/slamtypes.h:313-333).  The instantiation is the one launch_weights picks for n_global, so the index
+// equals the single filter's bit for bit.  Workgroup 0 writes nEff / the decision / the normalised vector.
+template <int BT, int R>
+__global__ __launch_bounds__(BT) void phd_gathered_resample_kernel(WeightArgs A, float* __restrict__ slabs, int* __restrict__ counts,
+                                                                   phd_pose* __restrict__ poses,
+                                                                   const unsigned char* __restrict__ buf, int cap, size_t stride,
+                                                                   int off, float* __restrict__ logw_fill, float nlw,
+                                                                   int* __restrict__ parent_reset, float* __restrict__ cn_dst,
+                                                                   int cn_len)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_gdyn[];
+    __shared__ int s_row;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    weights_body<BT, R, false, true>(A, s_gdyn, off + k, k == 0, &s_row);
+    __syncthreads();
+    const float* o = (const float*)(buf + (size_t)s_row * stride);
+    if (tid < 6) ((float*)&poses[k])[tid] = o[tid];
+    if (tid == 6) counts[k] = ((const int*)o)[6];
+    if (tid == 7) {
+        if (logw_fill) logw_fill[k] = nlw;
+        if (parent_reset) parent_reset[k] = k;
+    }
+    float* s = slabs + (size_t)k * 6 * cap;
+    for (int i = tid; i < 6 * cap; i += BT) s[i] = o[8 + i];
+    if (cn_dst)
+        for (int i = tid; i < cn_len; i += BT) cn_dst[(size_t)k * cn_len + i] = o[8 + 6 * cap + i];
+}
+
 // copy_particles for the maps (src/slamtypes.h:313-333): dst[p] = src[parent[sel[p]]] (maps, counts, poses);
 // sel == NULL: identity; sel[p] < 0: slot is filled by phd_import_kernel instead
 __global__ void phd_gather_maps_kernel(const float* __restrict__ src, const int* __restrict__ counts_src,
@@ -966,6 +997,24 @@ hipError_t launch_import(float* slabs, int* counts, phd_pose* poses, const int* 
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(phd_import_kernel, dim3(n), dim3(256), 0, st, slabs, counts, poses, which,
                        (const unsigned char*)buf, cap, stride, rowsel, logw_fill, nlw, parent_reset);
+    return hipGetLastError();
+}
+
+// n_global <= 1024 only (above, n workgroups repeating the scan cost more than the launch they save)
+hipError_t launch_gathered_resample(const WeightArgs& a, float* slabs, int* counts, phd_pose* poses, const void* rows, int cap,
+                                    size_t stride, int off, int n, float* logw_fill, float nlw, int* parent_reset,
+                                    float* cn_dst, int cn_len, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (a.n > 1024 || a.n_new != a.n) return hipErrorInvalidValue;
+    const size_t dyn = (size_t)a.n * 8;
+#define PHD_GR(BT, R)                                                                                                       \
+    hipLaunchKernelGGL((phd_gathered_resample_kernel<BT, R>), dim3(n), dim3(BT), dyn, st, a, slabs, counts, poses,            \
+                       (const unsigned char*)rows, cap, stride, off, logw_fill, nlw, parent_reset, cn_dst, cn_len)
+    if (a.n <= 256) PHD_GR(256, 1);       // the table of launch_weights
+    else if (a.n <= 512) PHD_GR(256, 2);
+    else PHD_GR(512, 2);
+#undef PHD_GR
     return hipGetLastError();
 }
 

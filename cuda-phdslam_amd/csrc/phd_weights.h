@@ -244,8 +244,12 @@ __device__ __forceinline__ phd_pose ld_pose(const phd_pose* p)
     return o;
 }
 
-template <int BT, int R, bool HANDOFF>
-__device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn)
+// ONE_SLOT (the gathered multi-GPU resample, one launch for weights + import): every workgroup runs the whole routine on
+// the gathered weights but draws only the parent index of resampling slot `slot` (left in *one_out, LDS, valid after the
+// caller's barrier); only the `lead` workgroup writes the shared outputs (nEff, decision, normalised weights).
+template <int BT, int R, bool HANDOFF, bool ONE_SLOT = false>
+__device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn, int slot = 0, bool lead = true,
+                                             int* one_out = nullptr)
 {
     __shared__ float sc[BT / 64];
     __shared__ int s_argmax;
@@ -292,14 +296,17 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
     int doit = 0;
     if (A.mode & W_RESAMPLE_FORCE) doit = 1;
     else if ((A.mode & W_RESAMPLE_AUTO) && (neff <= A.resample_thresh) && (A.mode & W_HAD_MEAS)) doit = 1; // :1286
-    if (tid == 0) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
+    if (tid == 0 && (!ONE_SLOT || lead)) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
     const int n_new = A.n_new;
     if (!doit) { // uniform: neff is the same in every thread
+        if (!ONE_SLOT || lead) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = tid + r * BT;
-            if (i < n) A.logw[i] = w[r];
+            for (int r = 0; r < R; ++r) {
+                const int i = tid + r * BT;
+                if (i < n) A.logw[i] = w[r];
+            }
         }
+        if (ONE_SLOT) { if (tid == 0) { A.idx_out[slot] = slot; *one_out = slot; } return; }
         for (int j = tid; j < ((A.mode & W_COMMIT) ? n : n_new); j += BT) {
             A.idx_out[j] = j;                                                                          // :1292-1296
             if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
@@ -353,7 +360,8 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
     }
     WSTAMP(5);
     const float nlw = (float)(-log((double)A.n_weight_norm));
-    for (int j = tid; j < n_new; j += BT) {
+    const int j_first = ONE_SLOT ? slot : 0, j_end = ONE_SLOT ? slot + 1 : n_new;
+    for (int j = j_first + tid; j < j_end; j += BT) {
         const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
         const double r = j * interval + u * interval;                                                  // :468
         const u64 T = (u64)ceil(r * scale);
@@ -369,16 +377,19 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
             idx = lo;
         }
         A.idx_out[j] = idx;
+        if (ONE_SLOT) *one_out = idx;
         if (A.mode & W_COMMIT) { // copy_particles (src/slamtypes.h:313-333)
             A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[idx]);
             A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[idx]);
         }
     }
     // weights: -log(N) after a committed resample (slamtypes.h:327), else the normalised values
+    if (!ONE_SLOT || lead) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = tid + r * BT;
-        if (i < n) A.logw[i] = (A.mode & W_COMMIT) ? nlw : w[r];
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * BT;
+            if (i < n) A.logw[i] = (A.mode & W_COMMIT) ? nlw : w[r];
+        }
     }
     WSTAMP(6);
 }
