@@ -134,6 +134,7 @@ struct phd_filter {
     std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots;
     void* send_buf = nullptr;
     size_t send_buf_bytes = 0;
+    void* rows_target = nullptr; // caller-owned destination of phd_step_local_rows_dev's rows (in-place all-gather)
     bool rows_out = false;     // this launch writes its outputs into the export rows (phd_step_local_rows_dev)
     bool rows_pending = false; // ... and the step still has to be completed by phd_global_resample_gathered
     bool want_raw = false; // the update kernel also writes raw = logw + dlogw (multi-GPU step: no weights launch before the all-gather)
@@ -690,7 +691,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     a.map_out = f->maps[f->cur ^ 1];
     a.count_out = f->counts[f->cur ^ 1];
     if (f->rows_out) { // the outputs land in the export rows (phd_step_local_rows_dev)
-        a.map_out = (float*)f->send_buf + 8;
+        a.map_out = (float*)(f->rows_target ? f->rows_target : f->send_buf) + 8;
         a.out_stride = (unsigned)(phd_particle_pack_bytes(f) / 4);
     }
     a.parent = f->parent[f->pcur];
@@ -735,7 +736,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         a.cphd = 1;
         a.cn_in = f->cn[f->cur];
         a.cn_out = f->cn[f->cur ^ 1];
-        if (f->rows_out) a.cn_out = (float*)f->send_buf + 8 + 6 * f->cap;
+        if (f->rows_out) a.cn_out = (float*)(f->rows_target ? f->rows_target : f->send_buf) + 8 + 6 * f->cap;
         a.cn_len = f->cn_len;
         a.lfact = f->d_lfact;
         a.lfact_len = f->lfact_len;
@@ -1497,7 +1498,7 @@ extern "C" int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, co
         return phd_export_shard_dev(f, d_rows, bytes_out);
     }
     const size_t need = (size_t)f->n * phd_particle_pack_bytes(f);
-    int rc = ensure_send_buffer(f, need);
+    int rc = f->rows_target ? PHD_OK : ensure_send_buffer(f, need);
     if (rc) return rc;
     FusedPredict fp = {u, d_noise};
     f->want_raw = true;
@@ -1507,8 +1508,15 @@ extern "C" int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, co
     f->rows_out = false;
     if (rc) return rc;
     f->rows_pending = !f->frozen;
-    *d_rows = f->send_buf;
+    *d_rows = f->rows_target ? f->rows_target : f->send_buf;
     if (bytes_out) *bytes_out = need;
+    return PHD_OK;
+}
+
+extern "C" int phd_set_rows_target(phd_filter* f, void* d_rows)
+{
+    CHECK_F0(f);
+    f->rows_target = d_rows;
     return PHD_OK;
 }
 

@@ -122,6 +122,7 @@ int all_gather(phd_multi* m, const std::vector<const void*>& src, const std::vec
         HIPCHK(hipSetDevice(s.device));
         for (int j = 0; j < m->world; ++j) {
             if (j != k) HIPCHK(hipStreamWaitEvent(s.stream, m->sh[j].ready, 0));
+            if (j == k && src[j] == (unsigned char*)dst[k] + (size_t)j * bytes) continue; // in place
             HIPCHK(hipMemcpyAsync((unsigned char*)dst[k] + (size_t)j * bytes, src[j], bytes, hipMemcpyDeviceToDevice, s.stream));
         }
     }
@@ -173,11 +174,15 @@ int all_to_all(phd_multi* m)
 
 int ensure_allrows(phd_multi* m)
 {
-    for (auto& s : m->sh)
+    for (int k = 0; k < m->world; ++k) {
+        Shard& s = m->sh[k];
         if (!s.allrows) {
             HIPCHK(hipSetDevice(s.device));
             HIPCHK(hipMalloc((void**)&s.allrows, (size_t)m->N * m->pack));
+            // the fused step writes its rows straight into this shard's segment: the all-gather is in place (no self copy)
+            PHDCHK(phd_set_rows_target(s.f, (unsigned char*)s.allrows + (size_t)k * m->n * m->pack));
         }
+    }
     return PHD_OK;
 }
 

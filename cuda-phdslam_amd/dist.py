@@ -146,6 +146,10 @@ class ShardedFilter:
         allrows = getattr(self, "_allrows", None)              # allocated once; stream-ordered reuse as for _allw
         if allrows is None or allrows.shape[1] != rows.shape[1] or allrows.device != rows.device:
             allrows = self._allrows = torch.empty((self.n_global, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+            if hasattr(self.b, "set_rows_target"):
+                # from the next step on the local step writes its rows straight into this rank's segment: the all-gather
+                # is in place (RCCL skips the self copy)
+                self.b.set_rows_target(allrows[self.rank * self.n:(self.rank + 1) * self.n])
         dist.all_gather_into_tensor(allrows.view(-1), rows.reshape(-1), group=self.group)
         return allrows
 
@@ -332,6 +336,12 @@ class GpuShard:
         self._check(self._lib().phd_step_local_rows_dev(self.f._h, _ctrl(control), self._ptr(d_noise), self._ptr(d_z), int(n_meas),
                                                         C.byref(p), C.byref(nb)), "phd_step_local_rows_dev")
         return self._rows_tensor(p.value, nb.value)
+
+    def set_rows_target(self, segment):
+        """step_local_rows() writes its rows into `segment` ([n, pack] uint8 on the device, kept alive here) from now on"""
+        assert segment.is_contiguous() and segment.numel() == self.f.n * self.pack_bytes()
+        self._rows_target = segment
+        self._check(self._lib().phd_set_rows_target(self.f._h, self._ptr(segment.data_ptr())), "phd_set_rows_target")
 
     def export_shard(self):
         C = self._C

@@ -321,6 +321,10 @@ int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_out);
  * except phd_sync / phd_device_status / phd_timing_* / phd_destroy. */
 int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise,
                             const phd_measurement* d_z, int n_meas, void** d_rows, size_t* bytes_out);
+/* In-place all-gather: d_rows != NULL makes phd_step_local_rows_dev write its rows there (n * phd_particle_pack_bytes bytes,
+ * device; normally this rank's segment of the all-gather's receive buffer, so the collective skips the self copy) instead of
+ * the library's send buffer; NULL restores the default.  The caller owns the buffer. */
+int phd_set_rows_target(phd_filter* f, void* d_rows);
 int phd_global_resample_gathered(phd_filter* f, const void* d_all_rows, double uniform, int world, int rank,
                                  int weights_in_rows, int32_t* idx_out);
 

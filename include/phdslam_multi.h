@@ -13,7 +13,8 @@
  *     migration of the particles whose parent lives on another shard        (ncclSend/ncclRecv pairs, point to point over xGMI)
  *
  * Small shards (all shards' packed particles together below gathered_limit_bytes) exchange whole shards with ONE
- * all-gather instead and never wait for the host.  Results equal a single filter's bit for bit (the weights routine
+ * in-place all-gather instead (the update kernel writes its rows into the shard's segment of the receive buffer) and never
+ * wait for the host.  Results equal a single filter's bit for bit (the weights routine
  * is a pure function of the gathered vector; resampling moves whole slabs).
  *
  * Shards that share a device (more shards than GPUs: one-GPU test boxes) exchange by stream-ordered device copies
