@@ -433,7 +433,7 @@ def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, loca
         acc = {"local_step_into_rows": 0.0, "all_gather_rows": 0.0, "normalise+indices+import": 0.0}
     else:
         acc = {"local_step": 0.0, "all_gather": 0.0, "resample_begin": 0.0, "all_to_all": 0.0, "resample_end": 0.0}
-    migrants = 0
+    migrants = remote_slots = 0
     for _ in range(k_bd):
         t_a = tick()
         if gathered:
@@ -449,20 +449,23 @@ def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, loca
             t_b = tick()
             allw = sf.gather_logweights()
             t_c = tick()
-            sc, rc, send, _ = shard.resample_begin(u, world, rank, allw)
+            sc, rc, send, idx_all = shard.resample_begin(u, world, rank, allw)
             t_d = tick()
             recv = sf._exchange(send[:sum(sc)], sc, rc, shard.pack_bytes())
             t_e = tick()
             shard.resample_end(recv)
             t_f = tick()
             ts_ = (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)
-            migrants = int(sum(rc))
+            migrants = int(sum(rc))          # rows that travelled (a parent once per destination rank) ...
+            mine = idx_all[rank * shard.f.n:(rank + 1) * shard.f.n]
+            remote_slots = int(((mine // shard.f.n) != rank).sum())   # ... for this many slots filled from other ranks
         for key, dt_ in zip(acc, ts_):
             acc[key] += dt_
     breakdown = {key: 1e6 * v / k_bd for key, v in acc.items()}
     if not gathered:
         breakdown["resample_with_migration"] = breakdown["resample_begin"] + breakdown["all_to_all"] + breakdown["resample_end"]
         breakdown["particles_received_rank0"] = migrants
+        breakdown["slots_filled_from_other_ranks_rank0"] = remote_slots
     else:
         breakdown["resample_with_migration"] = breakdown["all_gather_rows"] + breakdown["normalise+indices+import"]
     sync()

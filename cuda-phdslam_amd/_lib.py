@@ -121,6 +121,7 @@ SYMBOLS = {
     "phd_particle_pack_bytes": (_sz, [_vp]),
     "phd_export_particles_dev": (_i, [_vp, _vp, _i, _vp]),
     "phd_import_particles_dev": (_i, [_vp, _vp, _i, _vp]),
+    "phd_import_particles_sel_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
     "phd_finish_resample": (_i, [_vp]),
     "phd_global_resample_begin": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "phd_step_local_dev": (_i, [_vp, Control, _vp, _vp, _i]),

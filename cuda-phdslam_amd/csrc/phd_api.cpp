@@ -131,7 +131,7 @@ struct phd_filter {
     int lfact_len = 0;
     float2* cphd_scratch = nullptr; // [n_max][MM][MM]: rows of the ESF backward sweep (phd_kernels.hip, cphd_block)
     // migration plan of a global resample in flight (phd_global_resample_begin .. _end)
-    std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots;
+    std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots, plan_recv_rows;
     void* send_buf = nullptr;
     size_t send_buf_bytes = 0;
     void* rows_target = nullptr; // caller-owned destination of phd_step_local_rows_dev's rows (in-place all-gather)
@@ -813,9 +813,14 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
     WeightArgs w;
     int free_pose = 0;
     build_weight_args(f, mode, d_uniforms, n_uniforms, u0, w, free_pose);
+    // large sets: the routine's searches run on several workgroups that do not wait for each other, so the weights are
+    // written out of place (launch_weights) and the buffers swapped
+    const bool out_of_place = !f->frozen && f->n > 1024 && (mode & (WM_RESAMPLE_FORCE | WM_RESAMPLE_AUTO));
+    if (out_of_place) w.logw = f->logw_alt;
     t_begin(f, PHD_K_WEIGHTS);
     HIPCHK(launch_weights(w, f->stream));
     t_end(f);
+    if (out_of_place) std::swap(f->logw, f->logw_alt);
     commit_weights(f, mode, free_pose);
     return PHD_OK;
 }
@@ -1322,6 +1327,24 @@ extern "C" int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int
     return PHD_OK;
 }
 
+// the same with a row selection: slot slots[k] takes row rows[k] of the buffer (a received parent that fills several slots)
+extern "C" int phd_import_particles_sel_dev(phd_filter* f, const int32_t* slots, const int32_t* rows, int n, const void* d_buffer)
+{
+    CHECK_F(f);
+    if (!rows) return phd_import_particles_dev(f, slots, n, d_buffer);
+    if (n <= 0) return PHD_OK;
+    if (n > f->n) return fail(PHD_ERR_INVALID_ARG, "phd_import_particles_sel_dev: n > n_particles");
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3;
+    HIPCHK(hipMemcpyAsync(f->d_sizes, slots, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_tmp_int, rows, n * sizeof(int), hipMemcpyHostToDevice, f->stream)); // after phd_apply_parents' kernel (stream order)
+    HIPCHK(launch_import(f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], f->d_sizes, d_buffer, f->cap,
+                         phd_particle_pack_bytes(f), n, f->stream, f->d_tmp_int));
+    if (f->cphd)
+        HIPCHK(launch_copy_rows((const float*)d_buffer + 8 + 6 * f->cap, phd_particle_pack_bytes(f) / 4, f->d_tmp_int, nullptr,
+                                f->cn[f->cur ^ 1], f->cn_len, f->d_sizes, f->cn_len, n, f->stream));
+    return PHD_OK;
+}
+
 extern "C" int phd_finish_resample(phd_filter* f)
 {
     CHECK_F(f);
@@ -1397,13 +1420,25 @@ extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int w
     f->plan_recv_slots.clear();
     for (int j = 0; j < n; ++j)
         if (idx[off + j] / n == rank) f->plan_local_parent[j] = idx[off + j] - off;
+    // A parent travels ONCE per destination rank, however many of that rank's slots it fills (resampling is called when the
+    // weights have degenerated: a few parents fill most slots): both sides walk the destination's slots in order and skip
+    // a parent equal to the previous one from the same source (systematic indices are non-decreasing, so that is every
+    // repeat; were they not, the rule is still the same on both sides).  The receiver fans a row out to its slots.
+    f->plan_recv_rows.clear();
+    int row = -1;
     for (int r = 0; r < world; ++r) {
         send_counts[r] = recv_counts[r] = 0;
         if (r == rank) continue;
+        int last = -1;
         for (int g = r * n; g < (r + 1) * n; ++g)                  // what rank r needs from this rank, in r's slot order
-            if (idx[g] / n == rank) { f->plan_send.push_back(idx[g] - off); ++send_counts[r]; }
+            if (idx[g] / n == rank && idx[g] != last) { f->plan_send.push_back(idx[g] - off); ++send_counts[r]; last = idx[g]; }
+        last = -1;
         for (int j = 0; j < n; ++j)                                 // what this rank needs from rank r, in slot order
-            if (idx[off + j] / n == r) { f->plan_recv_slots.push_back(j); ++recv_counts[r]; }
+            if (idx[off + j] / n == r) {
+                if (idx[off + j] != last) { ++recv_counts[r]; ++row; last = idx[off + j]; }
+                f->plan_recv_slots.push_back(j);
+                f->plan_recv_rows.push_back(row);
+            }
     }
     int rc = ensure_send_buffer(f, std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f));
     if (rc) return rc;
@@ -1449,7 +1484,8 @@ extern "C" int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer)
     if (rc) return rc;
     if (!f->plan_recv_slots.empty()) {
         if (!d_recv_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_end: null receive buffer");
-        rc = phd_import_particles_dev(f, f->plan_recv_slots.data(), (int)f->plan_recv_slots.size(), d_recv_buffer);
+        rc = phd_import_particles_sel_dev(f, f->plan_recv_slots.data(), f->plan_recv_rows.data(), (int)f->plan_recv_slots.size(),
+                                          d_recv_buffer);
         if (rc) return rc;
     }
     f->plan_local_parent.clear();

@@ -745,7 +745,7 @@ __global__ __launch_bounds__(BT) void phd_gathered_resample_kernel(WeightArgs A,
     extern __shared__ __attribute__((aligned(16))) unsigned char s_gdyn[];
     __shared__ int s_row;
     const int k = blockIdx.x, tid = threadIdx.x;
-    weights_body<BT, R, false, true>(A, s_gdyn, off + k, k == 0, &s_row);
+    weights_body<BT, R, false, 1>(A, s_gdyn, off + k, k == 0, &s_row);
     __syncthreads();
     const float* o = (const float*)(buf + (size_t)s_row * stride);
     if (tid < 6) ((float*)&poses[k])[tid] = o[tid];
@@ -910,8 +910,10 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>,
+        hipError_t e = hipFuncSetAttribute((const void*)phd_weights_split_kernel<1024, 16, 8>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -919,12 +921,22 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
     // one table for this launcher and for the fused tail of the update kernel : 256 threads up
     // to 512 particles, 512 up to 4096, 1024 above; R = registers per thread
     const bool small = a.n_new <= a.n && a.n <= 16384;
-    if (small && a.n <= 256) hipLaunchKernelGGL((phd_weights_small_kernel<256, 1>), dim3(1), dim3(256), dyn, st, a);
-    else if (small && a.n <= 512) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, a);
-    else if (small && a.n <= 1024) hipLaunchKernelGGL((phd_weights_small_kernel<512, 2>), dim3(1), dim3(512), dyn, st, a);
-    else if (small && a.n <= 4096) hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, a);
-    else if (small) hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, a);
-    else if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
+    if (small) {
+        WeightArgs b = a;
+        // a pure index draw leaves the weights as they are: no write-back (and no alias for the split kernel to mind)
+        if (b.logw == b.logw_in && !(b.mode & (W_ACCUMULATE | W_NORMALIZE | W_COMMIT))) b.logw = nullptr;
+        const bool split = (b.mode & (W_RESAMPLE_FORCE | W_RESAMPLE_AUTO)) && b.n > 1024 && b.logw != b.logw_in;
+        // (above 1024 particles the index searches and copy_particles are split over 8 workgroups: same bits, a third of the time)
+        if (split && b.n <= 4096) hipLaunchKernelGGL((phd_weights_split_kernel<512, 8, 8>), dim3(8), dim3(512), dyn, st, b);
+        else if (split) hipLaunchKernelGGL((phd_weights_split_kernel<1024, 16, 8>), dim3(8), dim3(1024), dyn, st, b);
+        else if (b.n <= 256) hipLaunchKernelGGL((phd_weights_small_kernel<256, 1>), dim3(1), dim3(256), dyn, st, b);
+        else if (b.n <= 512) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, b);
+        else if (b.n <= 1024) hipLaunchKernelGGL((phd_weights_small_kernel<512, 2>), dim3(1), dim3(512), dyn, st, b);
+        else if (b.n <= 4096) hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, b);
+        else hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, b);
+        return hipGetLastError();
+    }
+    if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(phd_weights_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();
 }

@@ -35,27 +35,42 @@ __device__ __forceinline__ int cdf_scale_bits(int n)
 __device__ __forceinline__ u64 cdf_quantise(double p, double scale) { return (u64)floor((p > 1.0 ? 1.0 : p) * scale); }
 
 // in-place inclusive scan of q[0..m) (u64, LDS) by a workgroup of BT threads, plus `carry`; returns
-// the total (carry included).  Thread t owns the contiguous entries [t*per, (t+1)*per).
+// the total (carry included).  Wave w owns the contiguous block [w*64*per, (w+1)*64*per) and walks it in rows of 64
+// consecutive entries (lane l of a row reads entry row*64 + l: consecutive lanes, consecutive banks — a thread that owned
+// `per` consecutive entries would put the lanes 8*per bytes apart, a 32-way bank conflict at 16 per thread, which made this
+// scan 14.7 us at 16384 particles).  Integer sums: any grouping gives the same Q.
+__device__ __forceinline__ u64 lane63_u64(u64 v)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63);
+    return ((u64)hi << 32) | lo;
+}
 template <int BT>
 __device__ __forceinline__ u64 block_scan_u64(u64* q, int m, u64 carry, u64* s_wtot, int tid)
 {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const int per = (m + BT - 1) / BT;
-    const int lo = tid * per, hi = (lo + per < m) ? lo + per : m;
+    const int base = wave * 64 * per + lane;
     u64 local = 0;
-    for (int e = lo; e < hi; ++e) local += q[e];
-    const u64 incl = wave_incl_scan(local);
-    if (lane == 63) s_wtot[wave] = incl;
+    for (int e = 0; e < per; ++e) {
+        const int i = base + e * 64;
+        if (i < m) local += q[i];
+    }
+    const u64 wsum = lane63_u64(wave_incl_scan(local));
+    if (lane == 63) s_wtot[wave] = wsum;
     __syncthreads();
-    u64 woff = carry, total = carry;
+    u64 run = carry, total = carry;
 #pragma unroll
     for (int w = 0; w < BT / 64; ++w) {
         const u64 c = s_wtot[w];
-        if (w < wave) woff += c;
+        if (w < wave) run += c;
         total += c;
     }
-    u64 run = woff + incl - local;
-    for (int e = lo; e < hi; ++e) { run += q[e]; q[e] = run; }
+    for (int e = 0; e < per; ++e) {
+        const int i = base + e * 64;
+        const u64 incl = wave_incl_scan(i < m ? q[i] : 0ull);
+        if (i < m) q[i] = run + incl;
+        run += lane63_u64(incl);
+    }
     __syncthreads();
     return total;
 }
@@ -244,13 +259,17 @@ __device__ __forceinline__ phd_pose ld_pose(const phd_pose* p)
     return o;
 }
 
-// ONE_SLOT (the gathered multi-GPU resample, one launch for weights + import): every workgroup runs the whole routine on
-// the gathered weights but draws only the parent index of resampling slot `slot` (left in *one_out, LDS, valid after the
-// caller's barrier); only the `lead` workgroup writes the shared outputs (nEff, decision, normalised weights).
-template <int BT, int R, bool HANDOFF, bool ONE_SLOT = false>
+// WIN > 0 (slot window): the workgroup runs the whole routine on the weights but draws (and commits) only the resampling
+// slots [slot, slot + WIN * BT) — WIN searches per thread; only the `lead` workgroup writes the shared outputs (nEff,
+// decision, normalised weights).  Every workgroup of such a launch computes the same normalisation and the same CDF, so
+// there is nothing to exchange between them.  Two users: the gathered multi-GPU resample (WIN = 1, one slot per import
+// workgroup, its parent left in *one_out, LDS, valid after the caller's barrier) and phd_weights_split_kernel (the
+// searches and copy_particles of a large particle set split over several CUs).
+template <int BT, int R, bool HANDOFF, int WIN = 0>
 __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char* s_dyn, int slot = 0, bool lead = true,
                                              int* one_out = nullptr)
 {
+    constexpr bool WINDOWED = WIN > 0;
     __shared__ float sc[BT / 64];
     __shared__ int s_argmax;
     __shared__ u64 s_wtot[BT / 64];
@@ -258,7 +277,7 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
     __shared__ int s_besti[BT / 64];
     const int tid = threadIdx.x;
     const int n = A.n;
-#define WSTAMP(k) do { if (A.wstamps && tid == 0) A.wstamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WSTAMP(k) do { if (A.wstamps && tid == 0 && (!WINDOWED || lead)) A.wstamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
     WSTAMP(0);
     float w[R];
     // 1. load + accumulate (src/phdfilter.cu:3741-3744)
@@ -269,7 +288,7 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
         if (i < n) {
             w[r] = A.logw_in[A.in_stride ? (size_t)i * A.in_stride : (size_t)i];
             if (A.mode & W_ACCUMULATE) w[r] += ld_f32<HANDOFF>(&A.dlogw[i]);
-            if (A.raw_out) A.raw_out[i] = w[r];
+            if (A.raw_out && (!WINDOWED || lead)) A.raw_out[i] = w[r];
         }
     }
     // 2. logSumExp normalise (src/device_math.cuh:549-558, src/phdfilter.cu:3749-3754)
@@ -296,17 +315,26 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
     int doit = 0;
     if (A.mode & W_RESAMPLE_FORCE) doit = 1;
     else if ((A.mode & W_RESAMPLE_AUTO) && (neff <= A.resample_thresh) && (A.mode & W_HAD_MEAS)) doit = 1; // :1286
-    if (tid == 0 && (!ONE_SLOT || lead)) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
+    if (tid == 0 && (!WINDOWED || lead)) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
     const int n_new = A.n_new;
     if (!doit) { // uniform: neff is the same in every thread
-        if (!ONE_SLOT || lead) {
+        if (A.logw && (!WINDOWED || lead)) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int i = tid + r * BT;
                 if (i < n) A.logw[i] = w[r];
             }
         }
-        if (ONE_SLOT) { if (tid == 0) { A.idx_out[slot] = slot; *one_out = slot; } return; }
+        if (WINDOWED) { // (a window launch is always a forced resample; kept total for completeness)
+            const int lim = (A.mode & W_COMMIT) ? n : n_new;
+            const int je = (slot + WIN * BT < lim) ? slot + WIN * BT : lim;
+            for (int j = slot + tid; j < je; j += BT) {
+                A.idx_out[j] = j;
+                if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
+            }
+            if (one_out && tid == 0) *one_out = slot;
+            return;
+        }
         for (int j = tid; j < ((A.mode & W_COMMIT) ? n : n_new); j += BT) {
             A.idx_out[j] = j;                                                                          // :1292-1296
             if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
@@ -360,31 +388,46 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
     }
     WSTAMP(5);
     const float nlw = (float)(-log((double)A.n_weight_norm));
-    const int j_first = ONE_SLOT ? slot : 0, j_end = ONE_SLOT ? slot + 1 : n_new;
-    for (int j = j_first + tid; j < j_end; j += BT) {
-        const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
-        const double r = j * interval + u * interval;                                                  // :468
-        const u64 T = (u64)ceil(r * scale);
-        int idx;
-        if (T > ctot) {
-            idx = s_argmax;
-        } else {
-            int lo = 0, hi = n - 1;
-            while (lo < hi) { // smallest i with Q_i >= T
-                const int mid = (lo + hi) >> 1;
-                if (Q[mid] < T) lo = mid + 1; else hi = mid;
-            }
-            idx = lo;
+    // smallest i with Q_i >= T_j  ==  where the reference's "while (r > c) i++" stops (src/main.cpp:470-473).  The thread's
+    // R searches advance together, one power-of-two step per trip (branch-free lower bound): R independent LDS reads in
+    // flight per level instead of R x log2(n) dependent ones — the searches were half of this routine's time at 4096
+    // particles, which the fused step spends with every other workgroup already gone.
+    constexpr int RS = WINDOWED ? WIN : R;
+    const int j_first = WINDOWED ? slot : 0;
+    const int j_end = (WINDOWED && slot + WIN * BT < n_new) ? slot + WIN * BT : n_new;
+    u64 T[RS];
+    int pos[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int jj = j_first + tid + r * BT;
+        const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[jj < j_end ? jj : 0];
+        const double rr = jj * interval + u * interval;                                                // :468
+        T[r] = jj < j_end ? (u64)ceil(rr * scale) : 0ull; // 0: no Q is below it, the search stays at 0
+        pos[r] = 0;
+    }
+    for (int step = 1 << (31 - __clz(n)); step > 0; step >>= 1) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int probe = pos[r] + step; // pos = number of entries known to be < T
+            const u64 qv = Q[(probe <= n ? probe : n) - 1];
+            if (probe <= n && qv < T[r]) pos[r] = probe;
         }
-        A.idx_out[j] = idx;
-        if (ONE_SLOT) *one_out = idx;
+    }
+    WSTAMP(7);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int jj = j_first + tid + r * BT;
+        if (jj >= j_end) continue;
+        const int idx = (T[r] > ctot) ? s_argmax : pos[r];                                             // :475-494
+        A.idx_out[jj] = idx;
+        if (WINDOWED && one_out && jj == slot) *one_out = idx;
         if (A.mode & W_COMMIT) { // copy_particles (src/slamtypes.h:313-333)
-            A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[idx]);
-            A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[idx]);
+            A.pose_out[jj] = ld_pose<HANDOFF>(&A.pose_in[idx]);
+            A.parent_out[jj] = ld_i32<HANDOFF>(&A.parent_in[idx]);
         }
     }
     // weights: -log(N) after a committed resample (slamtypes.h:327), else the normalised values
-    if (!ONE_SLOT || lead) {
+    if (A.logw && (!WINDOWED || lead)) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = tid + r * BT;
@@ -392,6 +435,18 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
         }
     }
     WSTAMP(6);
+}
+
+// Large particle sets: the searches and copy_particles (half of the routine, instruction-bound on one CU) split over K
+// workgroups of slot windows; the normalisation and the CDF are repeated by each (identical: same block size, same trees).
+// The workgroups do not wait for each other, so the lead's weight output must not alias anybody's input: launch_weights
+// uses this kernel only when A.logw is NULL or a buffer other than A.logw_in.
+template <int BT, int R, int K>
+__global__ __launch_bounds__(BT) void phd_weights_split_kernel(WeightArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_wdyn[];
+    static_assert(R % K == 0, "slot windows");
+    weights_body<BT, R, false, R / K>(A, s_wdyn, (int)blockIdx.x * (R / K) * BT, blockIdx.x == 0, nullptr);
 }
 
 template <int BT, int R>

@@ -286,13 +286,15 @@ int phd_apply_parents(phd_filter* f, const int32_t* local_parent);
 size_t phd_particle_pack_bytes(const phd_filter* f);
 int phd_export_particles_dev(phd_filter* f, const int32_t* particles, int n, void* d_buffer);
 int phd_import_particles_dev(phd_filter* f, const int32_t* slots, int n, const void* d_buffer);
+/* slot slots[k] <- row rows[k] of the buffer (rows == NULL: row k): a received parent may fill several slots */
+int phd_import_particles_sel_dev(phd_filter* f, const int32_t* slots, const int32_t* rows, int n, const void* d_buffer);
 int phd_finish_resample(phd_filter* f); /* weights <- -log(global_particles) */
 
 /* The same exchange in two calls (one host round trip per resampling step).  begin: global indices
  * (phd_global_resample_indices on the gathered, normalised weights of phd_global_normalize), this
  * rank's part of the migration plan, export of the particles other ranks need into a library-owned
  * send buffer (grouped by destination rank; send_counts/recv_counts[world] in particles of
- * phd_particle_pack_bytes()).  The caller runs all_to_all_single(recv, send, recv_counts,
+ * phd_particle_pack_bytes(); a parent travels once per destination rank however many of its slots it fills).  The caller runs all_to_all_single(recv, send, recv_counts,
  * send_counts) (RCCL).  end: copy_particles on the shard (local parents + received particles),
  * weights <- -log(global_particles).  idx_out (optional, host, global_particles entries).
  * d_all_raw_logw: NULL after phd_global_normalize; or the gathered UN-normalised weights, in which case

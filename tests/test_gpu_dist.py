@@ -109,3 +109,49 @@ def test_two_ranks_equal_one_filter(tmp_path, fast, exchange):
             assert np.array_equal(got, maps[r * n + j]), (r, j)
         moved += int(np.sum(idx[r * n:(r + 1) * n] // n != r))
     assert moved > 0
+
+
+def test_migration_plan_moves_a_parent_once_per_destination():
+    """Degenerate weights (the case resampling exists for): one heavy parent fills most slots of every rank.  The plan sends
+    it ONCE to each rank that needs it; the receiver fans the row out to its slots.  Two shards of one 16-particle filter
+    on this GPU, crafted parent indices, device-copy transport."""
+    import ctypes as C
+    import torch
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    D = importlib.import_module("cuda-phdslam_amd.dist")
+    N, G, M, world = 16, 24, 10, 2
+    n = N // world
+    w = S.make_workload(N, G, M, seed=5)
+    # slots 0..9 <- particle 3 (rank 0), slots 10..12 <- 9 (rank 1), 13..14 <- 12 (rank 1), 15 <- 6 (rank 0; not sorted on purpose)
+    idx = np.array([3] * 10 + [9] * 3 + [12] * 2 + [6], np.int32)
+    shards = []
+    for r in range(world):
+        f = P.PhdFilter(P.default_config(n_particles=N), n_particles=n, map_capacity=4 * G, max_measurements=M,
+                        global_particles=N, global_offset=r * n)
+        f.set_particles(w["poses"][r * n:(r + 1) * n], w["logw"][r * n:(r + 1) * n])
+        f.set_maps(w["maps"][r * n:(r + 1) * n], w["sizes"][r * n:(r + 1) * n])
+        shards.append(D.GpuShard(f, N))
+    lib = P._lib.lib()
+    plans = []
+    for r, sh in enumerate(shards):
+        sc, rc, buf = (C.c_int32 * world)(), (C.c_int32 * world)(), C.c_void_p()
+        assert lib.phd_global_resample_plan(sh.f._h, idx.ctypes.data_as(C.c_void_p), world, r, sc, rc, C.byref(buf)) == 0
+        sh.f.sync()
+        pack = sh.pack_bytes()
+        rows = max(sum(sc), 1)
+        plans.append((list(sc), list(rc), sh._wrap(buf.value, rows * pack // 4).view(torch.uint8).view(rows, pack)))
+    # rank 0 -> rank 1: particle 3 once (slots 8, 9) and particle 6 once (slot 15); rank 1 -> rank 0: nothing
+    assert plans[0][0] == [0, 2] and plans[0][1] == [0, 0]
+    assert plans[1][0] == [0, 0] and plans[1][1] == [2, 0]
+    shards[0].resample_end(torch.empty((1, shards[0].pack_bytes()), dtype=torch.uint8, device="cuda:0"))
+    shards[1].resample_end(plans[0][2][:2].clone())
+    for r, sh in enumerate(shards):
+        poses, lw = sh.f.get_particles()
+        maps = sh.f.get_maps()
+        assert np.all(lw == np.float32(-np.log(N)))
+        for j in range(n):
+            src = int(idx[r * n + j])
+            assert poses[j].tobytes() == w["poses"][src].tobytes(), (r, j)
+            assert maps[j].tobytes() == w["maps"][src][:w["sizes"][src]].tobytes(), (r, j)
+        sh.f.close()

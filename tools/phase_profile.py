@@ -29,6 +29,9 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
         ws = f.weight_stamps.astype(np.int64)
         print("   weights kernel phases (us): load+normalise %.2f, neff %.2f, det_exp %.2f, scan %.2f, guard %.2f, search+commit %.2f"
               % tuple(np.diff(ws[:7]) * 0.01))
+        if ws[7]:
+            print("      inside search+commit: index searches %.2f us, copy_particles of the poses / parents + weights %.2f us"
+                  % ((ws[7] - ws[5]) * 0.01, (ws[6] - ws[7]) * 0.01))
         d = np.diff(st[:, :12], axis=1) * 0.01  # us
         tot = (st[:, 11] - st[:, 0]) * 0.01
         span = (st[:, 11].max() - st[:, 0].min()) * 0.01
