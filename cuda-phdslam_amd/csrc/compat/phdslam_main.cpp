@@ -36,6 +36,7 @@ static void die(const char* where)
 
 int main(int argc, char** argv)
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0); // per-step progress lines reach a pipe as they are printed
     if (argc < 2) {
         fprintf(stderr, "usage: %s <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--devices N [--shards S]]\n", argv[0]);
         return 2;

@@ -106,6 +106,8 @@ struct phd_filter {
     int* max_surv = nullptr;
     int* max_map = nullptr;
     int* d_tmp_int = nullptr; // n entries (selection / slot lists)
+    int* h_plan = nullptr;    // pinned [2 n]: per slot the local parent (or -1) | the received row: phd_global_resample_plan -> _end
+    int* d_plan = nullptr;
     unsigned* ticket = nullptr; // arrival counter of the fused step (zero between launches)
     bool fuse_enabled = true;
     // staging for AoS <-> SoA
@@ -270,6 +272,8 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     f->neff = (float*)f->report + 3; f->did = (int*)f->report + 4;
     A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
     A(dalloc(&f->d_tmp_int, f->n_max));
+    A(dalloc(&f->d_plan, 2 * (size_t)f->n_max));
+    A(hipHostMalloc((void**)&f->h_plan, 2 * (size_t)f->n_max * sizeof(int)));
     A(dalloc(&f->ticket, 1));
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
     if (f->spill_cap) {
@@ -328,7 +332,8 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
     hipFree(f->report); hipFree(f->state_pose); hipFree(f->state_argmax);
-    hipFree(f->d_tmp_int); hipFree(f->ticket);
+    hipFree(f->d_tmp_int); hipFree(f->ticket); hipFree(f->d_plan);
+    if (f->h_plan) hipHostFree(f->h_plan);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
@@ -1419,7 +1424,7 @@ extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int w
     f->plan_send.clear();
     f->plan_recv_slots.clear();
     for (int j = 0; j < n; ++j)
-        if (idx[off + j] / n == rank) f->plan_local_parent[j] = idx[off + j] - off;
+        if ((unsigned)(idx[off + j] - off) < (unsigned)n) f->plan_local_parent[j] = idx[off + j] - off;
     // A parent travels ONCE per destination rank, however many of that rank's slots it fills (resampling is called when the
     // weights have degenerated: a few parents fill most slots): both sides walk the destination's slots in order and skip
     // a parent equal to the previous one from the same source (systematic indices are non-decreasing, so that is every
@@ -1431,15 +1436,19 @@ extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int w
         if (r == rank) continue;
         int last = -1;
         for (int g = r * n; g < (r + 1) * n; ++g)                  // what rank r needs from this rank, in r's slot order
-            if (idx[g] / n == rank && idx[g] != last) { f->plan_send.push_back(idx[g] - off); ++send_counts[r]; last = idx[g]; }
+            if ((unsigned)(idx[g] - off) < (unsigned)n && idx[g] != last) { f->plan_send.push_back(idx[g] - off); ++send_counts[r]; last = idx[g]; }
         last = -1;
         for (int j = 0; j < n; ++j)                                 // what this rank needs from rank r, in slot order
-            if (idx[off + j] / n == r) {
+            if ((unsigned)(idx[off + j] - r * n) < (unsigned)n) {
                 if (idx[off + j] != last) { ++recv_counts[r]; ++row; last = idx[off + j]; }
                 f->plan_recv_slots.push_back(j);
                 f->plan_recv_rows.push_back(row);
             }
     }
+    // per-slot form of the same plan for phd_global_resample_end's single launch (pinned: the upload does not stage).  The
+    // previous step's upload has completed: the caller synchronised to read this step's indices.
+    for (int j = 0; j < n; ++j) { f->h_plan[j] = f->plan_local_parent[j]; f->h_plan[n + j] = -1; }
+    for (size_t k = 0; k < f->plan_recv_slots.size(); ++k) f->h_plan[n + f->plan_recv_slots[k]] = f->plan_recv_rows[k];
     int rc = ensure_send_buffer(f, std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f));
     if (rc) return rc;
     if (!f->plan_send.empty()) {
@@ -1480,16 +1489,26 @@ extern "C" int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer)
 {
     CHECK_F(f);
     if ((int)f->plan_local_parent.size() != f->n) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_end: no plan (call _begin first)");
-    int rc = phd_apply_parents(f, f->plan_local_parent.data());
-    if (rc) return rc;
-    if (!f->plan_recv_slots.empty()) {
-        if (!d_recv_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_end: null receive buffer");
-        rc = phd_import_particles_sel_dev(f, f->plan_recv_slots.data(), f->plan_recv_rows.data(), (int)f->plan_recv_slots.size(),
-                                          d_recv_buffer);
-        if (rc) return rc;
-    }
+    if (!f->plan_recv_slots.empty() && !d_recv_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_end: null receive buffer");
+    // one upload, one launch: local parents, received rows, weights <- -log N, identity indirection (copy_particles,
+    // src/slamtypes.h:313-333; the staged trio phd_apply_parents / phd_import_particles_dev / phd_finish_resample does the same
+    // in three uploads and four launches)
+    const int n = f->n;
+    HIPCHK(hipMemcpyAsync(f->d_plan, f->h_plan, 2 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3; // a frozen fused predict parks the predicted poses in +1
+    HIPCHK(launch_resample_end(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur],
+                               f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], f->d_plan, n, d_recv_buffer,
+                               phd_particle_pack_bytes(f), f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], f->cap,
+                               f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
+                               f->frozen ? nullptr : f->parent[f->pcur ^ 1], f->cphd ? f->cn[f->cur] : nullptr,
+                               f->cphd ? f->cn[f->cur ^ 1] : nullptr, f->cn_len, f->stream));
     f->plan_local_parent.clear();
-    return phd_finish_resample(f);
+    if (f->frozen) return PHD_OK; // bench protocol: the exchange ran, the snapshot stays
+    f->cur ^= 1;
+    f->pose_cur = (f->pose_cur + 1) % 3;
+    f->pcur ^= 1;
+    f->parent_dirty = false;
+    return PHD_OK; // stream-ordered: no host synchronisation
 }
 
 // The same exchange for SMALL shards without a host round trip (the "gathered" exchange): every rank all-gathers every

@@ -150,6 +150,10 @@ hipError_t launch_gathered_resample(const WeightArgs& a, float* slabs, int* coun
 hipError_t launch_import(float* slabs, int* counts, phd_pose* poses, const int* which, const void* buf, int cap,
                          size_t stride, int n, hipStream_t st, const int* rowsel = nullptr, float* logw_fill = nullptr,
                          float nlw = 0.f, int* parent_reset = nullptr);
+hipError_t launch_resample_end(const float* src, const int* counts_src, const int* parent, const phd_pose* pose_src, const int* plan,
+                               int n, const void* recv, size_t stride, float* dst, int* counts_dst, phd_pose* pose_dst, int cap,
+                               float* logw_fill, float nlw, int* parent_next, const float* cn_src, float* cn_dst, int cn_len,
+                               hipStream_t st);
 hipError_t launch_gather_maps(const float* src, const int* counts_src, const int* parent, const int* sel, float* dst,
                               int* counts_dst, const phd_pose* pose_src, phd_pose* pose_dst, int cap, int n,
                               hipStream_t st);

@@ -760,6 +760,47 @@ __global__ __launch_bounds__(BT) void phd_gathered_resample_kernel(WeightArgs A,
         for (int i = tid; i < cn_len; i += BT) cn_dst[(size_t)k * cn_len + i] = o[8 + 6 * cap + i];
 }
 
+// copy_particles (src/slamtypes.h:313-333) after a global resample, both sources in ONE launch: slot j takes its parent from this
+// shard (plan[j] >= 0: the local particle; map through the indirection `parent`) or from the received rows (plan[n + j]: the
+// row of the all-to-all's receive buffer; a row may fill several slots).  Tail of copy_particles in the same launch:
+// weights <- -log N (:327), the next step's map indirection <- identity (written to the OTHER indirection buffer: this
+// launch still reads the current one).
+__global__ void phd_resample_end_kernel(const float* __restrict__ src, const int* __restrict__ counts_src,
+                                        const int* __restrict__ parent, const phd_pose* __restrict__ pose_src,
+                                        const int* __restrict__ plan, int n, const unsigned char* __restrict__ recv, size_t stride,
+                                        float* __restrict__ dst, int* __restrict__ counts_dst, phd_pose* __restrict__ pose_dst,
+                                        int cap, float* __restrict__ logw_fill, float nlw, int* __restrict__ parent_next,
+                                        const float* __restrict__ cn_src, float* __restrict__ cn_dst, int cn_len)
+{
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int lp = plan[j];
+    const float *a, *cn;
+    int cnt;
+    if (lp >= 0) {
+        const int s = parent ? parent[lp] : lp;
+        cnt = counts_src[s];
+        a = src + (size_t)s * 6 * cap;
+        cn = cn_src ? cn_src + (size_t)s * cn_len : nullptr;
+        if (tid < 6) ((float*)&pose_dst[j])[tid] = ((const float*)&pose_src[lp])[tid];
+    } else {
+        const float* o = (const float*)(recv + (size_t)plan[n + j] * stride);
+        cnt = ((const int*)o)[6];
+        a = o + 8;
+        cn = o + 8 + 6 * cap;
+        if (tid < 6) ((float*)&pose_dst[j])[tid] = o[tid];
+    }
+    if (tid == 6) counts_dst[j] = cnt;
+    if (tid == 7) {
+        if (logw_fill) logw_fill[j] = nlw;
+        if (parent_next) parent_next[j] = j;
+    }
+    float* b = dst + (size_t)j * 6 * cap;
+    for (int pl = 0; pl < 6; ++pl)
+        for (int i = tid; i < cnt; i += blockDim.x) b[pl * cap + i] = a[pl * cap + i];
+    if (cn_dst)
+        for (int i = tid; i < cn_len; i += blockDim.x) cn_dst[(size_t)j * cn_len + i] = cn[i];
+}
+
 // copy_particles for the maps (src/slamtypes.h:313-333): dst[p] = src[parent[sel[p]]] (maps, counts, poses);
 // sel == NULL: identity; sel[p] < 0: slot is filled by phd_import_kernel instead
 __global__ void phd_gather_maps_kernel(const float* __restrict__ src, const int* __restrict__ counts_src,
@@ -1027,6 +1068,18 @@ hipError_t launch_gathered_resample(const WeightArgs& a, float* slabs, int* coun
     else if (a.n <= 512) PHD_GR(256, 2);
     else PHD_GR(512, 2);
 #undef PHD_GR
+    return hipGetLastError();
+}
+
+hipError_t launch_resample_end(const float* src, const int* counts_src, const int* parent, const phd_pose* pose_src, const int* plan,
+                               int n, const void* recv, size_t stride, float* dst, int* counts_dst, phd_pose* pose_dst, int cap,
+                               float* logw_fill, float nlw, int* parent_next, const float* cn_src, float* cn_dst, int cn_len,
+                               hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(phd_resample_end_kernel, dim3(n), dim3(256), 0, st, src, counts_src, parent, pose_src, plan, n,
+                       (const unsigned char*)recv, stride, dst, counts_dst, pose_dst, cap, logw_fill, nlw, parent_next, cn_src,
+                       cn_dst, cn_len);
     return hipGetLastError();
 }
 

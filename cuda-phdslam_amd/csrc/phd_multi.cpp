@@ -321,6 +321,9 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
         std::vector<int> devs(world);
         std::vector<ncclComm_t> comms(world);
         for (int k = 0; k < world; ++k) devs[k] = m->sh[k].device;
+        // one process, one node: the bootstrap needs no routable interface (a box without one may stall RCCL's interface
+        // search); the caller's own setting wins
+        setenv("NCCL_SOCKET_IFNAME", "lo", 0);
         ncclResult_t r = ncclCommInitAll(comms.data(), world, devs.data());
         if (r != ncclSuccess) rc = fail(PHD_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
         else for (int k = 0; k < world; ++k) m->sh[k].comm = comms[k];
