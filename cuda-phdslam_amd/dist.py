@@ -37,10 +37,15 @@ def plan_migration(idx, n_global, world, rank):
     exchange:
         local_parent[j]  : local index of slot j's parent, or -1 if the parent is remote
         send[r]          : local particle indices to export to rank r (in the order r expects)
-        recv_slots[r]    : local slots filled by what rank r sends (same order)
+        recv_slots[r]    : local slots filled by what rank r sends, in slot order
+        recv_rows[r]     : for each of those slots, the row of the receive buffer (rows grouped by source rank,
+                           ascending) that fills it
     Slot j of rank q (global index g = q*n + j) receives particle idx[g]; rank idx[g] // n owns it.
-    A parent needed by several slots of the same remote rank is sent once per slot: systematic
-    indices are non-decreasing, so duplicates are rare and the plan stays a pure function of idx.
+    A parent travels ONCE per destination rank however many of its slots it fills (resampling is called when the
+    weights have degenerated: a few parents fill most slots): both sides walk the destination's slots in order and skip
+    a parent equal to the previous one from the same source — systematic indices are non-decreasing, so that is every
+    repeat; were they not, the rule is still the same on both sides.  The same plan as phd_global_resample_plan
+    (csrc/phd_api.cpp).
     """
     off, n = shard_range(n_global, world, rank)
     idx = np.asarray(idx, np.int64)
@@ -50,19 +55,30 @@ def plan_migration(idx, n_global, world, rank):
     mine = idx[off:off + n]
     is_local = owner[off:off + n] == rank
     local_parent[is_local] = (mine[is_local] - off).astype(np.int32)
-    send, recv_slots = [], []
+
+    def first_of_run(a):
+        keep = np.ones(len(a), bool)
+        keep[1:] = a[1:] != a[:-1]
+        return keep
+
+    send, recv_slots, recv_rows = [], [], []
+    row0 = 0
     for r in range(world):
         if r == rank:
             send.append(np.zeros(0, np.int32))
             recv_slots.append(np.zeros(0, np.int32))
+            recv_rows.append(np.zeros(0, np.int32))
             continue
-        # what rank r needs from me: its slots whose parent I own, in slot order
-        need = (dest_rank == r) & (owner == rank)
-        send.append((idx[need] - off).astype(np.int32))
-        # what I need from rank r: my slots whose parent r owns, in slot order
+        # what rank r needs from me: its slots whose parent I own, in slot order, runs of one parent collapsed
+        need = idx[(dest_rank == r) & (owner == rank)]
+        send.append((need[first_of_run(need)] - off).astype(np.int32))
+        # what I need from rank r: my slots whose parent r owns, in slot order; a run shares one row
         got = np.nonzero(owner[off:off + n] == r)[0]
+        new = first_of_run(mine[got])
         recv_slots.append(got.astype(np.int32))
-    return local_parent, send, recv_slots
+        recv_rows.append((row0 + np.cumsum(new) - 1).astype(np.int32))
+        row0 += int(new.sum())
+    return local_parent, send, recv_slots, recv_rows
 
 
 class ShardedFilter:
@@ -175,16 +191,17 @@ class ShardedFilter:
             self.b.resample_end(recv)
             return idx
         idx = self.b.global_resample_indices(uniform)       # numpy [n_global], identical on all ranks
-        local_parent, send, recv_slots = plan_migration(idx, self.n_global, self.world, self.rank)
+        local_parent, send, recv_slots, recv_rows = plan_migration(idx, self.n_global, self.world, self.rank)
         if self.collectives:
             send_counts = [len(s) for s in send]
-            recv_counts = [len(s) for s in recv_slots]
+            recv_counts = [int(len(np.unique(r))) for r in recv_rows]
             order = np.concatenate(send) if sum(send_counts) else np.zeros(0, np.int32)
             out_buf = self.b.export_particles(order)        # tensor [n_send, pack] (uint8)
             in_buf = self._exchange(out_buf, send_counts, recv_counts, self.b.pack_bytes())
             self.b.apply_parents(local_parent)
             slots = np.concatenate(recv_slots) if sum(recv_counts) else np.zeros(0, np.int32)
-            self.b.import_particles(slots, in_buf)
+            rows = np.concatenate(recv_rows) if sum(recv_counts) else np.zeros(0, np.int32)
+            self.b.import_particles(slots, in_buf, rows)
         else:
             self.b.apply_parents(local_parent)
         self.b.finish_resample()
@@ -294,11 +311,13 @@ class GpuShard:
         lp = np.ascontiguousarray(local_parent, np.int32)
         self._check(self._lib().phd_apply_parents(self.f._h, self._ptr(lp)), "phd_apply_parents")
 
-    def import_particles(self, slots, buf):
+    def import_particles(self, slots, buf, rows=None):
+        """slot slots[k] <- row rows[k] of buf (rows None: row k)"""
         slots = np.ascontiguousarray(slots, np.int32)
+        rows = None if rows is None else np.ascontiguousarray(rows, np.int32)
         self._torch_to_filter()
-        self._check(self._lib().phd_import_particles_dev(self.f._h, self._ptr(slots), len(slots),
-                                                         self._ptr(buf.data_ptr())), "phd_import_particles_dev")
+        self._check(self._lib().phd_import_particles_sel_dev(self.f._h, self._ptr(slots), None if rows is None else self._ptr(rows),
+                                                             len(slots), self._ptr(buf.data_ptr())), "phd_import_particles_sel_dev")
 
     def finish_resample(self):
         self._check(self._lib().phd_finish_resample(self.f._h), "phd_finish_resample")

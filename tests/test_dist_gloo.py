@@ -61,10 +61,10 @@ class NumpyShard:
                 self._next[0][j] = self.maps[s].copy()
                 self._next[1][j] = self.poses[s]
 
-    def import_particles(self, slots, buf):
+    def import_particles(self, slots, buf, rows=None):
         b = buf.numpy()
         for k, j in enumerate(slots):
-            rec = b[k].view(np.float32)
+            rec = b[k if rows is None else rows[k]].view(np.float32)
             self._next[1][j] = rec[0]
             self._next[0][j] = rec[2:2 + int(rec[1])].copy()
 
@@ -160,19 +160,37 @@ def test_plan_migration_properties():
         n_global = 64 * world
         idx = np.sort(rng.integers(0, n_global, n_global))         # non-decreasing like systematic resampling
         n = n_global // world
-        plans = [D.plan_migration(idx, n_global, world, r) for r in range(world)]
-        for r, (lp, send, recv) in enumerate(plans):
-            # every slot is filled exactly once: locally or by exactly one remote rank
-            filled = np.zeros(n, int)
-            filled[lp >= 0] += 1
-            for q in range(world):
-                filled[recv[q]] += 1
-                # what r expects from q is what q plans to send to r, in the same order
-                assert len(plans[q][1][r]) == len(recv[q])
-                if len(recv[q]):
-                    assert np.array_equal(plans[q][1][r] + q * n, idx[r * n + recv[q]])
-            assert np.all(filled == 1)
-            assert np.array_equal(lp[lp >= 0] + r * n, idx[r * n:(r + 1) * n][lp >= 0])
+        check_plans(idx, n_global, world)
+    # degenerate weights, the case resampling exists for: three parents fill every slot; each travels once per destination
+    world, n = 4, 64
+    idx = np.sort(np.concatenate([np.full(150, 5), np.full(100, 70), np.full(6, 200)]))
+    plans = check_plans(idx, world * n, world)
+    assert [len(s) for s in plans[0][1]] == [0, 1, 1, 0]           # rank 0 owns particle 5: needed by ranks 1 and 2 (slots 64..149)
+    assert [len(s) for s in plans[1][1]] == [0, 0, 1, 1]           # rank 1 owns particle 70: fills 150..249 (ranks 2 and 3)
+    assert sum(len(s) for s in plans[3][2]) == 58 and len(np.unique(np.concatenate(plans[3][3]))) == 1   # slots 192..249 <- one row
+
+
+def check_plans(idx, n_global, world):
+    n = n_global // world
+    plans = [D.plan_migration(idx, n_global, world, r) for r in range(world)]
+    for r, (lp, send, recv, rows) in enumerate(plans):
+        # every slot is filled exactly once: locally or by exactly one remote rank
+        filled = np.zeros(n, int)
+        filled[lp >= 0] += 1
+        row0 = 0
+        for q in range(world):
+            filled[recv[q]] += 1
+            if len(recv[q]):
+                # the row a slot takes, counted inside q's block of the receive buffer, is where q put that slot's parent
+                rel = rows[q] - row0
+                assert rel.min() == 0 and rel.max() == len(plans[q][1][r]) - 1 and np.all(np.diff(rel) >= 0)
+                assert np.array_equal(plans[q][1][r][rel] + q * n, idx[r * n + recv[q]])
+            else:
+                assert len(plans[q][1][r]) == 0
+            row0 += len(plans[q][1][r])
+        assert np.all(filled == 1)
+        assert np.array_equal(lp[lp >= 0] + r * n, idx[r * n:(r + 1) * n][lp >= 0])
+    return plans
 
 
 # ----------------------------------------------------------------------------------------------

@@ -125,13 +125,17 @@ def test_migration_plan_moves_a_parent_once_per_destination():
     w = S.make_workload(N, G, M, seed=5)
     # slots 0..9 <- particle 3 (rank 0), slots 10..12 <- 9 (rank 1), 13..14 <- 12 (rank 1), 15 <- 6 (rank 0; not sorted on purpose)
     idx = np.array([3] * 10 + [9] * 3 + [12] * 2 + [6], np.int32)
-    shards = []
-    for r in range(world):
-        f = P.PhdFilter(P.default_config(n_particles=N), n_particles=n, map_capacity=4 * G, max_measurements=M,
-                        global_particles=N, global_offset=r * n)
-        f.set_particles(w["poses"][r * n:(r + 1) * n], w["logw"][r * n:(r + 1) * n])
-        f.set_maps(w["maps"][r * n:(r + 1) * n], w["sizes"][r * n:(r + 1) * n])
-        shards.append(D.GpuShard(f, N))
+    def make_shards():
+        out = []
+        for r in range(world):
+            f = P.PhdFilter(P.default_config(n_particles=N), n_particles=n, map_capacity=4 * G, max_measurements=M,
+                            global_particles=N, global_offset=r * n)
+            f.set_particles(w["poses"][r * n:(r + 1) * n], w["logw"][r * n:(r + 1) * n])
+            f.set_maps(w["maps"][r * n:(r + 1) * n], w["sizes"][r * n:(r + 1) * n])
+            out.append(D.GpuShard(f, N))
+        return out
+
+    shards = make_shards()
     lib = P._lib.lib()
     plans = []
     for r, sh in enumerate(shards):
@@ -146,12 +150,29 @@ def test_migration_plan_moves_a_parent_once_per_destination():
     assert plans[1][0] == [0, 0] and plans[1][1] == [2, 0]
     shards[0].resample_end(torch.empty((1, shards[0].pack_bytes()), dtype=torch.uint8, device="cuda:0"))
     shards[1].resample_end(plans[0][2][:2].clone())
+    def check_and_close():
+        for r, sh in enumerate(shards):
+            poses, lw = sh.f.get_particles()
+            maps = sh.f.get_maps()
+            assert np.all(lw == np.float32(-np.log(N)))
+            for j in range(n):
+                src = int(idx[r * n + j])
+                assert poses[j].tobytes() == w["poses"][src].tobytes(), (r, j)
+                assert maps[j].tobytes() == w["maps"][src][:w["sizes"][src]].tobytes(), (r, j)
+            sh.f.close()
+
+    check_and_close()
+    # the same exchange planned in Python (dist.plan_migration: the staged calls export / apply_parents / import / finish)
+    shards = make_shards()
+    py = [D.plan_migration(idx, N, world, r) for r in range(world)]
+    assert [[len(s) for s in p[1]] for p in py] == [plans[0][0], plans[1][0]]          # the library's send counts
+    sent = [sh.export_particles(np.concatenate(py[r][1])) for r, sh in enumerate(shards)]
     for r, sh in enumerate(shards):
-        poses, lw = sh.f.get_particles()
-        maps = sh.f.get_maps()
-        assert np.all(lw == np.float32(-np.log(N)))
-        for j in range(n):
-            src = int(idx[r * n + j])
-            assert poses[j].tobytes() == w["poses"][src].tobytes(), (r, j)
-            assert maps[j].tobytes() == w["maps"][src][:w["sizes"][src]].tobytes(), (r, j)
-        sh.f.close()
+        lp, send, slots, rows = py[r]
+        # what the other rank sent to r (two ranks: the whole of its send buffer)
+        recv = sent[1 - r] if len(sent[1 - r]) else torch.empty((1, sh.pack_bytes()), dtype=torch.uint8, device="cuda:0")
+        sh.apply_parents(lp)
+        if sum(len(x) for x in slots):
+            sh.import_particles(np.concatenate(slots), recv, np.concatenate(rows))
+        sh.finish_resample()
+    check_and_close()
