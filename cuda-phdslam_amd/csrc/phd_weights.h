@@ -327,7 +327,8 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
         }
         if (WINDOWED) { // (a window launch is always a forced resample; kept total for completeness)
             const int lim = (A.mode & W_COMMIT) ? n : n_new;
-            const int je = (slot + WIN * BT < lim) ? slot + WIN * BT : lim;
+            const int sp = one_out ? 1 : WIN * BT;
+            const int je = (slot + sp < lim) ? slot + sp : lim;
             for (int j = slot + tid; j < je; j += BT) {
                 A.idx_out[j] = j;
                 if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
@@ -394,7 +395,8 @@ __device__ __forceinline__ void weights_body(const WeightArgs& A, unsigned char*
     // particles, which the fused step spends with every other workgroup already gone.
     constexpr int RS = WINDOWED ? WIN : R;
     const int j_first = WINDOWED ? slot : 0;
-    const int j_end = (WINDOWED && slot + WIN * BT < n_new) ? slot + WIN * BT : n_new;
+    const int span = one_out ? 1 : WIN * BT;   // the gathered resample draws ONE slot per workgroup
+    const int j_end = (WINDOWED && slot + span < n_new) ? slot + span : n_new;
     u64 T[RS];
     int pos[RS];
 #pragma unroll
