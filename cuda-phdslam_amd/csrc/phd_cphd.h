@@ -105,6 +105,9 @@ __device__ __forceinline__ void cphd_esf_forward_park(const CphdLds& Q, float2* 
     float pm[4] = {0.f, 0.f, 0.f, 0.f};
     int pk[4] = {XF_ZERO_K, XF_ZERO_K, XF_ZERO_K, XF_ZERO_K};
     const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);   // a chain of M dependent steps on one wave: let it issue ahead of the SIMD's other waves
+#endif
     for (int m = 0; m < M; ++m) {
         // park row m: P_m[0..m] ([0] = 1 = 0.5 * 2^1)
         float2* row = P_scratch + (size_t)m * M;
@@ -146,6 +149,9 @@ __device__ __forceinline__ void cphd_esf_forward_park(const CphdLds& Q, float2* 
     for (int c = 0; c < 4; ++c)
         if (c < tiles && lane + 1 + 64 * c <= M)
             Q.efull[lane + 1 + 64 * c] = pm[c] > 0.f ? logf(pm[c]) + (float)pk[c] * 0.69314718f : LOG0F;
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __threadfence(); // the rows are read back by the other waves of this workgroup (after its barrier)
 }
 
@@ -209,6 +215,9 @@ __device__ __forceinline__ void cphd_esf_backward_dot(const CphdLds& Q, const fl
         }
     }
     const float xv = (tiles == 1 && lane < M) ? Q.lxi[lane] : 0.f;
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (int mb = M - 1; mb >= 0; mb -= PF * PHD_FW) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -280,6 +289,9 @@ __device__ __forceinline__ void cphd_esf_backward_dot(const CphdLds& Q, const fl
     }
     }
     }
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // barrier among a subset of the workgroup's waves (the hardware barrier counts all of them): an LDS arrival counter,
