@@ -627,6 +627,19 @@ def main():
             r["steps"] = k
             r["shard_steps_per_s"] = r["value"] * world       # round 1's unit for this workload (ranks x steps / time)
             secondary.append(r)
+            if world > 1 and cfg_id == 4:
+                # the N = 1 point of THIS line, measured in this run: the same 16384-particle filter on ONE GPU (rank 0 alone,
+                # fused/staged single-GPU step; the other ranks wait) — what value / N is to be compared with
+                dist.barrier()
+                if rank == 0:
+                    k1 = min(args.steps, 50)
+                    r1 = run_single(P, S, torch, 4, k1, max(min(args.warmup, 20), 5), 0.0, dev, local_rank, args.preroll_ms,
+                                    extras=False)
+                    r1["steps"] = k1
+                    r1["note"] = ("the same workload on ONE GPU, measured by rank 0 in this run while the other ranks wait: "
+                                  "the N = 1 point of this strong-scaling line")
+                    secondary.append(r1)
+                dist.barrier()
         scaling = "strong"  # total work (one 16384-particle filter) is fixed as N grows
 
     if rank == 0:
