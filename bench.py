@@ -536,6 +536,14 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, n_shards, preroll_ms):
     return res
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                         # best effort: only the ordering of a banner depends on it
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -592,6 +600,8 @@ def main():
         torch.cuda.set_device(0)
         res = run_cpp_multi(P, S, torch, args.config or 2, args.steps, args.warmup, int(os.environ["PHD_BENCH_CPP_MULTI"]),
                             args.preroll_ms)
+        sys.stdout.flush()
+        _flush_c_stdio()                                      # RCCL's banner first, the JSON line last
         print(json.dumps({"metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas", "value": res["value"], "unit": "steps/s",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "preroll_steps": res["preroll_steps"],
                           "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -642,6 +652,12 @@ def main():
                 dist.barrier()
         scaling = "strong"  # total work (one 16384-particle filter) is fixed as N grows
 
+    if multi:
+        # RCCL prints a version banner through C stdio at communicator creation; on a pipe it stays in the C buffer until the
+        # process exits — AFTER Python's own output.  Flush it on every rank now, then print: the JSON line is the last line.
+        sys.stdout.flush()
+        _flush_c_stdio()
+        dist.barrier()
     if rank == 0:
         out = {
             "metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas",
@@ -665,7 +681,7 @@ def main():
             "cpu_baseline": res.get("cpu_baseline"),
             "secondary": secondary,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
 
