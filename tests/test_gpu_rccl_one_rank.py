@@ -99,3 +99,19 @@ def test_collective_paths_on_a_one_rank_rccl_group(tmp_path):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
     r = np.load(os.path.join(str(tmp_path), "ok.npz"))
     assert bool(r["ok"]) and int(r["n_eap"]) > 0
+
+
+def test_bench_multi_rank_path_prints_the_json_line_last():
+    """bench.py's N > 1 path on a one-rank RCCL group: RCCL's version banner (C stdio, flushed at exit on a pipe) must not
+    follow the JSON line — the driver reads the last line of stdout"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PHD_BENCH_ONE_RANK_RCCL="1", PHD_BENCH_EXCHANGE="alltoall", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
+                        "--preroll-ms", "0", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["multi_gpu_exchange"] == "alltoall"
