@@ -299,8 +299,14 @@ def test_driver_sharded_equals_single_device(tmp_path, extra):
     for name, args in (("one", []), ("multi", extra)):
         o = os.path.join(d, name)
         os.makedirs(o)
-        r = subprocess.run([os.path.join(PKG, "bin", "phdslam"), cfg_path, "synth", "--out", o, "--seed", "9", "--capacity", "256"] + args,
-                           capture_output=True, text=True, timeout=300)
+        cmd = [os.path.join(PKG, "bin", "phdslam"), cfg_path, "synth", "--out", o, "--seed", "9", "--capacity", "256"] + args
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=90)
+        except subprocess.TimeoutExpired as e:
+            # seen once in this round (three box visits in a row, never again in 40 repeats, tools/gpu_stress.sh): the one-rank
+            # RCCL run stalled before its first output line.  A stall is retried once; a wrong result never is.
+            print("phdslam timed out after 90 s; output so far:", (e.stdout or b"")[-500:], "- retrying once")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=200)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append((o, r.stdout))
     assert "sharded filter: 48 particles" in outs[1][1]
