@@ -1,0 +1,23 @@
+"""The byte and flop models behind bench.py's roofline entries, pinned to hand-computed values — the
+figures the round-1 review recomputed: 31 662 472 algorithmic bytes per launch at 256 x 64 x 32, 3.19 GFLOP at 4096 x 256 x 64."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_algorithmic_bytes_and_flops_match_the_survey_formulas():
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    bench = importlib.import_module("bench")
+    # per particle: map read 28 G, pose 24, update components written and read back 2 * 28 (G (M + 1) + M), merged map 28 G,
+    # weight 8; + the measurement set once (12 M + 8)
+    def by_hand(N, G, M):
+        return N * (28 * G + 24 + 2 * 28 * (G * (M + 1) + M) + 28 * G + 8) + 12 * M + 8
+    assert by_hand(256, 64, 32) == 31662472
+    for (N, G, M) in ((256, 64, 32), (4096, 256, 64), (16384, 256, 64), (1, 64, 32)):
+        assert S.algorithmic_bytes(N, G, M) == by_hand(N, G, M), (N, G, M)
+    # 150 G + 45 G M + 30 M flops per particle
+    assert bench.algorithmic_flops(4096, 256, 64) == 4096 * (150 * 256 + 45 * 256 * 64 + 30 * 64)
+    assert abs(bench.algorithmic_flops(4096, 256, 64) - 3.185e9) < 1e7
