@@ -55,8 +55,15 @@ def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, 
             assert abs(dlw[p] - ref["dlogw"]) < 2e-3 + 2e-4 * abs(ref["dlogw"]), (p, dlw[p], ref["dlogw"])
             # merge stage bit for bit: the oracle's merge applied to the GPU's own survivors
             out0 = gmap[ref["cls"] == 0]
-            om = O.merge(surv, ocfg)
+            om, mgn = O.merge(surv, ocfg, with_margin=True)
             want = np.concatenate([om, out0]) if len(out0) else om
+            # The Mahalanobis test is +, -, *, / only: the device and the CPU agree on every bit.  The Hellinger distance
+            # (distance_metric = 1) goes through sqrtf and expf, where the device's and glibc's results may differ in the last
+            # place: a merge decision the oracle itself reports within 1e-5 of the threshold (seen: 1.2e-7, one ulp — 1 of
+            # ~27 000 random Hellinger cases, profiles/r02_fuzz.txt) can then fall either way; such a particle is not compared.
+            if ocfg.distanceMetric == 1 and mgn[0] < 1e-5:
+                assert abs(len(maps[p]) - len(want)) <= 2, (p, len(maps[p]), len(want))
+                continue
             assert len(maps[p]) == len(want), (p, len(maps[p]), len(want))
             for fld in ("weight", "mean", "cov"):
                 assert np.array_equal(maps[p][fld].view(np.uint32), want[fld].view(np.uint32)), \
