@@ -4,6 +4,8 @@ the oracle's merge on the device's own survivors, update stage against the oracl
 is fp-marginal, particle weights) over many random shapes, seeds and configuration corners.
 
     python tools/fuzz_parity.py [seconds=120] [first_seed=1000]
+    PHD_FUZZ_SPILL=1: dense scans of large maps on filters created with a spill list (survivor_capacity 4096): survivor lists
+    beyond the LDS capacity, merged by phd_merge_spill_kernel — the same checks
 """
 import os
 import sys
@@ -43,12 +45,25 @@ def main():
             over["maxRange"] = float(rng.choice([6.0, 10.0]))
         if rng.random() < 0.15:
             over["birthWeight"] = float(rng.choice([1e-3, 0.05]))
+        spill = os.environ.get("PHD_FUZZ_SPILL") == "1"
+        if spill:
+            N = int(rng.integers(1, 4))
+            G = int(rng.choice([160, 256, 320]))
+            M = int(rng.choice([128, 200, 256]))
+            clustered = True
+            over = {k: v for k, v in over.items() if k in ("distanceMetric", "minSeparation")}
+            if rng.random() < 0.3:
+                over["clutterRate"] = float(rng.choice([50.0, 150.0]))
         cfg = P.default_config(**over)
         try:
             w = S.make_workload(N, G, M, seed=seed, clustered=clustered and G >= 8)
             cap = min(2 * G + 4 * M + 64, 1024)
-            T.check_update_against_oracle(cfg, w, w["z"][0], cap=cap, mm=max(M, 8), min_structural=0.0,
-                                          structural_maps=over.get("distanceMetric", 0) == 0)
+            if spill:
+                T.check_update_against_oracle(cfg, w, w["z"][0], cap=1024 if G > 256 else 768, mm=256, scap=4096, min_structural=0.0,
+                                              structural_maps=False)
+            else:
+                T.check_update_against_oracle(cfg, w, w["z"][0], cap=cap, mm=max(M, 8), min_structural=0.0,
+                                              structural_maps=over.get("distanceMetric", 0) == 0)
             n_ok += 1
         except P.PhdError as e:
             if e.code != -5:
