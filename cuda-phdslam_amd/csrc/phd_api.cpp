@@ -278,7 +278,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
     if (f->spill_cap) {
         A(dalloc(&f->spill_rec, (size_t)f->n_max * 2 * f->spill_cap * 8));
-        A(dalloc(&f->spill_meta, (size_t)f->n_max * 4));
+        A(dalloc(&f->spill_meta, (size_t)f->n_max * 8));
         A(dalloc(&f->spill_out, (size_t)f->n_max * f->cap));
     }
     if (f->cphd) {

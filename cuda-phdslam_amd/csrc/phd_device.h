@@ -109,7 +109,7 @@ struct UpdateArgs {
     float2* cphd_scratch;       // [n][MM][MM] (mantissa, exponent) rows of the ESF backward sweep
     // spill path (survivor lists longer than S_cap; NULL / 0 when not enabled): see phd_spill.h
     float* spill_rec;           // [n][2][spill_cap][8] survivor records, and the sorted copy phd_merge_spill_kernel works on
-    int* spill_meta;            // [n][4]: survivor count (0: the LDS merge handled the particle), n_update, n_out0, -
+    int* spill_meta;            // [n][8]: survivor count (0: the LDS merge handled the particle), n_update, n_out0, r1, input slab
     unsigned short* spill_out;  // [n][cap] indices of the untouched out-of-range features
     int spill_cap;              // records per particle
     DevConfig cfg;

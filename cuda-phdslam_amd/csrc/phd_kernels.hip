@@ -36,6 +36,9 @@
 //
 // No CUDA compatibility layer, no Thrust/hipCUB, wave64 only.
 
+#include <mutex>
+#include <set>
+
 #include "phd_defs.h"
 #include "phd_lane.h"
 #include "phd_math.h"
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const int n_map = A.count_in[src];
     // survivors past the LDS capacity go to this particle's record list in HBM (when the filter was created with one)
     const SpillRef sp = {SPILL ? A.spill_rec + (size_t)p * 2 * A.spill_cap * 8 : nullptr, SPILL ? A.spill_cap : 0};
-    if (SPILL && tid == 0) A.spill_meta[(size_t)p * 4] = 0;
+    if (SPILL && tid == 0) A.spill_meta[(size_t)p * 8] = 0;
     phd_pose pose = A.pose[p];
     if (A.do_predict) {
         // fused vehicle predict: every lane computes the same pose (no broadcast needed); lane 0 stores it after the
@@ -477,10 +480,13 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         unsigned short* oi = A.spill_out + (size_t)p * cap;
         for (int i = tid; i < n_out0; i += PHD_T) oi[i] = L.out_idx[i];
         if (tid == 0) {
-            int* meta = A.spill_meta + (size_t)p * 4;
+            int* meta = A.spill_meta + (size_t)p * 8;
             meta[1] = n_in * (M + 1) + M;
             meta[2] = n_out0;
             meta[3] = __float_as_int(CPHD ? Q.scal[CQ_R1] : 1.f);
+            // the input slab: the indirection parent[p] is reset to p by this launch (parent_reset aliases parent), so the
+            // spill kernel cannot look it up again after a resample left parent[p] != p
+            meta[4] = src;
             meta[0] = n_all;
         }
     }
@@ -863,6 +869,26 @@ static const void* const k_update_fns[10] = {(const void*)phd_update_merge_kerne
                                              (const void*)phd_update_merge_kernel<false, true, true, true>};
 #define PHD_N_UPDATE_FNS 10
 
+// per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
+// ordinals, no race between host threads that create or drive filters on different devices at the same time.
+struct OncePerDevice {
+    std::mutex mu;
+    std::set<int> done;
+};
+static OncePerDevice g_update_attr, g_weights_attr;
+template <typename F>
+static hipError_t once_per_device(OncePerDevice& o, F&& setup)
+{
+    int dev_id = 0;
+    hipError_t e = hipGetDevice(&dev_id);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (o.done.count(dev_id)) return hipSuccess;
+    e = setup();
+    if (e == hipSuccess) o.done.insert(dev_id);
+    return e;
+}
+
 // the largest static __shared__ footprint among the instantiations of the update kernel (the fused ones carry the
 // weights routine's arrays): what a launch can use dynamically is 160 KiB minus this
 size_t update_static_lds_bytes()
@@ -877,22 +903,21 @@ size_t update_static_lds_bytes()
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st)
 {
-    // function attributes are per device: set once for every device this process launches on
-    static bool attr_set_dev[64] = {};
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    bool& attr_set = attr_set_dev[dev_id & 63];
-    if (!attr_set) {
-        // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
-        const void* const* fns = k_update_fns;
-        for (int k = 0; k < PHD_N_UPDATE_FNS; ++k) {
-            hipFuncAttributes fa;
-            hipError_t e = hipFuncGetAttributes(&fa, fns[k]);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
+    // function attributes are per device: set once for every device this process launches on (thread-safe: filters on
+    // different devices may be driven by different host threads)
+    {
+        const hipError_t e = once_per_device(g_update_attr, [] {
+            // dynamic LDS up to the CU's 160 KiB minus what the instantiation declares statically
+            for (int k = 0; k < PHD_N_UPDATE_FNS; ++k) {
+                hipFuncAttributes fa;
+                hipError_t e = hipFuncGetAttributes(&fa, k_update_fns[k]);
+                if (e != hipSuccess) return e;
+                e = hipFuncSetAttribute(k_update_fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        });
+        if (e != hipSuccess) return e;
     }
     const dim3 g1(n_particles), g2(n_particles + 1), b(PHD_T);   // g2: + the weights workgroup of the fused step
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
@@ -946,17 +971,14 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
     // one workgroup; small particle sets use a small one (cheaper barriers, same results: the
     // reductions are fixed trees per block size)
     // (the commit of the small kernel writes logw[j] for j < n: it needs n_new <= n, true for every caller)
-    static bool attr_set_dev[64] = {};
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    bool& attr_set = attr_set_dev[dev_id & 63];
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)phd_weights_split_kernel<1024, 16, 8>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+    {
+        const hipError_t e = once_per_device(g_weights_attr, [] {
+            hipError_t e = hipFuncSetAttribute((const void*)phd_weights_split_kernel<1024, 16, 8>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (e != hipSuccess) return e;
+            return hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        });
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-        if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const size_t dyn = (size_t)a.n * 8; // the fixed-point CDF, one u64 per particle
     // one table for this launcher and for the fused tail of the update kernel : 256 threads up

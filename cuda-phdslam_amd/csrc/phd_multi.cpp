@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -322,9 +323,12 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
         std::vector<ncclComm_t> comms(world);
         for (int k = 0; k < world; ++k) devs[k] = m->sh[k].device;
         // one process, one node: the bootstrap needs no routable interface (a box without one may stall RCCL's interface
-        // search); the caller's own setting wins
-        setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+        // search).  The caller's own setting wins; ours is scoped to this call — the process environment is restored, so a
+        // multi-node communicator the host creates later does not inherit a loopback-only bootstrap
+        const bool had_if = getenv("NCCL_SOCKET_IFNAME") != nullptr;
+        if (!had_if) setenv("NCCL_SOCKET_IFNAME", "lo", 1);
         ncclResult_t r = ncclCommInitAll(comms.data(), world, devs.data());
+        if (!had_if) unsetenv("NCCL_SOCKET_IFNAME");
         if (r != ncclSuccess) rc = fail(PHD_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
         else for (int k = 0; k < world; ++k) m->sh[k].comm = comms[k];
     }

@@ -19,7 +19,7 @@ namespace phd {
 #define PHD_SPILL_TILE 2048
 
 template <bool HELLINGER>
-__device__ __forceinline__ void merge_spill_body(const UpdateArgs& A, int p, int S, int n_update, int n_out0, float r_out_scale)
+__device__ __forceinline__ void merge_spill_body(const UpdateArgs& A, int p, int S, int n_update, int n_out0, float r_out_scale, int src)
 {
     __shared__ u64 s_keys[PHD_SPILL_TILE];
     __shared__ float s_seed[8];
@@ -33,7 +33,7 @@ __device__ __forceinline__ void merge_spill_body(const UpdateArgs& A, int p, int
     int* assign = (int*)rec;                                           // reused once the sorted copy exists: one int per survivor
     const unsigned rows_stride = A.fuse_weights ? 0u : A.out_stride;
     float* out = A.map_out + (size_t)p * (rows_stride ? rows_stride : (size_t)6 * cap);
-    const int src = A.parent[p];
+    // src: the slab the update kernel read (handed over in spill_meta: parent[p] has been reset to p by then)
     const float* in = A.map_in + (size_t)src * 6 * cap;
 
     // ---- rank by counting: rank_i = number of keys that sort before key_i (keys are unique) ----
@@ -163,12 +163,12 @@ __device__ __forceinline__ void merge_spill_body(const UpdateArgs& A, int p, int
 __global__ __launch_bounds__(PHD_T) void phd_merge_spill_kernel(UpdateArgs A)
 {
     const int p = blockIdx.x;
-    const int* meta = A.spill_meta + (size_t)p * 4;
+    const int* meta = A.spill_meta + (size_t)p * 8;
     const int S = meta[0];
     if (S <= 0) return;                                                 // the LDS merge handled this particle
     const float r_scale = __int_as_float(meta[3]);                      // CPHD: the missed-detection factor of untouched features
-    if (A.cfg.distanceMetric == 0) merge_spill_body<false>(A, p, S, meta[1], meta[2], r_scale);
-    else merge_spill_body<true>(A, p, S, meta[1], meta[2], r_scale);
+    if (A.cfg.distanceMetric == 0) merge_spill_body<false>(A, p, S, meta[1], meta[2], r_scale, meta[4]);
+    else merge_spill_body<true>(A, p, S, meta[1], meta[2], r_scale, meta[4]);
 }
 
 } // namespace phd

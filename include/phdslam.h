@@ -257,7 +257,9 @@ int phd_debug_gm_rounds(phd_filter* f);
  * ---------------------------------------------------------------------------------- */
 int phd_predict_ackerman_dev(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* d_noise);
 int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_meas);
-/* device pointer to this shard's normalised log-weights (n_particles floats) */
+/* device pointer to this shard's normalised log-weights (n_particles floats).  Valid only until the next hot-path call on
+ * this handle: the weights routine writes out of place above 1024 particles and the library swaps its two buffers, so a
+ * cached pointer may name the stale one — ask again after every step. */
 int phd_logweights_dev(phd_filter* f, float** d_logw_out);
 /* device pointer to the un-normalised log-weights after the update of the last phd_update
  * (before logSumExp); used for the multi-GPU all-gather */

@@ -750,3 +750,53 @@ def test_spill_path_in_the_fused_step_and_mixed_particle_sets():
         assert np.array_equal(pa, pb) and np.array_equal(la, lb)
         for x, y in zip(a.get_maps(), b.get_maps()):
             assert np.array_equal(x, y)
+
+
+def test_spill_path_reads_the_parent_slab_after_a_resample():
+    """after a committed resample the map indirection is lazy (parent[p] != p); the update kernel resets it
+    while it runs, so phd_merge_spill_kernel must take the input slab from the hand-over record, not from parent[p] — or the
+    untouched out-of-range features of a spilled particle come from a stale slab.  Every particle carries its own out-of-range
+    features here; a resample with non-identity indices, then a dense (spilling) update through the staged calls and through the
+    single-launch step, against a filter that was handed the resampled maps directly (identity indirection)."""
+    P, S = pkg(), synthetic()
+    N, G, M, n_far = 6, 256, 256, 8
+    w = S.make_workload(N, G, M, seed=811, clustered=True)
+    maps = np.zeros((N, G + n_far), w["maps"].dtype)
+    maps[:, :G] = w["maps"]
+    for p in range(N):
+        for k in range(n_far):                           # range > 1.2 max_range: class 0, appended untouched after the merge
+            maps[p, G + k]["mean"] = (30.0 + p, 4.0 * k - 10.0)
+            maps[p, G + k]["cov"] = (0.1 + 0.01 * p, 0.0, 0.0, 0.2)
+            maps[p, G + k]["weight"] = 0.3 + 0.05 * p + 0.01 * k
+    w["maps"], w["sizes"] = maps, np.full(N, G + n_far, np.int32)
+    lw = np.log(np.array([0.02, 0.4, 0.03, 0.05, 0.45, 0.05], np.float32))
+    w["logw"] = lw - np.float32(np.log(np.exp(lw.astype(np.float64)).sum()))
+    cfg = P.default_config()
+    import torch
+    dev = torch.device("cuda:0")
+    dz = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    dn = torch.from_numpy(w["noise"][0].copy()).to(dev)
+    torch.cuda.synchronize()
+    for fused in (False, True):
+        with make_filter(cfg, w, cap=768, mm=256, scap=4096) as a:
+            idx = a.resample(0.37)
+            assert not np.array_equal(idx, np.arange(N)), idx
+            pa0, la0 = a.get_particles()
+            w2 = dict(w, poses=pa0, logw=la0, maps=maps[idx])
+            with make_filter(cfg, w2, cap=768, mm=256, scap=4096) as c:
+                for f in (a, c):
+                    if fused:
+                        f.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, 0.3, force_resample=True)
+                        f.sync()
+                    else:
+                        f.update(w["z"][0])
+                sa, sc = a.status(), c.status()
+                assert sa["status"] == 0 and sa["max_survivors"] > 2048 and sa == sc
+                ma, mc = a.get_maps(), c.get_maps()
+                for p in range(N):
+                    assert np.array_equal(ma[p], mc[p]), (fused, p)
+                    # the untouched features are the PARENT's
+                    far = ma[p][ma[p]["mean"][:, 0] > 25.0]
+                    assert len(far) == n_far
+                    if not fused:
+                        assert np.all(far["mean"][:, 0] == np.float32(30.0 + idx[p])), (p, idx[p], far["mean"][:, 0])
