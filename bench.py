@@ -64,59 +64,78 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo (0 if it does not say)"""
+    seen, phys = set(), None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return len(seen)
+
+
 def cpu_baseline(w, cfg_id, budget_s):
-    """the CPU oracle (a port of the reference algorithm: kind "port") on the host cores: single thread and the best
-    thread count of 1..visible"""
+    """the CPU oracle (a port of the reference algorithm: kind "port") on the host cores, SURVEY.md §8d: the FULL particle
+    set of the configuration (no slice, no n/N scaling), compiled -O3 -march=native on THIS host (oracle.build_native),
+    single thread and the fastest thread count of a scan that includes the physical core count."""
     from oracle import oracle as O
     N, G, M = w["N"], w["G"], w["M"]
     cap = 2 * G
-    ocfg = O.default_config()
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # bound the sample: the full particle set at config 2, a slice of it at the big configs
-    n = N if N <= 512 else 256
-    maps = np.zeros((n, cap), O.GAUSSIAN)
-    maps[:, :G] = w["maps"][:n]
-    lw = O.normalize_weights(w["logw"][:n])
+    lib_path, build_info = O.build_native()
+    O.use_library(lib_path)
+    try:
+        ocfg = O.default_config()
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        phys = physical_cores()
+        maps = np.zeros((N, cap), O.GAUSSIAN)
+        maps[:, :G] = w["maps"]
+        lw = O.normalize_weights(w["logw"])
+        cn0 = np.full((N, 256), -np.log(256.0), np.float32) if cfg_id == 5 else None   # config 5: uniform rows (src/main.cpp:1142)
+        one = O.make_stepper(w["poses"], lw, maps, w["sizes"], cap, 0.05, 2.0, w["noise"][0], w["z"][0], ocfg, w["uniform"][0],
+                             True, clutter_rate=20.0, cn=cn0)
 
-    cn0 = np.full((n, 256), -np.log(256.0), np.float32)      # config 5: uniform cardinality rows (src/main.cpp:1142)
+        def timed(threads, k):
+            t0 = time.perf_counter()
+            for _ in range(k):
+                one(threads)
+            return (time.perf_counter() - t0) / k
 
-    def one(threads):
-        if cfg_id == 5:
-            return O.cphd_step(w["poses"][:n], lw, maps, w["sizes"][:n], cap, 0.05, 2.0, w["noise"][0][:n], w["z"][0], ocfg,
-                               20.0, cn0, w["uniform"][0], True, n_threads=threads)
-        return O.step(w["poses"][:n], lw, maps, w["sizes"][:n], cap, 0.05, 2.0, w["noise"][0][:n], w["z"][0], ocfg,
-                      w["uniform"][0], True, n_threads=threads)
-
-    def rate(threads, min_s, min_k):
-        one(threads)
-        t0 = time.perf_counter()
-        k = 0
-        while True:
-            one(threads)
-            k += 1
-            el = time.perf_counter() - t0
-            if k >= min_k and el >= min_s:
-                return k / el * (n / N), k, el   # a slice of n particles is n/N of a step
-
-    t_start = time.perf_counter()
-    single, k1, el1 = rate(1, 0.15 * budget_s, 1)
-    # the visible core count can exceed what the container may actually use (CPU quota): pick the
-    # thread count that is fastest on this host and report THAT as `cores`
-    best_t, best_rate = 1, single
-    t = 2
-    while t <= avail:
-        r, _, _ = rate(t, 0.0, 1)
-        if r > best_rate:
-            best_t, best_rate = t, r
-        t *= 2
-    left = max(0.2 * budget_s, budget_s - (time.perf_counter() - t_start))
-    best, kb, elb = rate(best_t, left, 3) if best_t > 1 else (single, k1, el1)
+        t_start = time.perf_counter()
+        # thread scan: powers of two, the physical core count, everything visible — one full step each (the first call at
+        # the widest count also warms the pages of every buffer)
+        cand = sorted({t for t in [2 ** k for k in range(1, 12)] + [phys, avail, avail // 2] if 1 < t <= avail})
+        one(avail)
+        scan = {}
+        for t in reversed(cand):                       # widest first: the slow narrow counts are dropped when time runs out
+            if time.perf_counter() - t_start > 0.35 * budget_s and scan:
+                break
+            scan[t] = timed(t, 1)
+        best_t = min(scan, key=scan.get) if scan else 1
+        # >= 5 timed full steps at the best thread count
+        kb = 5
+        sb = timed(best_t, kb) if best_t > 1 else None
+        # >= 2 timed full steps on one thread
+        k1 = 2
+        s1 = timed(1, k1)
+        if sb is None:
+            sb, kb = s1, k1
+        best, single = 1.0 / sb, 1.0 / s1
+        total = time.perf_counter() - t_start
+    finally:
+        O.use_library(None)
     return {"value": best, "unit": "steps/s", "cores": best_t, "kind": "port",
-            "cpu_model": cpu_model(), "cores_visible": avail,
+            "cpu_model": cpu_model(), "cores_visible": avail, "cores_physical": phys,
             "single_thread_steps_per_s": single, "best_thread_steps_per_s": best,
-            "sample": "%d steps of the oracle (oracle/scphd_cpu.c + cphd_cpu.c, -O3 -march=native, OpenMP over particles, %d threads "
-                      "— the fastest of 1..%d visible; single thread: %d steps in %.1f s) on %d of the %d particles of config %d "
-                      "(%dx%dx%d), %.1f s" % (kb, best_t, avail, k1, el1, n, N, cfg_id, N, G, M, elb)}
+            "thread_scan_s_per_step": {str(t): scan[t] for t in sorted(scan)},
+            "particles_timed": N, "extrapolated": False, **build_info,
+            "sample": "%d full steps (all %d particles, no scaling) of the oracle (oracle/scphd_cpu.c + cphd_cpu.c, %s, compiled on this "
+                      "host; OpenMP over particles) at %d threads — the fastest of the scan %s (visible %d, physical %d) — and %d full "
+                      "steps on one thread; config %d (%dx%dx%d), %.1f s in all"
+                      % (kb, N, build_info["compile_flags"], best_t, sorted(scan), avail, phys, k1, cfg_id, N, G, M, total)}
 
 
 def algorithmic_flops(N, G, M):
@@ -124,8 +143,10 @@ def algorithmic_flops(N, G, M):
     return N * (150.0 * G + 45.0 * G * M + 30.0 * M)
 
 
-def load_profile_json(name):
-    """a PMC summary kept under profiles/ (tools/pmc_*.sh wrote it on the GPU box): (dict, source label) or (None, None)"""
+def load_profile_json(name, build_id):
+    """a PMC summary kept under profiles/ (tools/pmc_*.sh wrote it on the GPU box): (dict, source label) — or (None, why) when
+    there is none or when it was recorded with ANOTHER build of the library than the one loaded now (the summaries carry the
+    library's build id, phd_version(); counters of a kernel that has changed since are not printed)"""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, None
@@ -133,7 +154,10 @@ def load_profile_json(name):
         d = json.load(open(path))
     except Exception:
         return None, None
-    label = "profiles/%s (build %s, recorded %s)" % (name, d.get("build", "?"), d.get("date", "?"))
+    if d.get("build_id") != build_id:
+        return None, "profiles/%s is stale: recorded with build %s (%s), the loaded library is build %s — counters withheld" % (
+            name, d.get("build_id", "?"), d.get("build", "?"), build_id)
+    label = "profiles/%s (build %s = %s, recorded %s)" % (name, d.get("build", "?"), d.get("build_id"), d.get("date", "?"))
     return d, label
 
 
@@ -205,28 +229,34 @@ def roofline_entries(P, S, cfg_id, N, G, M, ker_ms, pair_ms, gpu_ms_per_step, co
         b_min += N * 2 * 4 * 256
     ker_s = ker_ms * 1e-3
     achieved = b_step / ker_s / 1e9 if ker_s > 0 else 0.0
+    build_id = P._lib.lib().phd_version().decode().split("build ")[-1]
     # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh writes the summary on
-    # the GPU box; rocprofv3 cannot run inside the bench) — null if this configuration was not profiled.
-    # NOT measured in this run: the source file, build tag and date are printed beside it.
+    # the GPU box; rocprofv3 cannot run inside the bench) — null if this configuration was not profiled WITH THIS BUILD.
+    # NOT measured in this run: the source file, build id and date are printed beside it.
     traffic, traffic_src = None, None
     if with_traffic:
-        tj, traffic_src = load_profile_json("pmc_traffic_cfg%d.json" % cfg_id)
+        tj, traffic_src = load_profile_json("pmc_traffic_cfg%d.json" % cfg_id, build_id)
         if tj:
             traffic = tj.get("hbm_bytes_per_launch")
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "note": "contract figure (SURVEY.md 8d): ALGORITHMIC bytes / kernel time.  The fused kernel prunes before it "
-                    "stores, so the update components never reach HBM; the kernel is VALU-issue-bound, see roofline_valu",
+    roof = {"bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_compulsory": (b_min / ker_s / 1e9 / HBM_PEAK_GBS) if ker_s > 0 else None,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "note": "`frac` is the contract figure of SURVEY.md 8d: ALGORITHMIC bytes (every update component written once and read "
+                    "once) / kernel time / 8 TB/s.  The fused kernel prunes before it stores, so those components never reach HBM "
+                    "and `frac` may exceed 1: it carries no efficiency information.  `frac_compulsory` = compulsory bytes (map in + "
+                    "map out + 32 B per particle) / kernel time / 8 TB/s is what the HBM interface must carry; the kernel is bound "
+                    "by VALU issue, see roofline_valu",
             "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
             "kernel_avg_us_event_pairs": 1e3 * pair_ms, "gpu_region_ms_per_step": gpu_ms_per_step,
             "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
             "measured_hbm_gbs": (traffic / ker_s / 1e9) if (traffic and ker_s > 0) else None,
             "device_copy_ceiling_gbs": copy_gbs,
             "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-            "other_kernels_avg_us": other}
+            "other_kernels_avg_us": other, "library_build": build_id}
     flops = algorithmic_flops(N, G, M)
     tfl = flops / ker_s / 1e12 if ker_s > 0 else 0.0
-    sq, sq_src = load_profile_json("pmc_sq_cfg%d.json" % cfg_id)
+    sq, sq_src = load_profile_json("pmc_sq_cfg%d.json" % cfg_id, build_id)
     valu = {"bound": "valu-issue", "achieved": None, "peak": 1.0, "unit": "fraction of VALU issue cycles", "frac": None,
             "source": sq_src, "algorithmic_flops_per_launch": flops, "algorithmic_tflops": tfl,
             "frac_of_fp32_vector_peak": tfl / FP32_VECTOR_PEAK_TFLOPS,
@@ -499,17 +529,21 @@ def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, loca
     return res
 
 
-def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, n_shards, preroll_ms):
-    """the N > 1 step driven by the C++ multi-device host (libphdslam_multi.so, include/phdslam_multi.h) inside THIS process:
-    n_shards = 1 is a one-rank RCCL communicator (what the collective path costs before any link is involved); more shards
-    on this one GPU exchange by device copies (a dry run of the sharding logic, not a measurement of links)"""
+def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_phases=True):
+    """ONE filter sharded over len(devices) shards, driven by the C++ multi-device host (libphdslam_multi.so,
+    include/phdslam_multi.h) inside THIS process: one host thread, one HIP stream per shard, RCCL (ncclCommInitAll) when every
+    shard has a device of its own.  Shards that share a device (more shards than GPUs: PHD_BENCH_SHARE_GPU=1 on a one-GPU box)
+    exchange by device copies — a dry run of the sharding logic, not a measurement of links.  One shard on one device is a
+    one-rank RCCL communicator (what the collective path costs before any link is involved)."""
     MM = importlib.import_module("cuda-phdslam_amd.multi")
+    L = P._lib
     c = S.CONFIGS[cfg_id]
     N, G, M = c["N"], c["G"], c["M"]
+    n_shards = len(devices)
     w = S.make_workload(N, G, M, seed=0x5EED0000 + cfg_id, clustered=c["clustered"])
     cfg = P.default_config(n_particles=N)
     ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "gathered": MM.EXCHANGE_GATHERED}.get(os.environ.get("PHD_BENCH_EXCHANGE", ""), MM.EXCHANGE_AUTO)
-    m = MM.MultiFilter(cfg, n_shards=n_shards, devices=[0] * n_shards, map_capacity=2 * G, max_measurements=M, exchange=ex)
+    m = MM.MultiFilter(cfg, n_shards=n_shards, devices=list(devices), map_capacity=2 * G, max_measurements=M, exchange=ex)
     m.set_particles(w["poses"], w["logw"])
     m.set_maps(w["maps"], w["sizes"])
     m.set_frozen(True)
@@ -521,17 +555,63 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, n_shards, preroll_ms):
         m.step_resident(control, u, force_resample=True)
 
     def sync():
-        m.sync()
+        m.sync()                                              # every shard's stream drained
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
 
     ts = torch.cuda.current_stream()
     # (the shards run on their own streams: the event-based percentiles of timed_loop do not see them; wall clock only)
     elapsed, _, _, preroll = timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms)
+
+    # per-shard kernel time (HIP events on shard 0's stream around its launches) and the per-phase breakdown (HIP events on
+    # shard 0's stream at the phase boundaries, all shards drained after every step): separate passes
+    k_ev = min(steps, 50)
+    h0 = m.shard_handle(0)
+    L.check(L.lib().phd_timing_reset(h0), "phd_timing_reset")
+    L.check(L.lib().phd_timing_enable(h0, 1), "phd_timing_enable")
+    for _ in range(k_ev):
+        step()
+    sync()
+    ms = np.zeros(L.K_COUNT, np.float64)
+    cnt = np.zeros(L.K_COUNT, np.int64)
+    L.check(L.lib().phd_timing_read(h0, L.ptr(ms), L.ptr(cnt)), "phd_timing_read")
+    L.check(L.lib().phd_timing_enable(h0, 0), "phd_timing_enable")
+    avg_ms = ms / np.maximum(cnt, 1)
+    phases = None
+    if with_phases:
+        m.timing_reset()
+        m.timing(True)
+        for _ in range(min(steps, 30)):
+            step()
+        sync()
+        phases, k_ph = m.timing_read()
+        m.timing(False)
+        phases["resample_with_migration"] = phases["weights"] + phases["plan_export"] + phases["send_recv"] + phases["import"]
+        phases["steps_averaged"] = k_ph
+        phases["note"] = ("HIP events on shard 0's stream at the phase boundaries; every step of this pass ends with all shards "
+                          "drained, so the parts add up to more than a pipelined step")
+    n = N // n_shards
+    pair_ms = avg_ms[L.K_UPDATE_MERGE]
+    other = {"phd_predict_kernel": 1e3 * avg_ms[L.K_PREDICT], "phd_weights_kernel": 1e3 * avg_ms[L.K_WEIGHTS]}
+    roof, valu = roofline_entries(P, S, cfg_id, n, G, M, pair_ms, pair_ms, 1e3 * elapsed / steps, None, other, with_traffic=False)
+    distinct = len(set(devices)) == n_shards
     res = {"value": steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "preroll_steps": preroll,
-           "config": {"workload": "C++ multi-device host (libphdslam_multi.so): config %d (%d x %d x %d) as ONE filter over %d shard(s) on "
-                                  "this GPU, transport %s, exchange %s, forced resample, frozen snapshot" %
-                                  (cfg_id, N, G, M, n_shards, "RCCL (one-rank communicator)" if m.uses_rccl else "device copies",
+           "ms_per_step_gpu_p10_p50_p90": None,
+           "config": {"workload": "BASELINE.json configs[%d]: ONE filter of %d particles x %d Gaussians/particle x %d meas/step sharded over "
+                                  "%d shard(s) (shard k owns particles [k n, (k+1) n), n = %d), C++ multi-device host "
+                                  "(libphdslam_multi.so, one process, one host thread), transport %s, exchange %s, log-weight "
+                                  "all-gather + global systematic resample + migration every step, frozen snapshot" %
+                                  (cfg_id - 1, N, G, M, n_shards, n,
+                                   ("RCCL (ncclCommInitAll over %d device(s))" % n_shards) if m.uses_rccl else "device copies (shards share a GPU)",
                                    "gathered" if m.gathered else "alltoall"),
-                      "cpp_multi_host": True, "n_shards": n_shards, "rccl": m.uses_rccl}}
+                      "particles_total": N, "particles_per_shard": n, "gaussians_per_particle": G, "measurements_per_step": M,
+                      "host": "C++ (libphdslam_multi.so)", "cpp_multi_host": True, "n_shards": n_shards, "devices": list(devices),
+                      "rccl": m.uses_rccl, "rccl_ranks": n_shards if m.uses_rccl else 0,
+                      "value_counts": "filter steps per second (K / wall time with every shard drained)",
+                      "multi_gpu_exchange": "gathered" if m.gathered else "alltoall",
+                      "multi_gpu_phase_us_shard0": phases,
+                      **({} if distinct else {"share_gpu_dry_run": True})},
+           "roofline": roof, "roofline_valu": valu}
     m.close()
     return res
 
@@ -553,7 +633,8 @@ def main():
     ap.add_argument("--config", type=int, default=0,
                     help="headline workload: 0 = the default (3 at N = 1: BASELINE.json configs[2]; 4 at N > 1: configs[3] sharded); "
                          "2, 3, 5 (configs[1], [2], [4] = CPHD) at N = 1")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the headline's cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0,
+                    help="soft budget of the headline's cpu_baseline leg: bounds the thread scan; the 5 + 2 full timed steps always run (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
     ap.add_argument("--preroll-ms", type=float, default=PREROLL_MS)
     ap.add_argument("--bare", action="store_true",
@@ -569,12 +650,37 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    # PHD_BENCH_SHARE_GPU=1: dry run of the N > 1 path on a one-GPU box (every rank on device 0, gloo transport
-    # staged through host memory) — exercises this file's multi-rank code, its numbers are not a measurement
+    # PHD_BENCH_SHARE_GPU=1: dry run of the N > 1 path on a one-GPU box (every shard / rank on device 0; device-copy or gloo
+    # transport) — exercises the multi-shard code, its numbers are not a measurement
     share = os.environ.get("PHD_BENCH_SHARE_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: ONE process drives all N GPUs through the C++ multi-device host (libphdslam_multi.so: ncclCommInitAll
+        # over devices 0..N-1, one HIP stream per shard, one host thread) — BASELINE.json configs[3], strong scaling
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not share:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (PHD_BENCH_SHARE_GPU=1 runs the shards on one GPU as a dry run)"
+                             % (args.gpus, ndev))
+        devices = [0] * args.gpus if share else list(range(args.gpus))
+        torch.cuda.set_device(0)
+        cfg_id = args.config or 4
+        res = run_cpp_multi(P, S, torch, cfg_id, args.steps, args.warmup, devices, args.preroll_ms)
+        secondary = []
+        if not args.no_secondary and not args.bare:
+            # the N = 1 point of this strong-scaling line, measured in the same run: the same filter on ONE GPU
+            k1 = min(args.steps, 50)
+            r1 = run_single(P, S, torch, cfg_id, k1, max(min(args.warmup, 20), 5), 0.0, torch.device("cuda", 0), 0, args.preroll_ms,
+                            extras=False)
+            r1["steps"] = k1
+            r1["note"] = "the same workload on ONE GPU (single-device step), measured in this run: the N = 1 point of this strong-scaling line"
+            secondary.append(r1)
+        sys.stdout.flush()
+        _flush_c_stdio()                                      # RCCL's banner first, the JSON line last
+        print(json.dumps({"metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas", "value": res["value"], "unit": "steps/s",
+                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "preroll_steps": res["preroll_steps"],
+                          "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic", "config": res["config"], "roofline": res["roofline"],
+                          "roofline_valu": res["roofline_valu"], "cpu_baseline": None, "secondary": secondary}), flush=True)
+        return
     if share:
         local_rank = 0
     # PHD_BENCH_ONE_RANK_RCCL=1 (with --gpus 1): the N > 1 step — local step, RCCL all-gather, global resample, RCCL
@@ -596,16 +702,18 @@ def main():
 
     secondary = []
     if os.environ.get("PHD_BENCH_CPP_MULTI") and world == 1:
-        # diagnostic: the multi-device step through the C++ host in this process (labelled in config; not the N = 1 headline)
+        # diagnostic: the multi-device step through the C++ host in this process, PHD_BENCH_CPP_MULTI shards on THIS GPU
+        # (1 = a one-rank RCCL communicator); labelled in config, not the N = 1 headline
         torch.cuda.set_device(0)
-        res = run_cpp_multi(P, S, torch, args.config or 2, args.steps, args.warmup, int(os.environ["PHD_BENCH_CPP_MULTI"]),
+        res = run_cpp_multi(P, S, torch, args.config or 2, args.steps, args.warmup, [0] * int(os.environ["PHD_BENCH_CPP_MULTI"]),
                             args.preroll_ms)
         sys.stdout.flush()
         _flush_c_stdio()                                      # RCCL's banner first, the JSON line last
         print(json.dumps({"metric": "PHD-update steps/sec at N_particles x N_gauss x N_meas", "value": res["value"], "unit": "steps/s",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "preroll_steps": res["preroll_steps"],
                           "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic", "config": res["config"], "roofline": None, "cpu_baseline": None}))
+                          "dtype": "f32", "data": "synthetic", "config": res["config"], "roofline": res["roofline"],
+                          "cpu_baseline": None}))
         return
     if not multi:
         cfg_id = args.config or 3

@@ -37,7 +37,6 @@ static_assert(offsetof(phd_slam_config, saveAllMaps) == 320, "SlamConfig.saveAll
 static thread_local std::string g_err;
 
 extern "C" const char* phd_last_error(void) { return g_err.c_str(); }
-extern "C" const char* phd_version(void) { return "cuda-phdslam_amd 0.1 (gfx950)"; }
 
 static int fail(int code, const std::string& msg)
 {

@@ -73,9 +73,45 @@ struct phd_multi {
     int32_t* h_idx = nullptr;           // pinned: the global resample indices (downloaded once per step from shard 0)
     int n_meas = 0;                     // of the resident inputs
     bool have_noise = false;
+    // per-phase timing (phd_multi_timing_*): HIP events on shard 0's stream at the phase boundaries of a step
+    bool timing = false;
+    hipEvent_t tev[PHD_MULTI_PHASES + 1] = {};
+    int tmark = 0;                      // events recorded in the step in flight
+    int tphase[PHD_MULTI_PHASES + 1] = {};
+    double t_us[PHD_MULTI_PHASES] = {};
+    int64_t t_steps = 0;
 };
 
 namespace {
+
+// phase marks (timing pass only): an event on shard 0's stream; phase = what the span ENDING at this mark was
+int t_mark(phd_multi* m, int phase)
+{
+    if (!m->timing || m->tmark > PHD_MULTI_PHASES) return PHD_OK;
+    Shard& s = m->sh[0];
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipEventRecord(m->tev[m->tmark], s.stream));
+    m->tphase[m->tmark] = phase;
+    m->tmark += 1;
+    return PHD_OK;
+}
+// end of a step: all shards drained, spans accumulated (the timing pass synchronises every step; the timed loop does not run it)
+int t_finish(phd_multi* m)
+{
+    if (!m->timing) return PHD_OK;
+    for (auto& s : m->sh) {
+        HIPCHK(hipSetDevice(s.device));
+        HIPCHK(hipStreamSynchronize(s.stream));
+    }
+    for (int k = 1; k < m->tmark; ++k) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, m->tev[k - 1], m->tev[k]));
+        m->t_us[m->tphase[k]] += 1e3 * (double)ms;
+    }
+    if (m->tmark > 1) m->t_steps += 1;
+    m->tmark = 0;
+    return PHD_OK;
+}
 
 // stream-ordered hand-off for the peer-copy transport: every consumer stream waits for every producer's `ready`
 int peer_publish(phd_multi* m)
@@ -206,9 +242,12 @@ int resample_stage(phd_multi* m, double uniform, bool from_raw)
             src[k] = rows;
             dst[k] = m->sh[k].allrows;
         }
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
         PHDCHK(all_gather(m, src, dst, (size_t)m->n * m->pack));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_ALL_GATHER));
         for (int k = 0; k < W; ++k)
             PHDCHK(phd_global_resample_gathered(m->sh[k].f, m->sh[k].allrows, uniform, W, k, 0, nullptr));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_IMPORT));
         return PHD_OK;
     }
     // indices on every shard (identical), downloaded ONCE; every shard plans from the same host copy
@@ -218,14 +257,18 @@ int resample_stage(phd_multi* m, double uniform, bool from_raw)
         PHDCHK(phd_global_resample_launch(m->sh[k].f, from_raw ? m->sh[k].allw : nullptr, uniform, &d_idx));
         if (k == 0) d_idx0 = d_idx;
     }
+    PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
     HIPCHK(hipSetDevice(m->sh[0].device));
     HIPCHK(hipMemcpyAsync(m->h_idx, d_idx0, (size_t)m->N * sizeof(int32_t), hipMemcpyDeviceToHost, m->sh[0].stream));
     HIPCHK(hipStreamSynchronize(m->sh[0].stream));
     PHDCHK(peer_wait_consumed(m));
     for (int k = 0; k < W; ++k)
         PHDCHK(phd_global_resample_plan(m->sh[k].f, m->h_idx, W, k, m->sh[k].sc.data(), m->sh[k].rc.data(), &m->sh[k].send_buf));
+    PHDCHK(t_mark(m, PHD_MULTI_PHASE_PLAN_EXPORT));
     PHDCHK(all_to_all(m));
+    PHDCHK(t_mark(m, PHD_MULTI_PHASE_SEND_RECV));
     for (int k = 0; k < W; ++k) PHDCHK(phd_global_resample_end(m->sh[k].f, m->sh[k].recv));
+    PHDCHK(t_mark(m, PHD_MULTI_PHASE_IMPORT));
     return PHD_OK;
 }
 
@@ -243,7 +286,9 @@ int update_stage(phd_multi* m, const phd_ackerman_control* u)
         src[k] = raw;
         dst[k] = m->sh[k].allw;
     }
-    return all_gather(m, src, dst, (size_t)m->n * sizeof(float));
+    PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
+    PHDCHK(all_gather(m, src, dst, (size_t)m->n * sizeof(float)));
+    return t_mark(m, PHD_MULTI_PHASE_ALL_GATHER);
 }
 
 } // namespace
@@ -355,6 +400,7 @@ extern "C" int phd_multi_destroy(phd_multi* m)
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (m->h_idx) (void)hipHostFree(m->h_idx);
+    for (auto& e : m->tev) if (e) (void)hipEventDestroy(e);
     delete m;
     return PHD_OK;
 }
@@ -473,16 +519,16 @@ extern "C" int phd_multi_upload_inputs(phd_multi* m, const phd_ackerman_noise* n
     return PHD_OK;
 }
 
-extern "C" int phd_multi_step_resident(phd_multi* m, phd_ackerman_control u, double uniform, int force_resample,
-                                       int32_t* did_resample_out)
+// the step proper (phd_multi_step_resident wraps it with the phase-timing bookkeeping)
+static int step_resident_body(phd_multi* m, phd_ackerman_control u, double uniform, int force_resample, int32_t* did_resample_out)
 {
-    CHECK_M(m);
     const int W = m->world, M = m->n_meas;
     if (did_resample_out) *did_resample_out = 0;
     PHDCHK(peer_wait_consumed(m));
+    PHDCHK(t_mark(m, 0));                               // start of the step
     if (M <= 0) {                                       // no scan: predict only (src/main.cpp:1244-1260); no resample (:1286)
         for (auto& s : m->sh) PHDCHK(phd_step_local_dev(s.f, u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
-        return PHD_OK;
+        return t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP);
     }
     if (m->gathered && force_resample) {
         // small shards, forced resample: nothing waits for the host
@@ -495,9 +541,12 @@ extern "C" int phd_multi_step_resident(phd_multi* m, phd_ackerman_control u, dou
             src[k] = rows;
             dst[k] = m->sh[k].allrows;
         }
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
         PHDCHK(all_gather(m, src, dst, (size_t)m->n * m->pack));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_ALL_GATHER));
         for (int k = 0; k < W; ++k)
             PHDCHK(phd_global_resample_gathered(m->sh[k].f, m->sh[k].allrows, uniform, W, k, 1, nullptr));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_IMPORT));
         if (did_resample_out) *did_resample_out = 1;
         return PHD_OK;
     }
@@ -509,11 +558,51 @@ extern "C" int phd_multi_step_resident(phd_multi* m, phd_ackerman_control u, dou
         float neff = 0.f;
         for (int k = W - 1; k >= 0; --k)
             PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->N, k == 0 ? &neff : nullptr));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
         resample = neff <= m->cfg.resampleThresh;                                    // src/main.cpp:1286
         if (!resample) return PHD_OK;
     }
     if (did_resample_out) *did_resample_out = 1;
     return resample_stage(m, uniform, force_resample != 0);
+}
+
+extern "C" int phd_multi_step_resident(phd_multi* m, phd_ackerman_control u, double uniform, int force_resample,
+                                       int32_t* did_resample_out)
+{
+    CHECK_M(m);
+    m->tmark = 0;
+    const int rc = step_resident_body(m, u, uniform, force_resample, did_resample_out);
+    if (rc != PHD_OK) return rc;
+    return t_finish(m);
+}
+
+extern "C" int phd_multi_timing_enable(phd_multi* m, int enable)
+{
+    CHECK_M(m);
+    if (enable && !m->tev[0]) {
+        HIPCHK(hipSetDevice(m->sh[0].device));
+        for (int k = 0; k <= PHD_MULTI_PHASES; ++k) HIPCHK(hipEventCreate(&m->tev[k]));
+    }
+    m->timing = enable != 0;
+    m->tmark = 0;
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_timing_reset(phd_multi* m)
+{
+    CHECK_M(m);
+    for (int k = 0; k < PHD_MULTI_PHASES; ++k) m->t_us[k] = 0.0;
+    m->t_steps = 0;
+    return PHD_OK;
+}
+
+extern "C" int phd_multi_timing_read(phd_multi* m, double* us_total, int64_t* steps_out)
+{
+    CHECK_M(m);
+    if (!us_total || !steps_out) return fail(PHD_ERR_INVALID_ARG, "phd_multi_timing_read: null output");
+    for (int k = 0; k < PHD_MULTI_PHASES; ++k) us_total[k] = m->t_us[k];
+    *steps_out = m->t_steps;
+    return PHD_OK;
 }
 
 extern "C" int phd_multi_step(phd_multi* m, phd_ackerman_control u, const phd_ackerman_noise* noise, const phd_measurement* z,

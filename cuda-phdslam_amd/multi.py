@@ -51,7 +51,11 @@ MULTI_SYMBOLS = {
     "phd_multi_resample": (_i, [_vp, _d]),
     "phd_multi_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "phd_multi_expected_map": (_i, [_vp, _vp, _i, _vp]),
+    "phd_multi_timing_enable": (_i, [_vp, _i]),
+    "phd_multi_timing_reset": (_i, [_vp]),
+    "phd_multi_timing_read": (_i, [_vp, _vp, _vp]),
 }
+PHASES = ("local_step", "all_gather", "weights", "plan_export", "send_recv", "import")
 
 _mlib = None
 
@@ -182,6 +186,23 @@ class MultiFilter:
     def step_resident(self, control, uniform, force_resample=False):
         check(mlib().phd_multi_step_resident(self._h, _ctrl(control), float(uniform), int(force_resample), None),
               "phd_multi_step_resident")
+
+    def shard_handle(self, k):
+        """shard k's phd_filter handle (inspection: per-kernel timing, status)"""
+        return C.c_void_p(mlib().phd_multi_shard(self._h, int(k)))
+
+    def timing(self, enable):
+        check(mlib().phd_multi_timing_enable(self._h, int(enable)), "phd_multi_timing_enable")
+
+    def timing_reset(self):
+        check(mlib().phd_multi_timing_reset(self._h), "phd_multi_timing_reset")
+
+    def timing_read(self):
+        """-> ({phase: mean microseconds per step}, steps)"""
+        us = np.zeros(len(PHASES), np.float64)
+        k = C.c_int64(0)
+        check(mlib().phd_multi_timing_read(self._h, ptr(us), C.byref(k)), "phd_multi_timing_read")
+        return {nm: float(us[i]) / max(k.value, 1) for i, nm in enumerate(PHASES)}, int(k.value)
 
     def state_snapshot(self):
         e = np.zeros(1, POSE)

@@ -99,6 +99,18 @@ int phd_multi_state_snapshot(phd_multi* m, phd_pose* expected_out, phd_gaussian2
  * shard 0, which reduces the global mixture (src/gm_reduce.cpp:57-134) on its device */
 int phd_multi_expected_map(phd_multi* m, phd_gaussian2d* out, int capacity, int32_t* n_out);
 
+/* Where a step's time goes ("report resample-with-migration time separately"): with timing enabled every
+ * phd_multi_step_resident records HIP events on shard 0's stream at its phase boundaries and drains all shards at the end
+ * (a separate pass: the timed loop runs without it).  us_total[PHD_MULTI_PHASES] accumulates microseconds per phase over
+ * *steps_out steps: the local step (predict + update + prune + merge, one launch per shard), the RCCL all-gather, the
+ * replicated weights / index routine, the index download + migration plan + export (the one host round trip of the
+ * all-to-all form), the ncclSend/ncclRecv pairs, and copy_particles (import). */
+enum { PHD_MULTI_PHASE_LOCAL_STEP = 0, PHD_MULTI_PHASE_ALL_GATHER = 1, PHD_MULTI_PHASE_WEIGHTS = 2,
+       PHD_MULTI_PHASE_PLAN_EXPORT = 3, PHD_MULTI_PHASE_SEND_RECV = 4, PHD_MULTI_PHASE_IMPORT = 5, PHD_MULTI_PHASES = 6 };
+int phd_multi_timing_enable(phd_multi* m, int enable);
+int phd_multi_timing_reset(phd_multi* m);
+int phd_multi_timing_read(phd_multi* m, double* us_total /*[PHD_MULTI_PHASES]*/, int64_t* steps_out);
+
 #ifdef __cplusplus
 }
 #endif

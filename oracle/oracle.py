@@ -49,20 +49,82 @@ def default_config(**over):
     return cfg
 
 
+def _sources():
+    return [os.path.join(_HERE, f) for f in ("scphd_cpu.c", "cphd_cpu.c", "scphd_cpu.h", "Makefile")]
+
+
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "scphd_cpu.c")):
+    """the portable checker library (oracle/Makefile: -O3 -march=x86-64-v3 -ffp-contract=off): what the tests load"""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in _sources()):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
+
+
+NATIVE_CFLAGS = "-O3 -march=native -ffp-contract=off -fopenmp -fPIC -std=c11"
+
+
+def host_cpu():
+    """(model name, flags line) of the CPU this process runs on"""
+    model, flags = "unknown", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = line.split(":", 1)[1].strip()
+            if model != "unknown" and flags:
+                break
+    except OSError:
+        pass
+    return model, flags
+
+
+def build_native():
+    """bench.py's cpu_baseline leg: the same sources compiled -O3 -march=native ON THE HOST THAT RUNS THEM.
+    The file name is keyed on the CPU model + feature flags + compiler flags, so a library built on another machine
+    (the snapshot travels) is never picked up.  -> (path, info dict)"""
+    import hashlib
+    import platform
+    model, flags = host_cpu()
+    tag = hashlib.sha1((model + "|" + flags + "|" + NATIVE_CFLAGS).encode()).hexdigest()[:12]
+    d = os.path.join(_HERE, "_host")
+    try:
+        os.makedirs(d, exist_ok=True)
+        if not os.access(d, os.W_OK):
+            raise OSError("read-only")
+    except OSError:                                    # a read-only checkout: build beside the temp files instead
+        import tempfile
+        d = os.path.join(tempfile.gettempdir(), "phd_oracle_host_%d" % os.getuid())
+        os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "libscphd_cpu.native.%s.so" % tag)
+    srcs = [os.path.join(_HERE, "scphd_cpu.c"), os.path.join(_HERE, "cphd_cpu.c")]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in _sources()):
+        tmp = path + ".tmp.%d" % os.getpid()
+        subprocess.check_call(["gcc"] + NATIVE_CFLAGS.split() + ["-shared", "-o", tmp] + srcs + ["-lm"])
+        os.replace(tmp, path)
+    try:
+        cc = subprocess.check_output(["gcc", "--version"], text=True).splitlines()[0]
+    except Exception:
+        cc = "gcc"
+    return path, {"compile_flags": NATIVE_CFLAGS, "compiler": cc, "compiled_on_cpu": model,
+                  "compiled_on_host": platform.node(), "library": os.path.relpath(path, os.path.dirname(_HERE))}
 
 
 _lib = None
 
 
+def use_library(path=None):
+    """load another build of the oracle (bench.py: the host-native one); None: back to the portable checker"""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path or os.path.join(_HERE, "libscphd_cpu.so")
+    _lib = None
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if _LIB_PATH == os.path.join(_HERE, "libscphd_cpu.so"):
+            build()
         L = C.CDLL(_LIB_PATH)
         vp, i32, f32, f64 = C.c_void_p, C.c_int, C.c_float, C.c_double
         cp = C.POINTER(OConfig)
@@ -299,6 +361,34 @@ def step(poses, logw, maps, sizes, cap, alpha, v_encoder, noise, z, cfg, uniform
                       _p(maps_out), _p(sizes_out), _p(idx), _p(ne), int(n_threads))
     return dict(rc=rc, poses=poses, logw=logw, maps=maps_out.reshape(N, cap), sizes=sizes_out, idx=idx,
                 neff=float(ne[0]))
+
+
+def make_stepper(poses, logw, maps, sizes, cap, alpha, v_encoder, noise, z, cfg, uniform, force_resample, clutter_rate=None,
+                 cn=None):
+    """bench.py's cpu_baseline: -> f(n_threads) running ONE whole step (o_step, or o_cphd_step when cn is given) on the same
+    inputs with every buffer allocated and touched beforehand (the timed call is the C routine, not numpy's page faults)"""
+    poses0 = _c(poses, POSE); logw0 = _c(logw, np.float32)
+    maps = _c(maps, GAUSSIAN).reshape(-1); sizes = _c(sizes, np.int32)
+    N = len(poses0)
+    z = _c(z, MEAS)
+    noise = None if noise is None else _c(noise, np.float32)
+    maps_out = np.ones(N * cap, GAUSSIAN); sizes_out = np.zeros(N, np.int32)
+    idx = np.zeros(N, np.int32); ne = np.zeros(1, np.float32)
+    po = poses0.copy(); lw = logw0.copy()
+    if cn is not None:
+        cn = _c(cn, np.float32); cn_out = np.ones_like(cn)
+    L = lib()
+
+    def run(n_threads):
+        po[:] = poses0; lw[:] = logw0              # the step updates poses and weights in place
+        if cn is not None:
+            return L.o_cphd_step(_p(po), _p(lw), _p(maps), _p(sizes), N, cap, float(alpha), float(v_encoder), _p(noise), _p(z),
+                                 len(z), C.byref(cfg), float(clutter_rate), _p(cn), cn.shape[1], float(uniform),
+                                 int(force_resample), _p(maps_out), _p(sizes_out), _p(cn_out), _p(idx), _p(ne), int(n_threads))
+        return L.o_step(_p(po), _p(lw), _p(maps), _p(sizes), N, cap, float(alpha), float(v_encoder), _p(noise), _p(z), len(z),
+                        C.byref(cfg), float(uniform), int(force_resample), _p(maps_out), _p(sizes_out), _p(idx), _p(ne),
+                        int(n_threads))
+    return run
 
 
 def cphd_step(poses, logw, maps, sizes, cap, alpha, v_encoder, noise, z, cfg, clutter_rate, cn, uniform, force_resample,

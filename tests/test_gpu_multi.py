@@ -120,3 +120,38 @@ def test_rejects_what_it_cannot_shard():
         MM.MultiFilter(P.default_config(n_particles=64, nPredictParticles=2), n_shards=2, devices=[0, 0])
     with pytest.raises(P.PhdError):
         MM.MultiFilter(P.default_config(n_particles=64), n_shards=2, devices=[0, 0], transport=MM.TRANSPORT_RCCL)
+
+
+def test_bench_gpus_2_unlaunched_runs_the_cpp_host():
+    """`python3 bench.py --gpus 2` with no launcher: ONE process drives both shards through
+    libphdslam_multi.so.  On this one-GPU box PHD_BENCH_SHARE_GPU=1 puts both shards on device 0 (device-copy transport):
+    a dry run of the path the 2/4/8-GPU scaling record takes, configs[3] (16384 x 256 x 64), strong scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PHD_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--preroll-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "steps/s"
+    c = d["config"]
+    assert c["cpp_multi_host"] and c["n_shards"] == 2 and c["particles_total"] == 16384 and c["share_gpu_dry_run"]
+    ph = c["multi_gpu_phase_us_shard0"]
+    for k in ("local_step", "all_gather", "weights", "plan_export", "send_recv", "import", "resample_with_migration"):
+        assert ph[k] >= 0.0
+    assert ph["local_step"] > 100.0                       # 8192 particles x 256 x 64 on one GPU: hundreds of microseconds
+    assert d["roofline"]["kernel_avg_us"] > 0
+    one = [s for s in d["secondary"] if s["config"]["particles_total"] == 16384]
+    assert len(one) == 1 and one[0]["value"] > 0          # the N = 1 point, measured in the same run
+    # more GPUs than the box has, without the dry-run switch: a clear refusal, not a hang
+    env.pop("PHD_BENCH_SHARE_GPU")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)

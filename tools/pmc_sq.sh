@@ -11,7 +11,9 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
   python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --bare --steps $steps --warmup 5 --preroll-ms 0 > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_cfg${cfg}_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - "$cfg" "$tag" <<'PY'
-import csv, glob, json, sys, collections, datetime
+import csv, ctypes, glob, json, sys, collections, datetime
+_L = ctypes.CDLL('cuda-phdslam_amd/libphdslam.so'); _L.phd_version.restype = ctypes.c_char_p
+BUILD_ID = _L.phd_version().decode().split('build ')[-1]          # bench.py refuses counters of another build
 cfg, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list)
 dur = []
@@ -35,7 +37,7 @@ if m:
     # duration in shader cycles.  VALU issue fraction = cycles some wave of a SIMD spends issuing VALU / SIMD cycles:
     #   4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * SQ_BUSY_CYCLES / 32)
     kcyc = m["SQ_BUSY_CYCLES"] / 32.0
-    out = {"config": int(cfg), "kernel": "phd_update_merge_kernel", "build": tag, "date": datetime.date.today().isoformat(),
+    out = {"config": int(cfg), "kernel": "phd_update_merge_kernel", "build": tag, "build_id": BUILD_ID, "date": datetime.date.today().isoformat(),
            "dispatches_averaged": n, "kernel_avg_us": (sum(dur) / len(dur)) if dur else None,
            "kernel_shader_cycles": kcyc,
            "valu_issue_fraction": 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * kcyc),

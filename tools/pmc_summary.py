@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh for the update+merge kernel."""
-import csv, datetime, glob, json, os, sys
+import csv, ctypes, datetime, glob, json, os, sys
 cfg, tag = sys.argv[1], sys.argv[2]
+_L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cuda-phdslam_amd", "libphdslam.so"))
+_L.phd_version.restype = ctypes.c_char_p
+BUILD_ID = _L.phd_version().decode().split("build ")[-1]          # bench.py refuses counters of another build
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob("gpurun_out/pmc_%s_cfg%s_%s/**/*counter_collection.csv" % (c, cfg, tag), recursive=True)
@@ -17,7 +20,7 @@ if res["FETCH_SIZE"][0] is not None and res["WRITE_SIZE"][0] is not None:
     # (16 B/lane) streaming reads (guide: "double it"); this kernel's plane reads are 4 B/lane, a width
     # the guide calls uncalibrated, so both the raw and the doubled figure are kept.
     fetch, write = res["FETCH_SIZE"][0] * 1024, res["WRITE_SIZE"][0] * 1024
-    out = {"config": int(cfg), "kernel": "phd_update_merge_kernel", "build": tag, "date": datetime.date.today().isoformat(),
+    out = {"config": int(cfg), "kernel": "phd_update_merge_kernel", "build": tag, "build_id": BUILD_ID, "date": datetime.date.today().isoformat(),
            "dispatches_averaged": res["FETCH_SIZE"][1],
            "fetch_bytes_raw": fetch, "fetch_bytes_doubled": 2 * fetch, "write_bytes": write,
            "hbm_bytes_per_launch": 2 * fetch + write,
