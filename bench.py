@@ -322,7 +322,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
     stages = None
     if extras and cfg_id != 5:
         names = ["classify+ekf", "normalisers", "nondetect_emit", "detect_emit", "finalise+births", "sort", "merge_rounds",
-                 "sort_by_seed", "segments", "moment_matching", "append"]
+                 "moment_sums_a", "cluster_means", "moment_sums_b", "append"]
         f.debug(2)
         for _ in range(2):
             f.update(w["z"][0])

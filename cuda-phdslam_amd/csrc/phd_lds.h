@@ -25,6 +25,7 @@ typedef LDS_T(unsigned char)* lds_u8;
 struct LdsOffsets {
     u32 w, mx, my, xx, xy, yy, tr, u;
     u32 alias;      // start of the aliased region
+    u32 cinfo;      // (inside it) the merge's per-cluster seed records, behind both the rounds' working set and the sums
     u32 out_idx, z_r, z_b, logZ, zpart, zok, bgeo, part, win, red, ctr;
     u32 total;
 };
@@ -42,9 +43,13 @@ __host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
     const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C) + 2u * align16u(16u * (u32)C) +
                      align16u(4u * (u32)C);
     const u32 sort1 = 3u * sv + PHD_RWIN_BYTES;   // sort arrays / round lists + the rounds' window and seed records
-    const u32 sort2 = sv + align16u(4u * (u32)(S + 1));
+    // the exact moment sums of the round-based merge (phd_fixsum.h): 48 B of accumulators per output cluster (<= C) from the
+    // start of the region once the rounds are over, and 16 B per cluster of seed records written DURING the rounds — behind both
+    const u32 sums = 48u * (u32)C;
+    o.cinfo = o.alias + (sort1 > sums ? sort1 : sums);
     u32 amax = feat > sort1 ? feat : sort1;
-    amax = amax > sort2 ? amax : sort2;
+    const u32 msum = (o.cinfo - o.alias) + 16u * (u32)C;
+    amax = amax > msum ? amax : msum;
     const u32 small = 2u * PHD_SMALL_S * 32u + 64u + 2u * PHD_SMALL_S * 16u; // merge_small(): rows, member columns, seeds, staged planes
     amax = amax > small ? amax : small;
     p += amax;
@@ -82,8 +87,8 @@ struct Lds {
     LDS_T(v4f)* f_p;                              // Joseph-form updated covariance (the same for every measurement) and prior mean x: (xx, xy, yy, mx)
     lds_f32 f_my;                                 // prior mean y
     lds_u32 khi, klo, pay;                        // sort 1
-    lds_u32 key2;                                 // sort 2
-    lds_i32 seg;                                  // cluster starts, S+1
+    LDS_T(long long)* acc;                        // exact moment sums: [C][6] 64-bit words (after the rounds; aliases khi.. )
+    LDS_T(v4f)* cinfo;                            // per cluster: (seed mean x, y, seed weight, seed's survivor index), written in the rounds
     lds_f32 rwin;                                 // merge rounds: window copy + seed records (PHD_RWIN_BYTES), behind khi/klo/pay
     LDS_T(u64)* srow;                             // merge_small: [256][4] closeness to earlier positions
     LDS_T(u64)* scol;                             // merge_small: [256][4] members of the cluster seeded at a position
@@ -120,8 +125,8 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     L.khi = (lds_u32)(base + o.alias);
     L.klo = (lds_u32)(base + o.alias + sv);
     L.pay = (lds_u32)(base + o.alias + 2u * sv);
-    L.key2 = (lds_u32)(base + o.alias);
-    L.seg = (lds_i32)(base + o.alias + sv);
+    L.acc = (LDS_T(long long)*)(base + o.alias);
+    L.cinfo = (LDS_T(v4f)*)(base + o.cinfo);
     L.rwin = (lds_f32)(base + o.alias + 3u * sv);
     L.srow = (LDS_T(u64)*)(base + o.alias);
     L.scol = (LDS_T(u64)*)(base + o.alias + PHD_SMALL_S * 32u);

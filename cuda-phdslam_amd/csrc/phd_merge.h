@@ -6,6 +6,7 @@
 #include "phd_math.h"
 #include "phd_lds.h"
 #include "phd_sort.h"
+#include "phd_fixsum.h"
 
 namespace phd {
 
@@ -305,29 +306,30 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
                                       : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
         const bool selfok = dself < T;
         if (!selfok) mem[k >> 6] &= ~(1ull << (k & 63)); // a seed that is not close to itself is not in its own cluster
-        float W = 0.f, sx = 0.f, sy = 0.f;
+        // exact, order-free sums (phd_fixsum.h): anchored at the seed's weight, the seed's mean the origin of the offsets
+        const int Fw = fx_field(sa.w);
+        FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
             u64 m = mem[wd];
             while (m) {
                 const int p = 64 * wd + __builtin_ctzll(m);
                 m &= m - 1;
-                const v4f pa = L.sA[p];
-                const float w = pa.w;
-                W += w;
-                sx += w * pa.x;
-                sy += w * pa.y;
+                const v4f pa = L.sA[p], pb = L.sB[p];
+                fx_add_first(fs, Fw, smx, smy, pa.w, pa.x, pa.y, pb.x, pb.y, pb.z);
             }
         }
         // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then
         // yields W == 0
         int stop_at = 0x7FFFFFFF;
-        if (W == 0.f) stop_at = c;
+        if (fs.W == 0 && fs.ok && fs.ec < 255) stop_at = c;
         else if (!selfok) stop_at = c + 1;
         if (stop_at != 0x7FFFFFFF) atomicMin((int*)&L.ctr[CTR_KOUT], stop_at);
-        if (W != 0.f && c < cap) {
-            const float mx = sx / W, my = sy / W;
-            float cxx = 0.f, cxy = 0.f, cyy = 0.f;
+        if (!(fs.W == 0 && fs.ok && fs.ec < 255) && c < cap) {
+            float W, mx, my;
+            fx_mean(fs, Fw, W, mx, my);
+            const int Fc = fx_cov_anchor(Fw, fs.ec);
+            bool ok = fs.ok && fs.ec < 255;
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
                 u64 m = mem[wd];
@@ -335,20 +337,18 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
                     const int p = 64 * wd + __builtin_ctzll(m);
                     m &= m - 1;
                     const v4f pa = L.sA[p], pb = L.sB[p];
-                    const float w = pa.w;
-                    const float d0 = mx - pa.x;
-                    const float d1 = my - pa.y;
-                    cxx += w * (pb.x + d0 * d0);
-                    cxy += w * (pb.y + d0 * d1);
-                    cyy += w * (pb.z + d1 * d1);
+                    i64 qxx, qxy, qyy;
+                    fx_cov_terms(Fc, mx, my, pa.w, pa.x, pa.y, pb.x, pb.y, pb.z, qxx, qxy, qyy, ok);
+                    fs.cxx += qxx; fs.cxy += qxy; fs.cyy += qyy;
                 }
             }
-            out_slab[0 * cap + c] = W;
-            out_slab[1 * cap + c] = mx;
-            out_slab[2 * cap + c] = my;
-            out_slab[3 * cap + c] = cxx / W;
-            out_slab[4 * cap + c] = cxy / W;
-            out_slab[5 * cap + c] = cyy / W;
+            const float bad = __builtin_nanf("");
+            out_slab[0 * cap + c] = ok ? W : bad;
+            out_slab[1 * cap + c] = ok ? mx : bad;
+            out_slab[2 * cap + c] = ok ? my : bad;
+            out_slab[3 * cap + c] = ok ? fx_cov(fs.cxx, fs.W, Fc, Fw) : bad;
+            out_slab[4 * cap + c] = ok ? fx_cov(fs.cxy, fs.W, Fc, Fw) : bad;
+            out_slab[5 * cap + c] = ok ? fx_cov(fs.cyy, fs.W, Fc, Fw) : bad;
         }
     }
     __syncthreads();
@@ -405,6 +405,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     LDS_T(v4f)* const sG = sF + 72;                                  //                             (cov xx, xy, yy, -)
     for (int i = tid; i < S; i += PHD_T) ul_a[i] = (u16)i;
     int n_u = S;
+    int kbase = 0;                                             // seeds of the rounds so far = clusters opened
     lds_u16 cur = ul_a, nxt = ul_b;
     // the first window: broadcast-friendly copy of the first 64 survivors (later windows are written by the compaction
     // of the round before: the first 64 entries it keeps ARE the next window)
@@ -487,8 +488,10 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 seeds = nx;
             }
             if (wave == 0 && lane < nwin) {
+                // the cluster of a window candidate: its own if it is a seed, else the first seed it is close to.  Cluster
+                // index = seeds before it, over all rounds = its position in the output (descending seed weight)
                 const int owner = ((seeds >> lane) & 1ull) ? lane : __builtin_ctzll(row & seeds);
-                asg[4 * wpos[lane] + 3] = wpos[owner];
+                asg[4 * wpos[lane] + 3] = kbase + __popcll(seeds & ((1ull << owner) - 1ull));
             }
         }
         if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
@@ -503,13 +506,16 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         {
             const int rank = __popcll(seeds & lanemask_lt());
             if ((seeds >> lane) & 1ull) {
-                sF[rank] = (v4f){m2x, m2y, kE, __int_as_float(wpos[lane])};
+                sF[rank] = (v4f){m2x, m2y, kE, __int_as_float(kbase + rank)};
                 sG[rank] = wB[lane];
+                // the seed's record for the moment sums after the rounds (one wave writes it)
+                if (wave == 0 && kbase + rank < cap) L.cinfo[kbase + rank] = (v4f){kx, ky, ka.w, __int_as_float(wpos[lane])};
             }
             if (lane < 8) sF[nseeds + lane] = (v4f){0.f, 0.f, INFINITY, 0.f};   // pad to a multiple of 8: never a candidate
         }
         const int per = (nrest + PHD_T - 1) / PHD_T;           // entries per thread
         RSTAMP(2);
+        kbase += nseeds;                                        // (uniform: every wave computes the same seed mask)
         int kept = 0;
         u32 keepbits = 0;                                       // bit q: this thread's q-th entry stays listed
 #ifdef PHD_DUP_ASSIGN
@@ -611,166 +617,107 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     }
 
     STAMP(7);
-    // ---- group by seed, members in sorted-position order --------------------------------------------
-    // A counting sort instead of a second bitonic sort (a tenth of its instructions): members per seed (LDS atomics)
-    // -> one packed scan gives each seed its segment start (low half) and its cluster index (high half: seeds
-    // before it) -> members dropped into their seed's segment in arrival order -> every member finds its place by
-    // counting the smaller positions in its own segment (clusters are small), which makes the order — and so the
-    // summation order of the moment matching — deterministic.
-    {
-        lds_u32 cursor = L.khi;                 // per seed: members placed so far (then key2, the grouped list)
-        lds_u32 members = L.klo;                // segments in arrival order (then seg, the cluster starts)
-        lds_u32 cnt = L.pay;                    // per seed: member count -> packed exclusive prefix
-        for (int i = tid; i < S; i += PHD_T) { cnt[i] = 0u; cursor[i] = 0u; }
-        __syncthreads();
-        int sreg[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = tid + e * PHD_T;
-            sreg[e] = 0;
-            if (i < S) { sreg[e] = asg[4 * i + 3]; atomicAdd((u32*)&cnt[sreg[e]], 1u); }
-        }
-        __syncthreads();
-        const int per = (S + PHD_T - 1) / PHD_T; // <= 4 (S <= 2048)
-        u32 total;
-        {
-            const int lo = tid * per;
-            u32 v[4], local = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int sd = lo + e;
-                v[e] = (e < per && sd < S) ? (cnt[sd] | ((asg[4 * sd + 3] == sd) ? 0x10000u : 0u)) : 0u;
-                local += v[e];
-            }
-            const u32 incl = wave_incl_scan(local);
-            if (lane == 63) L.ctr[CTR_TMP + wave] = (int)incl;
-            __syncthreads();
-            u32 woff = 0u;
-            total = 0u;
-#pragma unroll
-            for (int w = 0; w < PHD_NW; ++w) {
-                const u32 c = (u32)L.ctr[CTR_TMP + w];
-                if (w < wave) woff += c;
-                total += c;
-            }
-            u32 run = woff + incl - local;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int sd = lo + e;
-                if (e < per && sd < S) { cnt[sd] = run; run += v[e]; }
-            }
-        }
-        __syncthreads();
-        int pos[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = tid + e * PHD_T;
-            if (i < S) members[(cnt[sreg[e]] & 0xFFFFu) + atomicAdd((u32*)&cursor[sreg[e]], 1u)] = (u32)i;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = tid + e * PHD_T;
-            pos[e] = 0;
-            if (i < S) {
-                const int b = (int)(cnt[sreg[e]] & 0xFFFFu), k = (int)cursor[sreg[e]];
-                int r = 0;
-                for (int t = 0; t < k; ++t) r += ((int)members[b + t] < i) ? 1 : 0;
-                pos[e] = b + r;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = tid + e * PHD_T;
-            if (i < S) {
-                // the grouped list holds the member's BYTE OFFSET into gA / gB (16 i < 2^15): one ds_read_u16 away
-                L.key2[pos[e]] = ((u32)sreg[e] << 16) | ((u32)i << 4);             // key2 aliases cursor
-                if (sreg[e] == i) L.seg[cnt[i] >> 16] = (int)(cnt[i] & 0xFFFFu);   // seg aliases members
-            }
-        }
-        if (tid == 0) { L.seg[total >> 16] = S; L.ctr[CTR_NHEAD] = (int)(total >> 16); L.ctr[CTR_KOUT] = 0x7FFFFFFF; }
-        __syncthreads();
-    }
-    STAMP(8);
-    const int n_clusters = L.ctr[CTR_NHEAD];
-    STAMP(9);
-
-    // ---- moment matching: one lane per cluster, sequential in (weight desc) order ----------------
-    // (src/gm_reduce.cpp:103-118's order; the loads of four members are issued together, the sums stay sequential)
-    if (tid == 0) atomicMin((int*)&L.ctr[CTR_KOUT], n_clusters);   // as in merge_small
-    const LDS_T(u16)* const koff = (const LDS_T(u16)*)L.key2;      // low half of entry j: koff[2 j]
-    const LDS_T(unsigned char)* const gAb = (const LDS_T(unsigned char)*)gA;
-    const LDS_T(unsigned char)* const gBb = (const LDS_T(unsigned char)*)gB;
-#define PHD_GA(off) (*(const LDS_T(v4f)*)(gAb + (off)))
-#define PHD_GB(off) (*(const LDS_T(v4f)*)(gBb + (off)))
+    // ---- moment matching by exact, order-free sums (phd_fixsum.h) --------------------------------------------------
+    // The reference adds a cluster's members with a reduction tree (src/phdfilter.cu:2795-2881); round 2 grouped the
+    // survivors by seed with a second sort and walked each cluster sequentially.  Integer sums need neither: every
+    // survivor adds its terms to its cluster's accumulators with LDS atomics, in whatever order the lanes arrive.
+    //   A: weights, weighted means, the covariance scale (largest exponent)      -> per-cluster W, mean
+    //   B: weighted covariances about the merged mean                             -> per-cluster covariance
+    const int n_clusters = kbase;
+    const int K = n_clusters < cap ? n_clusters : cap;         // clusters past the map capacity are reported, not stored
+    LDS_T(i64)* const acc = L.acc;
+    LDS_T(u32)* const acc32 = (LDS_T(u32)*)L.acc;
+    if (tid == 0) { L.ctr[CTR_NHEAD] = n_clusters; L.ctr[CTR_KOUT] = n_clusters; }
+    for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
 #ifdef PHD_DUP_MOMENTS
     for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
 #endif
-    for (int c0 = 0; c0 < n_clusters; c0 += PHD_T) {
-#pragma clang fp contract(off)
+    for (int i = tid; i < S; i += PHD_T) {
+        const v4f a = gA[i], b = gB[i];
+        const int c = __float_as_int(b.w);
+        if (c >= K) continue;
+        const v4f ci = L.cinfo[c];
+        const int Fw = fx_field(ci.z);
+        if (__float_as_int(ci.w) == i) {
+            // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
+            const float dself = HELLINGER ? hellinger_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z)
+                                          : mahal_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z);
+            if (!(dself < T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+        }
+        FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
+        fx_add_first(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
+        LDS_T(i64)* const q = acc + 6 * c;
+        __hip_atomic_fetch_add(q + 0, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 1, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 2, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 3, fs.yh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 4, fs.yl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&acc32[12 * c + 10], (u32)fs.ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!fs.ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    STAMP(8);
+    // per cluster: W, mean (:2828), the stop rule (:2821); the slot becomes (cxx, cxy, cyy, W | mean x, mean y, scales, flags)
+    for (int c = tid; c < K; c += PHD_T) {
+        FxSums fs;
+        fs.W = acc[6 * c + 0]; fs.xh = acc[6 * c + 1]; fs.xl = acc[6 * c + 2]; fs.yh = acc[6 * c + 3]; fs.yl = acc[6 * c + 4];
+        const u32 ec = acc32[12 * c + 10], fl = acc32[12 * c + 11];
+        const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
+        const int Fw = fx_field(L.cinfo[c].z);
+        // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then yields W == 0
+        int stop_at = 0x7FFFFFFF;
+        if (fs.W == 0 && ok) stop_at = c;
+        else if (!selfok) stop_at = c + 1;
+        if (stop_at != 0x7FFFFFFF) atomicMin((int*)&L.ctr[CTR_KOUT], stop_at);
+        float W, mx, my;
+        fx_mean(fs, Fw, W, mx, my);
+        const int Fc = fx_cov_anchor(Fw, (int)ec);
+        acc[6 * c + 0] = 0; acc[6 * c + 1] = 0; acc[6 * c + 2] = 0;
+        acc[6 * c + 3] = fs.W;
+        acc32[12 * c + 8] = __float_as_uint(mx); acc32[12 * c + 9] = __float_as_uint(my);
+        acc32[12 * c + 10] = (u32)Fc | ((u32)Fw << 16);
+        acc32[12 * c + 11] = (ok ? 0u : 1u) | (fl & 2u);
+        if (ok) { out_slab[0 * cap + c] = W; out_slab[1 * cap + c] = mx; out_slab[2 * cap + c] = my; }
+    }
+    __syncthreads();
+    STAMP(9);
 #ifdef PHD_DUP_MOMENTS
-        asm volatile("" ::: "memory");
+    for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
 #endif
-        const int c = c0 + tid;
-        if (c < n_clusters) {
-            const int b = L.seg[c], e = L.seg[c + 1];
-            const v4f sa = PHD_GA(koff[2 * b]), sb = PHD_GB(koff[2 * b]); // the seed (first in sorted order)
-            const float smx = sa.x, smy = sa.y, sxx = sb.x, sxy = sb.y, syy = sb.z;
-            float dself = HELLINGER ? hellinger_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy)
-                                    : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
-            const bool selfok = dself < T;
-            const int b0 = selfok ? b : b + 1; // a seed that is not close to itself is not in its own cluster
-            float W = 0.f, sx = 0.f, sy = 0.f;
-            int i = b0;
-            for (; i + 4 <= e; i += 4) {
-                const u32 o0 = koff[2 * i], o1 = koff[2 * i + 2], o2 = koff[2 * i + 4], o3 = koff[2 * i + 6];
-                const v4f a0 = PHD_GA(o0), a1 = PHD_GA(o1), a2 = PHD_GA(o2), a3 = PHD_GA(o3);
-                W += a0.w; sx += a0.w * a0.x; sy += a0.w * a0.y;
-                W += a1.w; sx += a1.w * a1.x; sy += a1.w * a1.y;
-                W += a2.w; sx += a2.w * a2.x; sy += a2.w * a2.y;
-                W += a3.w; sx += a3.w * a3.x; sy += a3.w * a3.y;
-            }
-            for (; i < e; ++i) {
-                const v4f a0 = PHD_GA(koff[2 * i]);
-                W += a0.w; sx += a0.w * a0.x; sy += a0.w * a0.y;
-            }
-            // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked
-            // and then yields W == 0
-            int stop_at = 0x7FFFFFFF;
-            if (W == 0.f) stop_at = c;
-            else if (!selfok) stop_at = c + 1;
-            if (stop_at != 0x7FFFFFFF) atomicMin((int*)&L.ctr[CTR_KOUT], stop_at);
-            if (W != 0.f && c < cap) {
-                const float mx = sx / W, my = sy / W;
-                float cxx = 0.f, cxy = 0.f, cyy = 0.f;
-#define PHD_COV_ACC(a, bq) do { const float d0 = mx - (a).x, d1 = my - (a).y;                 \
-                                cxx += (a).w * ((bq).x + d0 * d0); cxy += (a).w * ((bq).y + d0 * d1); \
-                                cyy += (a).w * ((bq).z + d1 * d1); } while (0)
-                i = b0;
-                for (; i + 4 <= e; i += 4) {
-                    const u32 o0 = koff[2 * i], o1 = koff[2 * i + 2], o2 = koff[2 * i + 4], o3 = koff[2 * i + 6];
-                    const v4f a0 = PHD_GA(o0), a1 = PHD_GA(o1), a2 = PHD_GA(o2), a3 = PHD_GA(o3);
-                    const v4f q0 = PHD_GB(o0), q1 = PHD_GB(o1), q2 = PHD_GB(o2), q3 = PHD_GB(o3);
-                    PHD_COV_ACC(a0, q0); PHD_COV_ACC(a1, q1); PHD_COV_ACC(a2, q2); PHD_COV_ACC(a3, q3);
-                }
-                for (; i < e; ++i) {
-                    const u32 o0 = koff[2 * i];
-                    const v4f a0 = PHD_GA(o0), q0 = PHD_GB(o0);
-                    PHD_COV_ACC(a0, q0);
-                }
-#undef PHD_COV_ACC
-                out_slab[0 * cap + c] = W;
-                out_slab[1 * cap + c] = mx;
-                out_slab[2 * cap + c] = my;
-                out_slab[3 * cap + c] = cxx / W;
-                out_slab[4 * cap + c] = cxy / W;
-                out_slab[5 * cap + c] = cyy / W;
-            }
+    for (int i = tid; i < S; i += PHD_T) {
+        const v4f a = gA[i], b = gB[i];
+        const int c = __float_as_int(b.w);
+        if (c >= K) continue;
+        const v4f h = ((LDS_T(v4f)*)acc)[3 * c + 2];           // (mean x, mean y, scales, flags)
+        const u32 sc = __float_as_uint(h.z);
+        // (flag 2: the seed is not in its own cluster, decided in pass A)
+        if ((__float_as_uint(h.w) & 2u) && __float_as_int(L.cinfo[c].w) == i) continue;
+        bool ok = true;
+        i64 qxx, qxy, qyy;
+        fx_cov_terms((int)(sc & 0xFFFFu), h.x, h.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
+        LDS_T(i64)* const q = acc + 6 * c;
+        __hip_atomic_fetch_add(q + 0, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 1, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 2, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    // per cluster: covariance = sum / W (:2879; the symmetric form needs no force_symmetric_covariance)
+    for (int c = tid; c < K; c += PHD_T) {
+        const i64 cxx = acc[6 * c + 0], cxy = acc[6 * c + 1], cyy = acc[6 * c + 2], Wq = acc[6 * c + 3];
+        const u32 sc = acc32[12 * c + 10];
+        const int Fc = (int)(sc & 0xFFFFu), Fw = (int)(sc >> 16);
+        if (acc32[12 * c + 11] & 1u) {
+            const float bad = __builtin_nanf("");
+#pragma unroll
+            for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + c] = bad;
+        } else {
+            out_slab[3 * cap + c] = fx_cov(cxx, Wq, Fc, Fw);
+            out_slab[4 * cap + c] = fx_cov(cxy, Wq, Fc, Fw);
+            out_slab[5 * cap + c] = fx_cov(cyy, Wq, Fc, Fw);
         }
     }
-#undef PHD_GA
-#undef PHD_GB
     __syncthreads();
     STAMP(10);
 }

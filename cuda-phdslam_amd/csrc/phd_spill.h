@@ -109,32 +109,35 @@ __device__ __forceinline__ void merge_spill_body(const UpdateArgs& A, int p, int
             const float dself = HELLINGER ? hellinger_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy)
                                           : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
             const bool selfok = dself < T;
-            float W = 0.f, sx = 0.f, sy = 0.f;
+            // exact, order-free sums (phd_fixsum.h), as in the LDS merges
+            const int Fw = fx_field(sr[0]);
+            FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
             for (int i = h; i < S; ++i) {
                 if (assign[i] != h || (i == h && !selfok)) continue;
                 const float* r = srt + (size_t)i * 8;
-                const float w = r[0];
-                W += w; sx += w * r[1]; sy += w * r[2];
+                fx_add_first(fs, Fw, smx, smy, r[0], r[1], r[2], r[3], r[4], r[5]);
             }
             int stop_at = 0x7FFFFFFF;
-            if (W == 0.f) stop_at = c;                                 // src/phdfilter.cu:2821
+            if (fs.W == 0 && fs.ok && fs.ec < 255) stop_at = c;                       // src/phdfilter.cu:2821
             else if (!selfok) stop_at = c + 1;
             if (stop_at != 0x7FFFFFFF) atomicMin(&s_stop, stop_at);
-            if (W != 0.f && c < cap) {
-                const float mx = sx / W, my = sy / W;
-                float cxx = 0.f, cxy = 0.f, cyy = 0.f;
+            if (!(fs.W == 0 && fs.ok && fs.ec < 255) && c < cap) {
+                float W, mx, my;
+                fx_mean(fs, Fw, W, mx, my);
+                const int Fc = fx_cov_anchor(Fw, fs.ec);
+                bool ok = fs.ok && fs.ec < 255;
                 for (int i = h; i < S; ++i) {
                     if (assign[i] != h || (i == h && !selfok)) continue;
                     const float* r = srt + (size_t)i * 8;
-                    const float w = r[0];
-                    const float d0 = mx - r[1];
-                    const float d1 = my - r[2];
-                    cxx += w * (r[3] + d0 * d0);
-                    cxy += w * (r[4] + d0 * d1);
-                    cyy += w * (r[5] + d1 * d1);
+                    i64 qxx, qxy, qyy;
+                    fx_cov_terms(Fc, mx, my, r[0], r[1], r[2], r[3], r[4], r[5], qxx, qxy, qyy, ok);
+                    fs.cxx += qxx; fs.cxy += qxy; fs.cyy += qyy;
                 }
-                out[0 * cap + c] = W; out[1 * cap + c] = mx; out[2 * cap + c] = my;
-                out[3 * cap + c] = cxx / W; out[4 * cap + c] = cxy / W; out[5 * cap + c] = cyy / W;
+                const float bad = __builtin_nanf("");
+                out[0 * cap + c] = ok ? W : bad; out[1 * cap + c] = ok ? mx : bad; out[2 * cap + c] = ok ? my : bad;
+                out[3 * cap + c] = ok ? fx_cov(fs.cxx, fs.W, Fc, Fw) : bad;
+                out[4 * cap + c] = ok ? fx_cov(fs.cxy, fs.W, Fc, Fw) : bad;
+                out[5 * cap + c] = ok ? fx_cov(fs.cyy, fs.W, Fc, Fw) : bad;
             }
         }
     }

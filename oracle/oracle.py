@@ -29,7 +29,7 @@ class OConfig(C.Structure):
                 ("resampleThresh", C.c_float),
                 ("l", C.c_float), ("h", C.c_float), ("a", C.c_float), ("b", C.c_float),
                 ("subdividePredict", C.c_int32), ("distanceMetric", C.c_int32),
-                ("labeledMeasurements", C.c_int32), ("particleWeighting", C.c_int32)]
+                ("labeledMeasurements", C.c_int32), ("particleWeighting", C.c_int32), ("mergeSums", C.c_int32)]
 
 
 def default_config(**over):
@@ -43,7 +43,7 @@ def default_config(**over):
                   pd=0.95, birthWeight=1e-4, birthNoiseFactor=1.0,
                   minFeatureWeight=1e-6, minSeparation=10.0, resampleThresh=0.5,
                   l=1.415, h=0.38, a=1.89, b=0.5,
-                  subdividePredict=1, distanceMetric=0, labeledMeasurements=0, particleWeighting=0)
+                  subdividePredict=1, distanceMetric=0, labeledMeasurements=0, particleWeighting=0, mergeSums=0)
     for k, v in over.items():
         setattr(cfg, k, v)
     return cfg

@@ -340,6 +340,134 @@ static int o_cmp_desc(const void* pa, const void* pb)
     return (a->idx > b->idx) - (a->idx < b->idx);
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* Exact, order-free moment sums (o_config.mergeSums == 0).
+ *
+ * The reference adds the members of a cluster with sumByReduction (src/phdfilter.cu:2795-2881): per-thread partial sums
+ * over a strided slice, then a tree — an order that depends on the block size.  A float sum has no value of its own
+ * under such a rule, an integer sum has.  So each TERM is the reference's float expression (one rounding per operation,
+ * no contraction), and the terms are added as integers after an exact conversion (a mantissa shift) to a fixed-point
+ * scale anchored at the cluster's own magnitudes:
+ *
+ *   field(x) = biased exponent of x, 1 for zero/denormals: |x| < 2^(field - 126)
+ *   fix(x, F, top) = sign(x) * floor(|x| * 2^(top + 150 - F))          requires field(x) <= F, x finite
+ *
+ *   weights        q = fix(w_i, Fw, 16),  Fw = field(weight of the seed)                 (the seed is the heaviest member)
+ *   weighted means q = fix(w_i * m_i, Fw + 28, 38), added as two 31-bit digits           (:2813)
+ *   covariances    q = fix(w_i * (P_i + d d^T), Fc, 18),  d = mean - m_i                 (:2854-2866)
+ *                  Fc = max(1, Fw + ec - 121),  ec = largest field among the members' P entries and squared
+ *                  offsets (m_i - m_seed)^2 — the merged mean is within twice the largest offset of every member
+ *
+ * W = sum(w) and the three quotients of :2828 / :2879 are then taken in double from the integer sums (exact below 2^53)
+ * and rounded to float once.  A term that violates its anchor or is not finite poisons the cluster (NaN output).
+ * The device (cuda-phdslam_amd/csrc/phd_fixsum.h) implements the same definition with LDS atomics. */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t W, xh, xl, yh, yl, cxx, cxy, cyy;
+    int Fw, ec, ok;
+    float smx, smy;
+} o_exact_sums;
+
+static int o_field(float x)
+{
+    uint32_t b; memcpy(&b, &x, 4);
+    int ef = (int)((b >> 23) & 0xFF);
+    return ef ? ef : 1;
+}
+
+static int64_t o_fix(float x, int F, int top, int* ok)
+{
+    uint32_t b; memcpy(&b, &x, 4);
+    int ef = (int)((b >> 23) & 0xFF);
+    uint32_t frac = b & 0x7FFFFFu;
+    if (ef == 255) { *ok = 0; return 0; }
+    uint64_t m = ef ? (uint64_t)(frac | 0x800000u) : (uint64_t)frac;
+    int e1 = ef ? ef : 1;
+    if (e1 > F) { *ok = 0; return 0; }
+    int k = e1 - F + top;
+    uint64_t q = (k >= 0) ? (m << k) : (k > -32 ? (m >> (-k)) : 0);
+    return (b >> 31) ? -(int64_t)q : (int64_t)q;
+}
+
+static void o_exact_begin(o_exact_sums* s, const o_gaussian* seed)
+{
+    memset(s, 0, sizeof(*s));
+    s->ok = 1;
+    s->Fw = o_field(seed->weight);
+    s->smx = seed->mean[0]; s->smy = seed->mean[1];
+}
+
+static void o_exact_digits(int64_t q, int64_t* hi, int64_t* lo)
+{
+    uint64_t a = q < 0 ? (uint64_t)(-q) : (uint64_t)q;
+    int64_t h = (int64_t)(a >> 31), l = (int64_t)(a & 0x7FFFFFFFu);
+    *hi += q < 0 ? -h : h;
+    *lo += q < 0 ? -l : l;
+}
+
+static void o_exact_first(o_exact_sums* s, const o_gaussian* g)
+{
+    const float w = g->weight;
+    s->W += o_fix(w, s->Fw, 16, &s->ok);
+    const float tx = w * g->mean[0], ty = w * g->mean[1];                 /* :2813 */
+    o_exact_digits(o_fix(tx, s->Fw + 28, 38, &s->ok), &s->xh, &s->xl);
+    o_exact_digits(o_fix(ty, s->Fw + 28, 38, &s->ok), &s->yh, &s->yl);
+    const float dx = g->mean[0] - s->smx, dy = g->mean[1] - s->smy;
+    const float dx2 = dx * dx, dy2 = dy * dy;
+    /* our maps are symmetric: cov[1] == cov[2] (force_symmetric_covariance, src/device_math.cuh:710-725) */
+    const float v[5] = {g->cov[0], g->cov[1], g->cov[3], dx2, dy2};
+    for (int k = 0; k < 5; k++) {
+        uint32_t b; memcpy(&b, &v[k], 4);
+        int ef = (int)((b >> 23) & 0xFF);
+        int e = ef ? ef : 1;                                             /* 255 for a non-finite value */
+        if (e > s->ec) s->ec = e;
+    }
+}
+
+static void o_exact_mean(const o_exact_sums* s, o_gaussian* mg)
+{
+    const double Wd = (double)s->W;
+    mg->weight = (float)ldexp(Wd, s->Fw - 166);
+    const double sx = fma((double)s->xh, 2147483648.0, (double)s->xl);
+    const double sy = fma((double)s->yh, 2147483648.0, (double)s->yl);
+    mg->mean[0] = (float)(sx / Wd * 64.0);                               /* :2828; 2^(Fw+28-38-150) / 2^(Fw-16-150) = 2^6 */
+    mg->mean[1] = (float)(sy / Wd * 64.0);
+}
+
+static int o_exact_anchor(const o_exact_sums* s)
+{
+    int F = s->Fw + s->ec - 121;
+    return F < 1 ? 1 : F;
+}
+
+static void o_exact_second(o_exact_sums* s, const o_gaussian* mg, const o_gaussian* g)
+{
+    const int Fc = o_exact_anchor(s);
+    const float d0 = mg->mean[0] - g->mean[0], d1 = mg->mean[1] - g->mean[1];   /* :2854-2855 */
+    const float txx = g->weight * (g->cov[0] + d0 * d0);                      /* :2863-2866 */
+    const float txy = g->weight * (g->cov[1] + d0 * d1);
+    const float tyy = g->weight * (g->cov[3] + d1 * d1);
+    s->cxx += o_fix(txx, Fc, 18, &s->ok);
+    s->cxy += o_fix(txy, Fc, 18, &s->ok);
+    s->cyy += o_fix(tyy, Fc, 18, &s->ok);
+}
+
+static void o_exact_cov(const o_exact_sums* s, o_gaussian* mg)
+{
+    if (!s->ok || s->ec >= 255) {
+        mg->weight = mg->mean[0] = mg->mean[1] = NAN;
+        for (int j = 0; j < 4; j++) mg->cov[j] = NAN;
+        return;
+    }
+    const int Fc = o_exact_anchor(s);
+    const double Wd = (double)s->W;
+    const int sh = (Fc - 18) - (s->Fw - 16);
+    mg->cov[0] = (float)ldexp((double)s->cxx / Wd, sh);                   /* :2879 */
+    mg->cov[1] = (float)ldexp((double)s->cxy / Wd, sh);
+    mg->cov[2] = mg->cov[1];
+    mg->cov[3] = (float)ldexp((double)s->cyy / Wd, sh);
+}
+
 int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, float* margin_out)
 {
     float margin_d = FLT_MAX, margin_w = FLT_MAX;
@@ -370,6 +498,8 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
         }
         /* pass 1 (:2795-2830): members, weight, weighted mean — in sorted order, seed first */
         float W = 0, sx = 0, sy = 0;
+        o_exact_sums es;
+        o_exact_begin(&es, seed);
         for (int k = first; k < n; k++) {
             int i = order[k].idx;
             member[i] = 0;
@@ -387,13 +517,19 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
                 W += in[i].weight;
                 sx += in[i].weight * in[i].mean[0];
                 sy += in[i].weight * in[i].mean[1];
+                o_exact_first(&es, &in[i]);
             }
         }
-        if (W == 0) break;                                              /* :2821 */
         o_gaussian mg;
-        mg.weight = W;
-        mg.mean[0] = sx / W;                                            /* :2828 */
-        mg.mean[1] = sy / W;
+        if (cfg->mergeSums == 1) {
+            if (W == 0) break;                                          /* :2821 */
+            mg.weight = W;
+            mg.mean[0] = sx / W;                                        /* :2828 */
+            mg.mean[1] = sy / W;
+        } else {
+            if (es.ok && es.ec < 255 && es.W == 0) break;               /* :2821 on the exact sum */
+            o_exact_mean(&es, &mg);
+        }
         /* pass 2 (:2837-2881) */
         float c[4] = {0, 0, 0, 0};
         for (int k = first; k < n; k++) {
@@ -405,12 +541,17 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
             for (int j = 0; j < 2; j++)
                 for (int kk = 0; kk < 2; kk++)
                     c[j * 2 + kk] += in[i].weight * (in[i].cov[j * 2 + kk] + dd[j] * dd[kk]); /* :2863-2866 */
+            if (cfg->mergeSums != 1) o_exact_second(&es, &mg, &in[i]);
             merged[i] = 1;                                              /* :2869 */
         }
-        for (int j = 0; j < 4; j++) mg.cov[j] = c[j] / W;                /* :2879 */
-        /* force_symmetric_covariance, src/device_math.cuh:710-725: lower = (lower+upper)/2 */
-        mg.cov[1] = (mg.cov[1] + mg.cov[2]) / 2;
-        mg.cov[2] = mg.cov[1];
+        if (cfg->mergeSums == 1) {
+            for (int j = 0; j < 4; j++) mg.cov[j] = c[j] / W;            /* :2879 */
+            /* force_symmetric_covariance, src/device_math.cuh:710-725: lower = (lower+upper)/2 */
+            mg.cov[1] = (mg.cov[1] + mg.cov[2]) / 2;
+            mg.cov[2] = mg.cov[1];
+        } else {
+            o_exact_cov(&es, &mg);
+        }
         out[n_out++] = mg;                                              /* :2885-2887 */
     }
     free(order); free(merged); free(member);

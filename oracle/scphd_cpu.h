@@ -52,6 +52,11 @@ typedef struct {
     int32_t distanceMetric;        /* 0 Mahalanobis, 1 Hellinger */
     int32_t labeledMeasurements;
     int32_t particleWeighting;     /* only 0 supported */
+    /* how o_merge adds a cluster's members (the reference uses a block-size-dependent reduction tree,
+     * src/phdfilter.cu:2795-2881: no order of its own):
+     *   0  exact, order-free integer sums of the reference's terms (what the device computes; see o_merge)
+     *   1  float sums in (weight desc) order, seed first — the order of src/gm_reduce.cpp:103-118 */
+    int32_t mergeSums;
 } o_config;
 
 float o_safe_log(float x);

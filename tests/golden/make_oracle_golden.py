@@ -7,6 +7,9 @@ the reference's own state100.bin snapshot, src/main.cpp:1262-1269,1314-1321).
 3 seeds x {1 x 64 x 32, 8 x 64 x 32, 4 x 256 x 64 (clustered landmarks)}: inputs (poses, log-weights, maps, measurement
 set, control noise, resampling uniform), predicted poses, per-particle survivors (pruned update components + slab
 indices), merged maps, log-weight increments, decision margins, normalised weights, resampling indices.
+`out_maps` are the merged maps under the exact, order-free moment sums (o_config.mergeSums = 0: what the device computes);
+`out_maps_float` the same merge with float sums in weight order (mergeSums = 1) — bit for bit the `out_maps` of the file as
+it stood before round 3 (checked when the file was regenerated).
 
 Both the oracle (tests/test_oracle_golden.py, CPU) and the device (tests/test_gpu_golden.py) are tested against
 this FILE, not against each other only — so the oracle and the kernels cannot drift together unnoticed.  The file
@@ -41,12 +44,16 @@ def make_case(n, g, m, seed):
     ocfg = oracle_config_from(cfg)
     z = w["z"][0]
     pred = O.predict_ackerman(w["poses"], CONTROL[1], CONTROL[0], w["noise"][0], ocfg)
-    surv, sidx, nsurv, maps, sizes, dlogw, margins = [], [], [], [], [], [], []
+    ocfg_float = oracle_config_from(cfg, mergeSums=1)       # the merge with float sums in weight order (round 2's definition)
+    surv, sidx, nsurv, maps, maps_float, sizes, dlogw, margins = [], [], [], [], [], [], [], []
     for p in range(n):
         r = oracle_full_update(pred[p], w["maps"][p, :w["sizes"][p]], z, ocfg)
         surv.append(r["survivors"]); sidx.append(r["slab_idx"]); nsurv.append(len(r["survivors"]))
         maps.append(r["map"]); sizes.append(len(r["map"])); dlogw.append(r["dlogw"])
         margins.append((r["prune_margin"], r["margin"][0], r["margin"][1]))
+        rf = oracle_full_update(pred[p], w["maps"][p, :w["sizes"][p]], z, ocfg_float)
+        assert len(rf["map"]) == len(r["map"])             # the two definitions differ in roundings, never in structure
+        maps_float.append(rf["map"])
     dlogw = np.array(dlogw, np.float32)
     lw = O.normalize_weights(w["logw"], dlogw)
     idx = O.resample(lw, w["uniform"][0])
@@ -54,7 +61,8 @@ def make_case(n, g, m, seed):
         "poses": w["poses"], "logw": w["logw"], "maps": w["maps"], "sizes": w["sizes"], "z": z, "noise": w["noise"][0],
         "uniform": np.float64(w["uniform"][0]), "pred": pred,
         "surv": np.concatenate(surv), "sidx": np.concatenate(sidx), "nsurv": np.array(nsurv, np.int32),
-        "out_maps": np.concatenate(maps), "out_sizes": np.array(sizes, np.int32), "dlogw": dlogw,
+        "out_maps": np.concatenate(maps), "out_maps_float": np.concatenate(maps_float),
+        "out_sizes": np.array(sizes, np.int32), "dlogw": dlogw,
         "margins": np.array(margins, np.float64), "logw_norm": lw, "neff": np.float32(O.neff(lw)), "idx": idx,
     }
 

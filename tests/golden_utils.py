@@ -21,4 +21,5 @@ def load_case(n, g, m, seed):
     c["surv_of"] = lambda p: c["surv"][so[p]:so[p + 1]]
     c["sidx_of"] = lambda p: c["sidx"][so[p]:so[p + 1]]
     c["map_of"] = lambda p: c["out_maps"][mo[p]:mo[p + 1]]
+    c["map_float_of"] = lambda p: c["out_maps_float"][mo[p]:mo[p + 1]]
     return c

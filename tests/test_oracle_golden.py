@@ -21,6 +21,7 @@ MERGE_MARGIN = 2e-4
 def test_oracle_reproduces_its_frozen_outputs(n, g, m, seed):
     c = load_case(n, g, m, seed)
     ocfg = oracle_config_from(pkg().default_config())
+    ocfg_float = oracle_config_from(pkg().default_config(), mergeSums=1)
     pred = O.predict_ackerman(c["poses"], CONTROL[1], CONTROL[0], c["noise"], ocfg)
     for k in ("px", "py", "ptheta"):
         assert np.abs(pred[k] - c["pred"][k]).max() < 2e-6, k
@@ -39,6 +40,17 @@ def test_oracle_reproduces_its_frozen_outputs(n, g, m, seed):
         assert len(got) == len(want)
         for fld in ("weight", "mean", "cov"):
             assert np.array_equal(got[fld].view(np.uint32), want[fld].view(np.uint32)), (p, fld)
+        # the same merge with float sums in weight order (o_config.mergeSums = 1, round 2's definition): frozen too, and
+        # within rounding of the exact sums
+        omf = O.merge(c["surv_of"](p), ocfg_float)
+        wantf = c["map_float_of"](p)
+        gotf = np.concatenate([omf, cls0]) if len(cls0) else omf
+        assert len(gotf) == len(wantf) == len(want)
+        for fld in ("weight", "mean", "cov"):
+            assert np.array_equal(gotf[fld].view(np.uint32), wantf[fld].view(np.uint32)), (p, fld)
+        assert np.allclose(gotf["weight"], got["weight"], rtol=2e-6, atol=0)
+        assert np.abs(gotf["mean"] - got["mean"]).max() <= 2e-6 * max(1.0, np.abs(got["mean"]).max())
+        assert np.allclose(gotf["cov"], got["cov"], rtol=3e-5, atol=1e-9)
         pm, mm = c["margins"][p, 0], c["margins"][p, 1]
         if pm > PRUNE_MARGIN:
             assert np.array_equal(r["slab_idx"], c["sidx_of"](p)), "particle %d: survivor set differs from the frozen one" % p

@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("cuda-phdslam_amd"); S = importlib.import_module("cuda-phdslam_amd.synthetic")
 NAMES = ["classify+ekf", "pass1 normalisers", "nondetect emit", "pass2 detect emit", "finalise+births", "sort1+permute",
-         "merge rounds", "sort2", "heads/segments", "moment matching", "append+tail"]
+         "merge rounds", "sums A (w, w m)", "cluster means", "sums B (cov) + divide", "append+tail"]
 for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
     w = S.config_workload(cid)
     N, G, M = w["N"], w["G"], w["M"]
