@@ -45,6 +45,117 @@ __device__ __forceinline__ bool is_close(float smx, float smy, float sxx, float 
 }
 
 // ------------------------------------------------------------------------------------------
+// Moment matching by exact, order-free sums (phd_fixsum.h), shared by both LDS merges.
+// The reference adds a cluster's members with a reduction tree (src/phdfilter.cu:2795-2881); round 2 grouped the
+// survivors by seed with a second sort and walked each cluster sequentially.  Integer sums need neither: every survivor
+// adds its terms to its cluster's accumulators with LDS atomics, in whatever order the lanes arrive.
+//   A: weights, weighted means, the covariance scale (largest exponent)      -> per-cluster W, mean
+//   B: weighted covariances about the merged mean                             -> per-cluster covariance
+// recA[i] = (mean x, mean y, -, weight), recB[i] = (cov xx, xy, yy, cluster index as int bits) for the S survivors;
+// cinfo[c] = (seed mean x, y, seed weight, the seed's survivor index); acc: 48 B per cluster, free to be overwritten.
+// Leaves the cluster count (min(n_clusters, first stop)) in ctr[CTR_KOUT].  Every thread of the workgroup calls it.
+// ------------------------------------------------------------------------------------------
+template <bool HELLINGER, bool STAMPS>
+__device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(v4f)* recB, int S, int n_clusters, int cap,
+                                            LDS_T(long long)* acc, const LDS_T(v4f)* cinfo, lds_i32 ctr, float T,
+                                            float* __restrict__ out_slab, int tid, u64* st)
+{
+    const int K = n_clusters < cap ? n_clusters : cap;         // clusters past the map capacity are reported, not stored
+    LDS_T(u32)* const acc32 = (LDS_T(u32)*)acc;
+    if (tid == 0) { ctr[CTR_NHEAD] = n_clusters; ctr[CTR_KOUT] = n_clusters; }
+    for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#ifdef PHD_DUP_MOMENTS
+    for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
+#endif
+    for (int i = tid; i < S; i += PHD_T) {
+        const v4f a = recA[i], b = recB[i];
+        const int c = __float_as_int(b.w);
+        if (c >= K) continue;
+        const v4f ci = cinfo[c];
+        const int Fw = fx_field(ci.z);
+        if (__float_as_int(ci.w) == i) {
+            // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
+            const float dself = HELLINGER ? hellinger_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z)
+                                          : mahal_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z);
+            if (!(dself < T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+        }
+        FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
+        fx_add_first(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
+        LDS_T(i64)* const q = acc + 6 * c;
+        __hip_atomic_fetch_add(q + 0, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 1, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 2, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 3, fs.yh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 4, fs.yl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&acc32[12 * c + 10], (u32)fs.ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!fs.ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    STAMP(8);
+    // per cluster: W, mean (:2828), the stop rule (:2821); the slot becomes (cxx, cxy, cyy, W | mean x, mean y, scales, flags)
+    for (int c = tid; c < K; c += PHD_T) {
+        FxSums fs;
+        fs.W = acc[6 * c + 0]; fs.xh = acc[6 * c + 1]; fs.xl = acc[6 * c + 2]; fs.yh = acc[6 * c + 3]; fs.yl = acc[6 * c + 4];
+        const u32 ec = acc32[12 * c + 10], fl = acc32[12 * c + 11];
+        const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
+        const int Fw = fx_field(cinfo[c].z);
+        // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then yields W == 0
+        int stop_at = 0x7FFFFFFF;
+        if (fs.W == 0 && ok) stop_at = c;
+        else if (!selfok) stop_at = c + 1;
+        if (stop_at != 0x7FFFFFFF) atomicMin((int*)&ctr[CTR_KOUT], stop_at);
+        float W, mx, my;
+        fx_mean(fs, Fw, W, mx, my);
+        const int Fc = fx_cov_anchor(Fw, (int)ec);
+        acc[6 * c + 0] = 0; acc[6 * c + 1] = 0; acc[6 * c + 2] = 0;
+        acc[6 * c + 3] = fs.W;
+        acc32[12 * c + 8] = __float_as_uint(mx); acc32[12 * c + 9] = __float_as_uint(my);
+        acc32[12 * c + 10] = (u32)Fc | ((u32)Fw << 16);
+        acc32[12 * c + 11] = (ok ? 0u : 1u) | (fl & 2u);
+        if (ok) { out_slab[0 * cap + c] = W; out_slab[1 * cap + c] = mx; out_slab[2 * cap + c] = my; }
+    }
+    __syncthreads();
+    STAMP(9);
+#ifdef PHD_DUP_MOMENTS
+    for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
+#endif
+    for (int i = tid; i < S; i += PHD_T) {
+        const v4f a = recA[i], b = recB[i];
+        const int c = __float_as_int(b.w);
+        if (c >= K) continue;
+        const v4f h = ((LDS_T(v4f)*)acc)[3 * c + 2];           // (mean x, mean y, scales, flags)
+        const u32 sc = __float_as_uint(h.z);
+        // (flag 2: the seed is not in its own cluster, decided in pass A)
+        if ((__float_as_uint(h.w) & 2u) && __float_as_int(cinfo[c].w) == i) continue;
+        bool ok = true;
+        i64 qxx, qxy, qyy;
+        fx_cov_terms((int)(sc & 0xFFFFu), h.x, h.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
+        LDS_T(i64)* const q = acc + 6 * c;
+        __hip_atomic_fetch_add(q + 0, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 1, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 2, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    // per cluster: covariance = sum / W (:2879; the symmetric form needs no force_symmetric_covariance)
+    for (int c = tid; c < K; c += PHD_T) {
+        const i64 cxx = acc[6 * c + 0], cxy = acc[6 * c + 1], cyy = acc[6 * c + 2], Wq = acc[6 * c + 3];
+        const u32 sc = acc32[12 * c + 10];
+        const int Fc = (int)(sc & 0xFFFFu), Fw = (int)(sc >> 16);
+        if (acc32[12 * c + 11] & 1u) {
+            const float bad = __builtin_nanf("");
+#pragma unroll
+            for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + c] = bad;
+        } else {
+            out_slab[3 * cap + c] = fx_cov(cxx, Wq, Fc, Fw);
+            out_slab[4 * cap + c] = fx_cov(cxy, Wq, Fc, Fw);
+            out_slab[5 * cap + c] = fx_cov(cyy, Wq, Fc, Fw);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // merge_small: the same greedy merge for S <= 256 survivors in ONE shot instead of rounds.
 //
 // With at most 256 survivors every position is a candidate seed, so the whole decision structure fits in
@@ -123,9 +234,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     for (int hb = 0; hb < nhb; ++hb) n_half += (2 * hb + 2 < ncu) ? 2 * hb + 2 : ncu;
     {
         static_assert(PHD_SMALL_S == 256, "merge_small uses four 64-bit words per row");
-        // (the rows are not cleared: every quarter a later phase reads — words lc <= k / 64 of the rows k < S — is written
-        //  below; the member masks are cleared here, they are first touched two barriers later)
-        for (int t = tid; t < PHD_SMALL_S * 4; t += PHD_T) L.scol[t] = 0ull;
+        // (the rows are not cleared: every quarter a later phase reads — words lc <= k / 64 of the rows k < S — is written below)
         if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
         LDS_T(u16)* srow16 = (LDS_T(u16)*)L.srow;
         for (int u0 = 2 * wave; u0 < n_half; u0 += 2 * PHD_NW) {
@@ -261,14 +370,20 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     }
     __syncthreads();
     if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
-    // ---- membership: every position joins the first seed of its row (a seed joins itself)
+    // ---- membership: every position joins the first seed of its row (a seed joins itself); its cluster index — the seeds
+    //      before its owner, i.e. the output position — goes into the record, the seed leaves the cluster's record
     const u64 s0 = L.sseed[0], s1 = L.sseed[1], s2 = L.sseed[2], s3 = L.sseed[3];
+    // (the rows and the member-mask area are dead after this pass: the sums' accumulators take the first 12 KB of the
+    //  16 KB they occupy, the cluster records the last 4 KB)
+    LDS_T(long long)* const acc = (LDS_T(long long)*)L.srow;
+    LDS_T(v4f)* const cinfo = (LDS_T(v4f)*)((lds_u8)L.srow + 48u * PHD_SMALL_S);
+    int owner = 0;
     bool is_seed = false;
     if (tid < S) {
         const int k = tid;
         const u64 sw = (k < 64) ? s0 : (k < 128) ? s1 : (k < 192) ? s2 : s3;
         is_seed = (sw >> (k & 63)) & 1ull;
-        int owner = k;
+        owner = k;
         if (!is_seed) {
             const int kbk = k >> 6;                  // words beyond the position's own block were never written
             const u64 m0 = L.srow[k * 4 + 0] & s0, m1 = (kbk >= 1) ? (L.srow[k * 4 + 1] & s1) : 0ull,
@@ -276,81 +391,30 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
             owner = m0 ? __builtin_ctzll(m0) : m1 ? 64 + __builtin_ctzll(m1) : m2 ? 128 + __builtin_ctzll(m2)
                                                                             : 192 + __builtin_ctzll(m3);
         }
-        atomicOr((u64*)&L.scol[owner * 4 + (k >> 6)], 1ull << (k & 63));
     }
-    if (tid == 0) L.ctr[CTR_KOUT] = 0x7FFFFFFF;
-    __syncthreads();
+    __syncthreads();                                  // every row has been read: the accumulators may overwrite them
+    if (tid < S) {
+        const int k = tid, o = owner;
+        const u64 below = (o & 63) ? (~0ull >> (64 - (o & 63))) : 0ull;
+        int c = 0;                                    // cluster index = seeds before the owner
+        c += (o >= 64) ? __popcll(s0) : __popcll(s0 & below);
+        if (o >= 64) c += (o >= 128) ? __popcll(s1) : __popcll(s1 & below);
+        if (o >= 128) c += (o >= 192) ? __popcll(s2) : __popcll(s2 & below);
+        if (o >= 192) c += __popcll(s3 & below);
+        ((LDS_T(int)*)&L.sB[k])[3] = c;
+        if (is_seed && c < cap) {
+            const v4f sa = L.sA[k];
+            cinfo[c] = (v4f){sa.x, sa.y, sa.w, __int_as_float(k)};
+        }
+    }
     if (STAMPS && tid == 0) {
         const u64 tq3 = __builtin_amdgcn_s_memrealtime();
         st[12] += tq1 - tq0; st[13] += tq2 - tq1; st[14] += tq3 - tq2; st[15] += 1;
     }
     STAMP(7);
-    STAMP(8);
-    STAMP(9);
-    // ---- moment matching: the thread that owns a seed, members in ascending position
+    // ---- moment matching by exact, order-free sums (moment_sums above)
     const int n_clusters = __popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3);
-    if (tid == 0) atomicMin((int*)&L.ctr[CTR_KOUT], n_clusters);   // the count is min(clusters, first stop): settled by the barrier below
-    if (is_seed) {
-#pragma clang fp contract(off)
-        const int k = tid;
-        const u64 below = (k & 63) ? (~0ull >> (64 - (k & 63))) : 0ull;
-        int c = 0; // cluster index = seeds before this one
-        c += (k >= 64) ? __popcll(s0) : __popcll(s0 & below);
-        if (k >= 64) c += (k >= 128) ? __popcll(s1) : __popcll(s1 & below);
-        if (k >= 128) c += (k >= 192) ? __popcll(s2) : __popcll(s2 & below);
-        if (k >= 192) c += __popcll(s3 & below);
-        u64 mem[4] = {L.scol[k * 4 + 0], L.scol[k * 4 + 1], L.scol[k * 4 + 2], L.scol[k * 4 + 3]};
-        const v4f sa = L.sA[k], sb = L.sB[k];
-        const float smx = sa.x, smy = sa.y, sxx = sb.x, sxy = sb.y, syy = sb.z;
-        const float dself = HELLINGER ? hellinger_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy)
-                                      : mahal_dist(smx, smy, sxx, sxy, syy, smx, smy, sxx, sxy, syy);
-        const bool selfok = dself < T;
-        if (!selfok) mem[k >> 6] &= ~(1ull << (k & 63)); // a seed that is not close to itself is not in its own cluster
-        // exact, order-free sums (phd_fixsum.h): anchored at the seed's weight, the seed's mean the origin of the offsets
-        const int Fw = fx_field(sa.w);
-        FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
-#pragma unroll
-        for (int wd = 0; wd < 4; ++wd) {
-            u64 m = mem[wd];
-            while (m) {
-                const int p = 64 * wd + __builtin_ctzll(m);
-                m &= m - 1;
-                const v4f pa = L.sA[p], pb = L.sB[p];
-                fx_add_first(fs, Fw, smx, smy, pa.w, pa.x, pa.y, pb.x, pb.y, pb.z);
-            }
-        }
-        // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then
-        // yields W == 0
-        int stop_at = 0x7FFFFFFF;
-        if (fs.W == 0 && fs.ok && fs.ec < 255) stop_at = c;
-        else if (!selfok) stop_at = c + 1;
-        if (stop_at != 0x7FFFFFFF) atomicMin((int*)&L.ctr[CTR_KOUT], stop_at);
-        if (!(fs.W == 0 && fs.ok && fs.ec < 255) && c < cap) {
-            float W, mx, my;
-            fx_mean(fs, Fw, W, mx, my);
-            const int Fc = fx_cov_anchor(Fw, fs.ec);
-            bool ok = fs.ok && fs.ec < 255;
-#pragma unroll
-            for (int wd = 0; wd < 4; ++wd) {
-                u64 m = mem[wd];
-                while (m) {
-                    const int p = 64 * wd + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const v4f pa = L.sA[p], pb = L.sB[p];
-                    i64 qxx, qxy, qyy;
-                    fx_cov_terms(Fc, mx, my, pa.w, pa.x, pa.y, pb.x, pb.y, pb.z, qxx, qxy, qyy, ok);
-                    fs.cxx += qxx; fs.cxy += qxy; fs.cyy += qyy;
-                }
-            }
-            const float bad = __builtin_nanf("");
-            out_slab[0 * cap + c] = ok ? W : bad;
-            out_slab[1 * cap + c] = ok ? mx : bad;
-            out_slab[2 * cap + c] = ok ? my : bad;
-            out_slab[3 * cap + c] = ok ? fx_cov(fs.cxx, fs.W, Fc, Fw) : bad;
-            out_slab[4 * cap + c] = ok ? fx_cov(fs.cxy, fs.W, Fc, Fw) : bad;
-            out_slab[5 * cap + c] = ok ? fx_cov(fs.cyy, fs.W, Fc, Fw) : bad;
-        }
-    }
+    moment_sums<HELLINGER, STAMPS>(L.sA, L.sB, S, n_clusters, cap, acc, cinfo, L.ctr, T, out_slab, tid, st);
     __syncthreads();
     STAMP(10);
 }
@@ -617,107 +681,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     }
 
     STAMP(7);
-    // ---- moment matching by exact, order-free sums (phd_fixsum.h) --------------------------------------------------
-    // The reference adds a cluster's members with a reduction tree (src/phdfilter.cu:2795-2881); round 2 grouped the
-    // survivors by seed with a second sort and walked each cluster sequentially.  Integer sums need neither: every
-    // survivor adds its terms to its cluster's accumulators with LDS atomics, in whatever order the lanes arrive.
-    //   A: weights, weighted means, the covariance scale (largest exponent)      -> per-cluster W, mean
-    //   B: weighted covariances about the merged mean                             -> per-cluster covariance
-    const int n_clusters = kbase;
-    const int K = n_clusters < cap ? n_clusters : cap;         // clusters past the map capacity are reported, not stored
-    LDS_T(i64)* const acc = L.acc;
-    LDS_T(u32)* const acc32 = (LDS_T(u32)*)L.acc;
-    if (tid == 0) { L.ctr[CTR_NHEAD] = n_clusters; L.ctr[CTR_KOUT] = n_clusters; }
-    for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-#ifdef PHD_DUP_MOMENTS
-    for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
-#endif
-    for (int i = tid; i < S; i += PHD_T) {
-        const v4f a = gA[i], b = gB[i];
-        const int c = __float_as_int(b.w);
-        if (c >= K) continue;
-        const v4f ci = L.cinfo[c];
-        const int Fw = fx_field(ci.z);
-        if (__float_as_int(ci.w) == i) {
-            // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
-            const float dself = HELLINGER ? hellinger_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z)
-                                          : mahal_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z);
-            if (!(dself < T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
-        }
-        FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
-        fx_add_first(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
-        LDS_T(i64)* const q = acc + 6 * c;
-        __hip_atomic_fetch_add(q + 0, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 1, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 2, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 3, fs.yh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 4, fs.yl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&acc32[12 * c + 10], (u32)fs.ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!fs.ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    STAMP(8);
-    // per cluster: W, mean (:2828), the stop rule (:2821); the slot becomes (cxx, cxy, cyy, W | mean x, mean y, scales, flags)
-    for (int c = tid; c < K; c += PHD_T) {
-        FxSums fs;
-        fs.W = acc[6 * c + 0]; fs.xh = acc[6 * c + 1]; fs.xl = acc[6 * c + 2]; fs.yh = acc[6 * c + 3]; fs.yl = acc[6 * c + 4];
-        const u32 ec = acc32[12 * c + 10], fl = acc32[12 * c + 11];
-        const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
-        const int Fw = fx_field(L.cinfo[c].z);
-        // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then yields W == 0
-        int stop_at = 0x7FFFFFFF;
-        if (fs.W == 0 && ok) stop_at = c;
-        else if (!selfok) stop_at = c + 1;
-        if (stop_at != 0x7FFFFFFF) atomicMin((int*)&L.ctr[CTR_KOUT], stop_at);
-        float W, mx, my;
-        fx_mean(fs, Fw, W, mx, my);
-        const int Fc = fx_cov_anchor(Fw, (int)ec);
-        acc[6 * c + 0] = 0; acc[6 * c + 1] = 0; acc[6 * c + 2] = 0;
-        acc[6 * c + 3] = fs.W;
-        acc32[12 * c + 8] = __float_as_uint(mx); acc32[12 * c + 9] = __float_as_uint(my);
-        acc32[12 * c + 10] = (u32)Fc | ((u32)Fw << 16);
-        acc32[12 * c + 11] = (ok ? 0u : 1u) | (fl & 2u);
-        if (ok) { out_slab[0 * cap + c] = W; out_slab[1 * cap + c] = mx; out_slab[2 * cap + c] = my; }
-    }
-    __syncthreads();
-    STAMP(9);
-#ifdef PHD_DUP_MOMENTS
-    for (int dup_ = 0; dup_ <= PHD_DUP_MOMENTS; ++dup_)
-#endif
-    for (int i = tid; i < S; i += PHD_T) {
-        const v4f a = gA[i], b = gB[i];
-        const int c = __float_as_int(b.w);
-        if (c >= K) continue;
-        const v4f h = ((LDS_T(v4f)*)acc)[3 * c + 2];           // (mean x, mean y, scales, flags)
-        const u32 sc = __float_as_uint(h.z);
-        // (flag 2: the seed is not in its own cluster, decided in pass A)
-        if ((__float_as_uint(h.w) & 2u) && __float_as_int(L.cinfo[c].w) == i) continue;
-        bool ok = true;
-        i64 qxx, qxy, qyy;
-        fx_cov_terms((int)(sc & 0xFFFFu), h.x, h.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
-        LDS_T(i64)* const q = acc + 6 * c;
-        __hip_atomic_fetch_add(q + 0, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 1, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 2, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    // per cluster: covariance = sum / W (:2879; the symmetric form needs no force_symmetric_covariance)
-    for (int c = tid; c < K; c += PHD_T) {
-        const i64 cxx = acc[6 * c + 0], cxy = acc[6 * c + 1], cyy = acc[6 * c + 2], Wq = acc[6 * c + 3];
-        const u32 sc = acc32[12 * c + 10];
-        const int Fc = (int)(sc & 0xFFFFu), Fw = (int)(sc >> 16);
-        if (acc32[12 * c + 11] & 1u) {
-            const float bad = __builtin_nanf("");
-#pragma unroll
-            for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + c] = bad;
-        } else {
-            out_slab[3 * cap + c] = fx_cov(cxx, Wq, Fc, Fw);
-            out_slab[4 * cap + c] = fx_cov(cxy, Wq, Fc, Fw);
-            out_slab[5 * cap + c] = fx_cov(cyy, Wq, Fc, Fw);
-        }
-    }
+    // ---- moment matching by exact, order-free sums (moment_sums above) ----
+    moment_sums<HELLINGER, STAMPS>(gA, gB, S, kbase, cap, L.acc, L.cinfo, L.ctr, T, out_slab, tid, st);
     __syncthreads();
     STAMP(10);
 }
