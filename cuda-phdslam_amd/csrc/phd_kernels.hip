@@ -62,6 +62,27 @@ size_t cphd_lds_bytes(int cn_len, int MM)
     return cphd_lds_layout(cn_len, MM, off);
 }
 
+// the last step of a particle's hand-off to the weights workgroup of the fused step: its hand-off stores (pose, indirection
+// reset, log-weight increment — relaxed agent-scope atomics by the same thread, i.e. sc1 write-through stores) must be
+// complete before the ticket counts the particle.  Two forms, A/B-measured (profiles/r03_ab_handoff.txt, tools/ab_bench.sh):
+//   default             drain this thread's stores (s_waitcnt vmcnt(0)), then a relaxed agent-scope increment
+//   -DPHD_HANDOFF_MM    the C++ memory-model form: a RELEASE increment here, an ACQUIRE fence after the consumer's poll.
+//                       The release at agent scope also writes back the XCD's L2 (buffer_wbl2 sc1) — needed for plain stores,
+//                       redundant for these write-through ones — which costs 1.4 us on the one-workgroup-per-CU critical path:
+//                       256 x 64 x 32 runs 53.3 k instead of 57.5 k steps/s (-7.9 %); 4096 x 256 x 64 is unchanged (2842 vs 2845).
+// The default therefore stays the drained form; what it relies on is that the compiler keeps the atomic stores, the asm
+// statement ("memory" clobber) and the atomic increment in program order — all three are volatile-like side effects it may
+// not reorder — and that sc1 stores are visible at agent scope once vmcnt has drained (cdna guide, Guideline 16).
+__device__ __forceinline__ void handoff_ticket(unsigned* ticket)
+{
+#ifdef PHD_HANDOFF_MM
+    __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // the fused update + prune + merge kernel
 // ------------------------------------------------------------------------------------------
@@ -95,6 +116,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > (1u << 24)) { ok = false; break; }   // ~seconds: never in practice
             }
+#ifdef PHD_HANDOFF_MM
+            // acquire: pairs with the release of every particle's ticket increment — what those workgroups stored before
+            // it (pose, indirection, log-weight increment) is visible to the loads below
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
             // time-out: the particles' workgroups are still adding to the ticket, so it is NOT reset here and the routine
             // does NOT run on incomplete data; the status bit makes the host fail the step and re-zero the ticket
             // (phd_device_status / phd_step_report)
@@ -338,8 +364,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         if (tid == 0) {
             if (FUSEW) { // as in the PHD branch below: the last hand-off store, then the ticket
                 __hip_atomic_store(&A.dlogw[p], Q.scal[CQ_LY0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                handoff_ticket(A.ticket);
             } else {
                 A.dlogw[p] = Q.scal[CQ_LY0];                                                         // .bak:2661-2667
                 if (A.raw_out) A.raw_out[p] = A.logw_in[p] + Q.scal[CQ_LY0];
@@ -369,8 +394,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (FUSEW) {
                 // the last of this particle's hand-off stores (pose: at the top; indirection: after the first barrier)
                 __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                handoff_ticket(A.ticket);
             } else A.dlogw[p] = dl;
             if (!FUSEW && A.raw_out) A.raw_out[p] = A.logw_in[p] + dl;                                // :3741-3744
         }

@@ -17,7 +17,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "phdslam.h"
@@ -372,9 +377,44 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
         // multi-node communicator the host creates later does not inherit a loopback-only bootstrap
         const bool had_if = getenv("NCCL_SOCKET_IFNAME") != nullptr;
         if (!had_if) setenv("NCCL_SOCKET_IFNAME", "lo", 1);
-        ncclResult_t r = ncclCommInitAll(comms.data(), world, devs.data());
+        // Communicator creation under a watchdog: a bootstrap that does not come back (seen once in round 2 on one box, before
+        // the first output line of `phdslam --devices 1`) becomes an error with a pointer to the diagnostics instead of a
+        // process that hangs forever.  PHD_RCCL_INIT_TIMEOUT = seconds (default 120; 0 = wait without limit).
+        struct InitJob {
+            std::vector<int> devs;
+            std::vector<ncclComm_t> comms;
+            ncclResult_t r = ncclSuccess;
+            bool done = false;
+            std::mutex mu;
+            std::condition_variable cv;
+        };
+        auto job = std::make_shared<InitJob>();
+        job->devs = devs;
+        job->comms.resize(world);
+        const char* te = getenv("PHD_RCCL_INIT_TIMEOUT");
+        const int timeout_s = te ? atoi(te) : 120;
+        std::thread([job, world]() {
+            const ncclResult_t rr = ncclCommInitAll(job->comms.data(), world, job->devs.data());
+            std::lock_guard<std::mutex> lk(job->mu);
+            job->r = rr;
+            job->done = true;
+            job->cv.notify_all();
+        }).detach();
+        ncclResult_t r = ncclSuccess;
+        bool timed_out = false;
+        {
+            std::unique_lock<std::mutex> lk(job->mu);
+            if (timeout_s > 0) timed_out = !job->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return job->done; });
+            else job->cv.wait(lk, [&] { return job->done; });
+            if (!timed_out) { r = job->r; comms = job->comms; }
+        }
         if (!had_if) unsetenv("NCCL_SOCKET_IFNAME");
-        if (r != ncclSuccess) rc = fail(PHD_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        (void)hipSetDevice(m->sh[0].device);
+        if (timed_out)
+            rc = fail(PHD_ERR_HIP, "ncclCommInitAll did not return within " + std::to_string(timeout_s) +
+                                   " s (PHD_RCCL_INIT_TIMEOUT): run with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,BOOTSTRAP to see where "
+                                   "the bootstrap waits; --shards on one device (device-copy transport) needs no communicator");
+        else if (r != ncclSuccess) rc = fail(PHD_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
         else for (int k = 0; k < world; ++k) m->sh[k].comm = comms[k];
     }
     if (rc != PHD_OK) {

@@ -477,7 +477,11 @@ def test_full_size_properties(cfg_id, sample):
             st = f.status()
             poses, lw = f.get_particles()
             maps = f.get_maps()
+            dlw = f.weight_increments()
+            surv_of = {}
             if rep == 0:
+                for p in np.arange(0, N, max(N // sample, 1))[:sample]:
+                    surv_of[int(p)] = f.survivors(int(p))
                 # merge conserves mass: sum of map weights == sum of survivor weights (+ untouched features)
                 for p in range(0, N, max(N // 64, 1)):
                     surv, _ = f.survivors(p)
@@ -486,14 +490,14 @@ def test_full_size_properties(cfg_id, sample):
                     # symmetric covariances, finite values
                     assert np.all(np.isfinite(maps[p]["weight"])) and np.all(maps[p]["cov"][:, 1] == maps[p]["cov"][:, 2])
             idx = f.resample(w["uniform"][0])
-            outs.append((poses, lw, maps, idx))
+            outs.append((poses, lw, maps, idx, dlw, surv_of))
         assert st["max_map"] <= 2 * G
     # determinism: two runs are bit-identical
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][3], outs[1][3])
     for x, y in zip(outs[0][2], outs[1][2]):
         assert np.array_equal(x, y)
-    poses, lw, maps, idx = outs[0]
+    poses, lw, maps, idx = outs[0][:4]
     assert abs(np.exp(lw.astype(np.float64)).sum() - 1) < 1e-4
     assert np.all(np.diff(idx) >= 0) and idx.min() >= 0 and idx.max() < N
     assert np.array_equal(idx, O.resample(lw, w["uniform"][0]))
@@ -501,24 +505,71 @@ def test_full_size_properties(cfg_id, sample):
     # (by the oracle's own margins) is compared structurally, and their NUMBER is asserted
     ref_poses = O.predict_ackerman(w["poses"], 0.05, 2.0, w["noise"][0], ocfg)
     picks = np.arange(0, N, max(N // sample, 1))[:sample]
-    n_ok, bad = compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, "cfg %d" % cfg_id)
-    print("config %d: %d of %d sampled particles structurally compared with the oracle" % (cfg_id, n_ok, len(picks)))
+    poses, lw, maps, idx, dlw, surv = outs[0]
+    n_ok, bad = compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, "cfg %d" % cfg_id, dlw=dlw, survivors=lambda p: surv[p])
+    print("config %d: %d of %d sampled particles structurally compared with the oracle (the rest: log-weight increment, survivor "
+          "set up to marginal members, mass / transport bound)" % (cfg_id, n_ok, len(picks)))
     assert not bad, bad
-    assert n_ok >= 0.5 * len(picks), "only %d of %d sampled particles were structurally comparable" % (n_ok, len(picks))
+    # floors: the counts observed on hardware (profiles/r03*_gpu_tests.log: 126/128, 100/128, 56/64) minus a small slack
+    floor = {2: 0.9, 3: 0.7, 4: 0.78}[cfg_id]
+    assert n_ok >= floor * len(picks), "only %d of %d sampled particles were structurally comparable" % (n_ok, len(picks))
+    # the normalised weights of ALL particles from the device's own increments (the oracle's sequential log-sum-exp)
+    ref_lw = O.normalize_weights(w["logw"], dlw)
+    raw_mag = float(np.abs(w["logw"].astype(np.float64) + dlw).max())
+    assert np.abs(lw - ref_lw).max() < 1e-5 + 2e-6 * np.abs(ref_lw).max() + 2.4e-7 * raw_mag * np.log2(N + 1)
 
 
-def compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, what):
-    """-> (number of particles compared structurally, list of failures).  A particle is compared when no prune decision
-    and no merge distance of the ORACLE's run came within fp noise of its threshold."""
+def map_transport_bound(a, b):
+    """a loose distance between two Gaussian mixtures that may differ by a few structural decisions (one merge more or less, a
+    component of weight ~ min_feature_weight more or less): (relative difference of the total mass, mass-weighted mean distance
+    from every component to the nearest component of the other mixture, both directions)"""
+    wa, wb = a["weight"].astype(np.float64), b["weight"].astype(np.float64)
+    ma, mb = a["mean"].astype(np.float64), b["mean"].astype(np.float64)
+    d = np.sqrt(((ma[:, None, :] - mb[None, :, :]) ** 2).sum(-1))
+    tr = max((wa * d.min(1)).sum() / wa.sum(), (wb * d.min(0)).sum() / wb.sum())
+    return abs(wa.sum() - wb.sum()) / wb.sum(), tr
+
+
+def compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, what, dlw=None, survivors=None):
+    """-> (number of particles compared structurally, list of failures).  EVERY picked particle is checked against the oracle:
+      * its log-weight increment (no structural decision in it), when `dlw` is given;
+      * its survivor set, when `survivors(p)` is given: equal where the oracle's prune margin is clear, otherwise equal up to
+        members whose weight is within PRUNE_MARGIN of min_feature_weight;
+      * its map: component by component where no prune decision and no merge distance of the ORACLE's run came within fp
+        noise of its threshold; otherwise bounded by total mass and mass-weighted nearest-component distance (a marginal
+        decision moves a few components, not the mixture)."""
     n_ok, bad = 0, []
+    minw = float(ocfg.minFeatureWeight)
     for p in picks:
-        ref = oracle_full_update(ref_poses[p], w["maps"][p, :w["sizes"][p]], w["z"][0], ocfg)
-        if ref["prune_margin"] > PRUNE_MARGIN and ref["margin"][0] > MERGE_MARGIN:
-            try:
+        gmap = w["maps"][p, :w["sizes"][p]]
+        ref = oracle_full_update(ref_poses[p], gmap, w["z"][0], ocfg)
+        try:
+            if dlw is not None:
+                assert abs(dlw[p] - ref["dlogw"]) < 2e-3 + 2e-4 * abs(ref["dlogw"]), \
+                    "%s particle %d: log-weight increment %g vs %g" % (what, p, dlw[p], ref["dlogw"])
+            clear = ref["prune_margin"] > PRUNE_MARGIN and ref["margin"][0] > MERGE_MARGIN
+            if survivors is not None:
+                surv, sidx = survivors(p)
+                if ref["prune_margin"] > PRUNE_MARGIN:
+                    assert np.array_equal(sidx, ref["slab_idx"]), "%s particle %d: survivor sets differ" % (what, p)
+                else:
+                    common, ia, ib = np.intersect1d(sidx, ref["slab_idx"], return_indices=True)
+                    only_dev = np.setdiff1d(np.arange(len(sidx)), ia)
+                    only_ref = np.setdiff1d(np.arange(len(ref["slab_idx"])), ib)
+                    assert np.all(np.abs(surv["weight"][only_dev] - minw) <= 2 * PRUNE_MARGIN * minw), \
+                        "%s particle %d: a survivor only the device keeps is not marginal" % (what, p)
+                    assert np.all(np.abs(ref["survivors"]["weight"][only_ref] - minw) <= 2 * PRUNE_MARGIN * minw), \
+                        "%s particle %d: a survivor only the oracle keeps is not marginal" % (what, p)
+                    assert_maps_close(surv[ia], ref["survivors"][ib], ordered=True, what="%s common survivors of particle %d" % (what, p))
+            if clear:
                 assert_maps_close(maps[p], ref["map"], what="%s particle %d" % (what, p))
                 n_ok += 1
-            except AssertionError as e:
-                bad.append(str(e))
+            else:
+                dm, tr = map_transport_bound(maps[p], ref["map"])
+                assert dm < 1e-3 and tr < 0.02, "%s particle %d (marginal decisions): mass differs by %g, transport %g m" % (what, p, dm, tr)
+                assert abs(len(maps[p]) - len(ref["map"])) <= 3, (what, p, len(maps[p]), len(ref["map"]))
+        except AssertionError as e:
+            bad.append(str(e))
     return n_ok, bad
 
 
@@ -527,7 +578,7 @@ def compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, what):
 # the merges — the instantiation bench.py times) against the staged, un-fused calls, bit for bit, on the BASELINE.json
 # workloads themselves, forced and nEff-triggered resampling; plus the oracle on a sample chosen by margin
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg_id,sample", [(2, 256), (3, 256), (5, 0)])
+@pytest.mark.parametrize("cfg_id,sample", [(2, 256), (3, 256), (5, 64)])
 def test_bench_path_at_bench_size(cfg_id, sample):
     P, S = pkg(), synthetic()
     w = S.config_workload(cfg_id, n_meas_sets=2)
@@ -551,6 +602,8 @@ def test_bench_path_at_bench_size(cfg_id, sample):
             b.update(w["z"][k])
             pb_pre, lb_pre = b.get_particles()
             maps_pre = b.get_maps() if k == 0 else None
+            dlw_pre = b.weight_increments() if k == 0 else None
+            cn_pre = b.cardinalities() if (k == 0 and cfg_id == 5) else None
             if force:
                 idx = b.resample(w["uniform"][k])
                 did = True
@@ -572,10 +625,26 @@ def test_bench_path_at_bench_size(cfg_id, sample):
                     assert np.array_equal(ma[j], maps_pre[idx[j]])
                 ref_poses = O.predict_ackerman(w["poses"], 0.05, 2.0, w["noise"][0], ocfg)
                 picks = np.arange(0, N, max(N // sample, 1))[:sample]
-                n_ok, bad = compare_maps_with_oracle(maps_pre, ref_poses, w, ocfg, picks, "cfg %d (bench path)" % cfg_id)
-                print("config %d bench path: %d of %d sampled particles structurally compared with the oracle" % (cfg_id, n_ok, len(picks)))
+                if cfg_id == 5:
+                    # the CPHD variant against its oracle at bench size: log-weight increment, cardinality row, and the map
+                    # bounded by mass and mass-weighted nearest-component distance (the CPHD oracle reports no decision
+                    # margins; tests/test_gpu_cphd.py compares survivors and merges component by component at small sizes)
+                    prior = np.full(256, -np.log(256.0), np.float32)
+                    for p in picks:
+                        ref = O.cphd_update_particle(ref_poses[p], w["maps"][p, :w["sizes"][p]], w["z"][0], ocfg, cfg.clutterRate, prior)
+                        assert abs(dlw_pre[p] - ref["dlogw"]) < 5e-3 + 2e-4 * abs(ref["dlogw"]), (p, dlw_pre[p], ref["dlogw"])
+                        live = ref["cn"] > -40
+                        assert np.allclose(cn_pre[p][live], ref["cn"][live], atol=1e-2), (p, np.abs(cn_pre[p][live] - ref["cn"][live]).max())
+                        dm, tr = map_transport_bound(maps_pre[p], ref["map"])
+                        assert dm < 2e-3 and tr < 0.02 and abs(len(maps_pre[p]) - len(ref["map"])) <= 3, (p, dm, tr, len(maps_pre[p]), len(ref["map"]))
+                    print("config 5 bench path: %d sampled particles compared with the CPHD oracle" % len(picks))
+                    continue
+                n_ok, bad = compare_maps_with_oracle(maps_pre, ref_poses, w, ocfg, picks, "cfg %d (bench path)" % cfg_id, dlw=dlw_pre)
+                print("config %d bench path: %d of %d sampled particles structurally compared with the oracle (the rest: log-weight "
+                      "increment, mass / transport bound)" % (cfg_id, n_ok, len(picks)))
                 assert not bad, bad
-                assert n_ok >= 0.25 * len(picks), (n_ok, len(picks))
+                # floors: the counts observed on hardware (255/256, 208/256) minus a small slack
+                assert n_ok >= {2: 0.9, 3: 0.7}[cfg_id] * len(picks), (n_ok, len(picks))
         sa, sb = a.status(), b.status()
         assert sa["max_survivors"] == sb["max_survivors"] and sa["max_map"] == sb["max_map"]
 
