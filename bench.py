@@ -208,7 +208,7 @@ def timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms, agree=None):
     return elapsed, gpu_region_ms, [pct(0.1), pct(0.5), pct(0.9)], preroll
 
 
-def make_filter(P, torch, cfg_id, n_local, G, M, n_global, offset, dev, local_rank):
+def make_filter(P, torch, cfg_id, n_local, G, M, n_global, offset, dev, local_rank, map_capacity=0, survivor_capacity=0):
     cfg = P.default_config(n_particles=n_global)
     if cfg_id == 5:                                           # BASELINE.json configs[4]: the CPHD variant
         cfg.filterType = 1
@@ -216,7 +216,8 @@ def make_filter(P, torch, cfg_id, n_local, G, M, n_global, offset, dev, local_ra
     # one stream for everything: the filter's kernels and (N > 1) the RCCL collectives torch enqueues
     ts = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(ts)
-    f = P.PhdFilter(cfg, n_particles=n_local, map_capacity=2 * G, max_measurements=M, device=local_rank, stream=ts.cuda_stream,
+    f = P.PhdFilter(cfg, n_particles=n_local, map_capacity=map_capacity or 2 * G, max_measurements=M,
+                    survivor_capacity=survivor_capacity, device=local_rank, stream=ts.cuda_stream,
                     global_particles=n_global, global_offset=offset)
     return f, ts
 
@@ -273,7 +274,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
     c = S.CONFIGS[cfg_id]
     N, G, M = c["N"], c["G"], c["M"]
     w = S.make_workload(N, G, M, seed=0x5EED0000 + cfg_id, clustered=c["clustered"])
-    f, ts = make_filter(P, torch, cfg_id, N, G, M, N, 0, dev, local_rank)
+    f, ts = make_filter(P, torch, cfg_id, N, G, M, N, 0, dev, local_rank, c.get("map_capacity", 0), c.get("survivor_capacity", 0))
     f.set_particles(w["poses"], w["logw"])
     f.set_maps(w["maps"], w["sizes"])
     d_z = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
@@ -349,7 +350,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
         del src_t, dst_t
 
     pair_ms = avg_ms[P._lib.K_UPDATE_MERGE]              # event pair around every launch (separate pass)
-    one_launch_per_step = cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0
+    one_launch_per_step = cnt[P._lib.K_WEIGHTS] == 0 and cnt[P._lib.K_PREDICT] == 0 and not c.get("survivor_capacity")
     # when the whole step is ONE launch of the dominant kernel (fused step), the events bracketing the timed
     # region give its average duration directly (launch-to-launch), free of the pair's marker packets
     ker_ms = gpu_region_ms / steps if one_launch_per_step else pair_ms
@@ -360,9 +361,16 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
         "ms_per_step": 1e3 * elapsed / steps,
         "ms_per_step_gpu_p10_p50_p90": pcts,
         "preroll_steps": preroll,
-        "config": {"workload": "BASELINE.json configs[%d]: %d particles x %d Gaussians/particle x %d meas/step%s, Ackerman motion, "
-                               "forced resample every step, frozen snapshot, whole step = ONE launch" %
-                               (cfg_id - 1, N, G, M, " (CPHD variant, max_cardinality 255)" if cfg_id == 5 else ""),
+        "config": {"workload": ("BASELINE.json configs[%d]: %d particles x %d Gaussians/particle x %d meas/step%s, Ackerman motion, "
+                                "forced resample every step, frozen snapshot, whole step = ONE launch" %
+                                (cfg_id - 1, N, G, M, " (CPHD variant, max_cardinality 255)" if cfg_id == 5 else "")) if cfg_id <= 5 else
+                               ("dense scan (not a BASELINE.json config): %d particles x %d Gaussians/particle x %d meas/step — the "
+                                "reference's measurement clamp (src/phdfilter.cu:3390-3394) on the merge-stress map; ~2 700 survivors per "
+                                "particle, past the 2 048 the LDS merge holds: every particle's merge runs in phd_merge_spill_kernel "
+                                "(survivor_capacity %d, map_capacity %d); update launch + spill-merge launch per step, forced resample, "
+                                "frozen snapshot" % (N, G, M, c["survivor_capacity"], c["map_capacity"])),
+                   "update_components_per_step": N * (G * (M + 1) + M),
+                   "ps_per_update_component": 1e12 * elapsed / steps / (N * (G * (M + 1) + M)),
                    "particles_total": N, "gaussians_per_particle": G, "measurements_per_step": M,
                    "one_launch_per_step": bool(one_launch_per_step),
                    "max_survivors": st["max_survivors"], "max_map": st["max_map"],
@@ -632,7 +640,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=0,
                     help="headline workload: 0 = the default (3 at N = 1: BASELINE.json configs[2]; 4 at N > 1: configs[3] sharded); "
-                         "2, 3, 5 (configs[1], [2], [4] = CPHD) at N = 1")
+                         "2, 3, 5 (configs[1], [2], [4] = CPHD) at N = 1; 6 = the dense-scan rider (4096 x 256 x 256, spill path)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0,
                     help="soft budget of the headline's cpu_baseline leg: bounds the thread scan; the 5 + 2 full timed steps always run (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
@@ -720,14 +728,16 @@ def main():
         res = run_single(P, S, torch, cfg_id, args.steps, args.warmup, 0.0 if args.bare else args.cpu_seconds, dev, local_rank,
                          args.preroll_ms, extras=not args.bare)
         if not args.no_secondary and not args.bare:
-            for sid in (2, 3, 5, 4):
+            for sid in (2, 3, 5, 4, 6):
                 if sid == cfg_id:
                     continue
                 # riders: shorter CPU leg, no copy-ceiling / stage pass (reported once, by the headline); configs[3]
                 # (16384 particles, the multi-GPU workload) on this ONE GPU is the N = 1 point of the strong-scaling curve
                 k = args.steps if sid != 2 else max(args.steps, 2000)   # 23 us steps: 2000 of them are 50 ms
-                r = run_single(P, S, torch, sid, k, max(args.warmup, 20 if sid != 2 else 200),
-                               0.0 if sid == 4 else min(args.cpu_seconds, 4.0), dev, local_rank, args.preroll_ms, extras=False)
+                if sid == 6:
+                    k = min(args.steps, 40)                            # 6.5 ms steps
+                r = run_single(P, S, torch, sid, k, max(args.warmup, 20 if sid != 2 else 200) if sid != 6 else 5,
+                               0.0 if sid in (4, 6) else min(args.cpu_seconds, 4.0), dev, local_rank, args.preroll_ms, extras=False)
                 r["steps"] = k
                 secondary.append(r)
         scaling = "weak"   # N = 1: a single point of either curve; per-GPU work is what the N > 1 line divides

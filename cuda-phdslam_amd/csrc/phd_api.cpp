@@ -72,6 +72,8 @@ struct phd_filter {
     float* spill_rec = nullptr;
     int* spill_meta = nullptr;
     unsigned short* spill_out = nullptr;
+    long long* spill_acc = nullptr;
+    int* spill_tmp = nullptr;
     int n_global = 0, global_offset = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -279,6 +281,8 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         A(dalloc(&f->spill_rec, (size_t)f->n_max * 2 * f->spill_cap * 8));
         A(dalloc(&f->spill_meta, (size_t)f->n_max * 8));
         A(dalloc(&f->spill_out, (size_t)f->n_max * f->cap));
+        A(dalloc(&f->spill_acc, (size_t)f->n_max * f->cap * 8));
+        A(dalloc(&f->spill_tmp, (size_t)f->n_max * f->spill_cap));
     }
     if (f->cphd) {
         A(dalloc(&f->cn[0], (size_t)f->n_max * f->cn_len)); A(dalloc(&f->cn[1], (size_t)f->n_max * f->cn_len));
@@ -336,7 +340,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
-    hipFree(f->spill_rec); hipFree(f->spill_meta); hipFree(f->spill_out);
+    hipFree(f->spill_rec); hipFree(f->spill_meta); hipFree(f->spill_out); hipFree(f->spill_acc); hipFree(f->spill_tmp);
     gm_workspace_destroy(f->gm);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     delete f;
@@ -748,6 +752,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
     }
     if (f->spill_cap) {
         a.spill_rec = f->spill_rec; a.spill_meta = f->spill_meta; a.spill_out = f->spill_out; a.spill_cap = f->spill_cap;
+        a.spill_acc = f->spill_acc; a.spill_tmp = f->spill_tmp;
     }
     a.cfg = f->dcfg;
     int free_pose = 0;

@@ -112,6 +112,8 @@ struct UpdateArgs {
     int* spill_meta;            // [n][8]: survivor count (0: the LDS merge handled the particle), n_update, n_out0, r1, input slab
     unsigned short* spill_out;  // [n][cap] indices of the untouched out-of-range features
     int spill_cap;              // records per particle
+    int* spill_tmp;             // [n][spill_cap]: bucket member lists of the spill merge's sort
+    long long* spill_acc;       // [n][cap][8]: per cluster six 64-bit words of exact moment sums + the seed's record (16 B)
     DevConfig cfg;
 };
 

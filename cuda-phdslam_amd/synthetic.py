@@ -19,6 +19,9 @@ CONFIGS = {
     3: dict(N=4096, G=256, M=64, clustered=True),
     4: dict(N=16384, G=256, M=64, clustered=True),
     5: dict(N=4096, G=256, M=64, clustered=True),   # CPHD variant (filter_type = 1, max_cardinality 255)
+    # not a BASELINE.json config: the densest scan the reference accepts (M clamped to 256, src/phdfilter.cu:3390-3394) on the
+    # merge-stress map — ~2 700 survivors per particle, past the 2 048 the LDS merge holds: every particle takes the spill path
+    6: dict(N=4096, G=256, M=256, clustered=True, map_capacity=768, survivor_capacity=4096),
 }
 
 SENSOR = dict(max_range=15.0, max_bearing=3.141593, std_range=0.25, std_bearing=0.008727)
