@@ -550,7 +550,8 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
     n_shards = len(devices)
     w = S.make_workload(N, G, M, seed=0x5EED0000 + cfg_id, clustered=c["clustered"])
     cfg = P.default_config(n_particles=N)
-    ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "gathered": MM.EXCHANGE_GATHERED}.get(os.environ.get("PHD_BENCH_EXCHANGE", ""), MM.EXCHANGE_AUTO)
+    ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "gathered": MM.EXCHANGE_GATHERED, "pull": MM.EXCHANGE_PULL}.get(
+        os.environ.get("PHD_BENCH_EXCHANGE", ""), MM.EXCHANGE_AUTO)
     m = MM.MultiFilter(cfg, n_shards=n_shards, devices=list(devices), map_capacity=2 * G, max_measurements=M, exchange=ex)
     m.set_particles(w["poses"], w["logw"])
     m.set_maps(w["maps"], w["sizes"])
@@ -611,12 +612,12 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
                                   "all-gather + global systematic resample + migration every step, frozen snapshot" %
                                   (cfg_id - 1, N, G, M, n_shards, n,
                                    ("RCCL (ncclCommInitAll over %d device(s))" % n_shards) if m.uses_rccl else "device copies (shards share a GPU)",
-                                   "gathered" if m.gathered else "alltoall"),
+                                   m.exchange),
                       "particles_total": N, "particles_per_shard": n, "gaussians_per_particle": G, "measurements_per_step": M,
                       "host": "C++ (libphdslam_multi.so)", "cpp_multi_host": True, "n_shards": n_shards, "devices": list(devices),
                       "rccl": m.uses_rccl, "rccl_ranks": n_shards if m.uses_rccl else 0,
                       "value_counts": "filter steps per second (K / wall time with every shard drained)",
-                      "multi_gpu_exchange": "gathered" if m.gathered else "alltoall",
+                      "multi_gpu_exchange": m.exchange,
                       "multi_gpu_phase_us_shard0": phases,
                       **({} if distinct else {"share_gpu_dry_run": True})},
            "roofline": roof, "roofline_valu": valu}
@@ -769,6 +770,34 @@ def main():
                     secondary.append(r1)
                 dist.barrier()
         scaling = "strong"  # total work (one 16384-particle filter) is fixed as N grows
+        # The headline of a launched N > 1 run is the C++ multi-device host as well (north_star: "host code stays C++"): rank 0
+        # drives all N devices of the node through libphdslam_multi.so (ncclCommInitAll over N devices, one stream per shard,
+        # one host thread) while the other ranks wait at a barrier; the one-process-per-GPU Python host measured above becomes
+        # a labelled secondary.  Skipped (the Python host stays the headline, with the reason) when rank 0 cannot see N
+        # devices, in the share-GPU / one-rank dry runs, or if the C++ host fails.
+        if world > 1 and not share and not one_rank and cfg_id == 4:
+            dist.barrier()
+            cpp, why = None, None
+            if rank == 0:
+                if torch.cuda.device_count() < world:
+                    why = "rank 0 sees %d device(s), needs %d" % (torch.cuda.device_count(), world)
+                else:
+                    try:
+                        cpp = run_cpp_multi(P, S, torch, cfg_id, args.steps, args.warmup, list(range(world)), args.preroll_ms)
+                    except Exception as e:                            # the scaling record must survive: fall back, say why
+                        why = "C++ host failed: %s" % (str(e)[:300],)
+                    torch.cuda.set_device(local_rank)
+            dist.barrier()
+            if rank == 0:
+                if cpp is not None:
+                    res["note"] = ("the same sharded step driven from Python (cuda-phdslam_amd/dist.py, one process per GPU over "
+                                   "torch.distributed): secondary to the C++ host of this line")
+                    res["steps"] = args.steps
+                    secondary.append(res)
+                    res = cpp
+                else:
+                    res["config"]["cpp_multi_host"] = False
+                    res["config"]["cpp_multi_host_skipped"] = why
 
     if multi:
         # RCCL prints a version banner through C stdio at communicator creation; on a pipe it stays in the C buffer until the
@@ -786,7 +815,7 @@ def main():
             "warmup": args.warmup,
             "preroll_steps": res["preroll_steps"],
             "ms_per_step": res["ms_per_step"],
-            "ms_per_step_gpu_p10_p50_p90": res["ms_per_step_gpu_p10_p50_p90"],
+            "ms_per_step_gpu_p10_p50_p90": res.get("ms_per_step_gpu_p10_p50_p90"),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

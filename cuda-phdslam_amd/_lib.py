@@ -135,6 +135,8 @@ SYMBOLS = {
     "phd_step_local_rows_dev": (_i, [_vp, Control, _vp, _vp, _i, _vp, _vp]),
     "phd_set_rows_target": (_i, [_vp, _vp]),
     "phd_global_resample_gathered": (_i, [_vp, _vp, _d, _i, _i, _i, _vp]),
+    "phd_peer_view_get": (_i, [_vp, _vp]),
+    "phd_global_resample_pull": (_i, [_vp, _vp, _i, _i]),
     "phd_set_frozen": (_i, [_vp, _i]),
     "phd_step_dev": (_i, [_vp, Control, _vp, _vp, _i, _d, _i]),
     "phd_sync": (_i, [_vp]),

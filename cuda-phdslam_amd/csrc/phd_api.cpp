@@ -1515,6 +1515,39 @@ extern "C" int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer)
     return PHD_OK; // stream-ordered: no host synchronisation
 }
 
+// copy_particles by direct reads of the owners' memory: see include/phdslam.h
+extern "C" int phd_peer_view_get(phd_filter* f, phd_peer_view* out)
+{
+    CHECK_F(f);
+    if (!out) return fail(PHD_ERR_INVALID_ARG, "phd_peer_view_get: null output");
+    out->maps = f->maps[f->cur];
+    out->counts = f->counts[f->cur];
+    out->parent = f->parent[f->pcur];
+    out->poses = f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur];
+    out->cn = f->cphd ? f->cn[f->cur] : nullptr;
+    return PHD_OK;
+}
+
+extern "C" int phd_global_resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank)
+{
+    CHECK_F(f);
+    if (world < 1 || world > PHD_MAX_PEERS || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
+        return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_pull: world/rank do not match the filter's shard");
+    if (!views) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_pull: null views");
+    const int n = f->n;
+    const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3; // a frozen fused predict parks the predicted poses in +1
+    HIPCHK(launch_resample_pull(views, world, f->idx, rank * n, n, rank, f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext],
+                                f->cap, f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
+                                f->frozen ? nullptr : f->parent[f->pcur ^ 1], f->cphd ? f->cn[f->cur ^ 1] : nullptr, f->cn_len,
+                                f->stream));
+    if (f->frozen) return PHD_OK; // bench protocol: the exchange ran, the snapshot stays
+    f->cur ^= 1;
+    f->pose_cur = (f->pose_cur + 1) % 3;
+    f->pcur ^= 1;
+    f->parent_dirty = false;
+    return PHD_OK; // stream-ordered: no host synchronisation
+}
+
 // The same exchange for SMALL shards without a host round trip (the "gathered" exchange): every rank all-gathers every
 // rank's whole shard — rows of phd_particle_pack_bytes, the un-normalised log-weight in header word 7 — and then
 // normalises, draws the (identical) global indices and takes its slots' parents straight out of the gathered rows.

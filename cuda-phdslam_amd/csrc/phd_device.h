@@ -126,6 +126,10 @@ hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, c
 int update_fuse_max_particles();
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
+#define PHD_MAX_PEERS 16        // shards whose memory one pull kernel can read (phd_global_resample_pull)
+hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n, int rank, float* dst,
+                                int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,
+                                float* cn_dst, int cn_len, hipStream_t st);
 hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st);   // no-op unless a.spill_rec
 hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman_control u,
                           const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,

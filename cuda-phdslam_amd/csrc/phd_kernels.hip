@@ -831,6 +831,56 @@ __global__ void phd_resample_end_kernel(const float* __restrict__ src, const int
         for (int i = tid; i < cn_len; i += blockDim.x) cn_dst[(size_t)j * cn_len + i] = cn[i];
 }
 
+// copy_particles after a global resample by direct reads of the owners' memory (phd_global_resample_pull): slot j of this
+// shard takes global particle g = idx[off + j], i.e. particle g mod n of shard g / n, through that shard's view.  Systematic
+// / stratified indices are non-decreasing, so the slots a remote parent fills are consecutive: phase 0 copies every local
+// parent and the FIRST slot of every remote one (the only reads that cross the link), phase 1 fills the other slots of a
+// remote parent from that first slot, which is local by then.  The tail of copy_particles rides along: weights <- -log N
+// (:327), the next step's indirection <- identity.
+struct PeerViews { phd_peer_view v[PHD_MAX_PEERS]; };
+__global__ void phd_resample_pull_kernel(PeerViews V, const int* __restrict__ idx, int off, int n, int rank, int phase,
+                                         float* __restrict__ dst, int* __restrict__ counts_dst, phd_pose* __restrict__ pose_dst,
+                                         int cap, float* __restrict__ logw_fill, float nlw, int* __restrict__ parent_next,
+                                         float* __restrict__ cn_dst, int cn_len)
+{
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int g = idx[off + j];
+    const int owner = g / n, lp = g - owner * n;
+    const bool remote = owner != rank;
+    const bool first = j == 0 || idx[off + j - 1] != g;
+    if (phase == 0 ? (remote && !first) : !(remote && !first)) return;
+    float* b = dst + (size_t)j * 6 * cap;
+    if (phase == 0) {
+        const phd_peer_view& P = V.v[owner];
+        const int s = P.parent ? P.parent[lp] : lp;
+        const int cnt = P.counts[s];
+        const float* a = P.maps + (size_t)s * 6 * cap;
+        if (tid < 6) ((float*)&pose_dst[j])[tid] = ((const float*)&P.poses[lp])[tid];
+        if (tid == 6) counts_dst[j] = cnt;
+        for (int pl = 0; pl < 6; ++pl)
+            for (int i = tid; i < cnt; i += blockDim.x) b[pl * cap + i] = a[pl * cap + i];
+        if (cn_dst)
+            for (int i = tid; i < cn_len; i += blockDim.x) cn_dst[(size_t)j * cn_len + i] = P.cn[(size_t)s * cn_len + i];
+    } else {
+        // the first slot this parent fills: lower bound of g in idx[off .. off + j)
+        int lo = 0, hi = j;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (idx[off + mid] < g) lo = mid + 1; else hi = mid; }
+        const int f0 = lo;
+        const int cnt = counts_dst[f0];
+        const float* a = dst + (size_t)f0 * 6 * cap;
+        if (tid < 6) ((float*)&pose_dst[j])[tid] = ((const float*)&pose_dst[f0])[tid];
+        if (tid == 6) counts_dst[j] = cnt;
+        for (int pl = 0; pl < 6; ++pl)
+            for (int i = tid; i < cnt; i += blockDim.x) b[pl * cap + i] = a[pl * cap + i];
+        if (cn_dst)
+            for (int i = tid; i < cn_len; i += blockDim.x) cn_dst[(size_t)j * cn_len + i] = cn_dst[(size_t)f0 * cn_len + i];
+    }
+    if (tid == 7) {
+        if (logw_fill) logw_fill[j] = nlw;
+        if (parent_next) parent_next[j] = j;
+    }
+}
+
 // copy_particles for the maps (src/slamtypes.h:313-333): dst[p] = src[parent[sel[p]]] (maps, counts, poses);
 // sel == NULL: identity; sel[p] < 0: slot is filled by phd_import_kernel instead
 __global__ void phd_gather_maps_kernel(const float* __restrict__ src, const int* __restrict__ counts_src,
@@ -1126,6 +1176,20 @@ hipError_t launch_resample_end(const float* src, const int* counts_src, const in
     hipLaunchKernelGGL(phd_resample_end_kernel, dim3(n), dim3(256), 0, st, src, counts_src, parent, pose_src, plan, n,
                        (const unsigned char*)recv, stride, dst, counts_dst, pose_dst, cap, logw_fill, nlw, parent_next, cn_src,
                        cn_dst, cn_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n, int rank, float* dst,
+                                int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,
+                                float* cn_dst, int cn_len, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (world > PHD_MAX_PEERS) return hipErrorInvalidValue;
+    PeerViews V = {};
+    for (int k = 0; k < world; ++k) V.v[k] = views[k];
+    for (int phase = 0; phase < (world > 1 ? 2 : 1); ++phase)
+        hipLaunchKernelGGL(phd_resample_pull_kernel, dim3(n), dim3(256), 0, st, V, idx, off, n, rank, phase, dst, counts_dst, pose_dst,
+                           cap, logw_fill, nlw, parent_next, cn_dst, cn_len);
     return hipGetLastError();
 }
 

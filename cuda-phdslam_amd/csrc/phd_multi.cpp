@@ -74,6 +74,7 @@ struct phd_multi {
     int world = 0, N = 0, n = 0, cap = 0, MM = 0;
     size_t pack = 0, gathered_limit = 32u << 20;
     bool rccl = false, gathered = false, frozen = false;
+    bool pull = false;                  // migrants are read straight out of the owners' slabs (phd_global_resample_pull)
     std::vector<Shard> sh;
     int32_t* h_idx = nullptr;           // pinned: the global resample indices (downloaded once per step from shard 0)
     int n_meas = 0;                     // of the resident inputs
@@ -139,7 +140,7 @@ int peer_consumed(phd_multi* m)
 // before a shard overwrites data its peers read in the previous exchange
 int peer_wait_consumed(phd_multi* m)
 {
-    if (m->rccl) return PHD_OK;
+    if (m->rccl && !m->pull) return PHD_OK;            // (RCCL collectives order themselves; direct peer reads do not)
     for (auto& s : m->sh) {
         HIPCHK(hipSetDevice(s.device));
         for (auto& o : m->sh)
@@ -263,6 +264,17 @@ int resample_stage(phd_multi* m, double uniform, bool from_raw)
         if (k == 0) d_idx0 = d_idx;
     }
     PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
+    if (m->pull) {
+        // no host round trip: every shard copies its slots' parents straight out of the owners' slabs.  Every owner's update
+        // is complete by now on every reader's stream (the all-gather of the log-weights that precedes this stage — an RCCL
+        // collective, or the event waits of the device-copy transport); the readers' `done` events keep the owners' next
+        // update from overwriting what is being read (peer_wait_consumed at the head of the next step).
+        std::vector<phd_peer_view> views((size_t)W);
+        for (int k = 0; k < W; ++k) PHDCHK(phd_peer_view_get(m->sh[k].f, &views[k]));
+        for (int k = 0; k < W; ++k) PHDCHK(phd_global_resample_pull(m->sh[k].f, views.data(), W, k));
+        PHDCHK(peer_consumed(m));
+        return t_mark(m, PHD_MULTI_PHASE_IMPORT);
+    }
     HIPCHK(hipSetDevice(m->sh[0].device));
     HIPCHK(hipMemcpyAsync(m->h_idx, d_idx0, (size_t)m->N * sizeof(int32_t), hipMemcpyDeviceToHost, m->sh[0].stream));
     HIPCHK(hipStreamSynchronize(m->sh[0].stream));
@@ -355,6 +367,21 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
         m->pack = phd_particle_pack_bytes(m->sh[0].f);
         m->gathered = o.exchange == PHD_EXCHANGE_GATHERED ||
                       (o.exchange == PHD_EXCHANGE_AUTO && (size_t)m->N * m->pack <= m->gathered_limit);
+        // direct reads of the other shards' slabs: peer access between every pair of distinct devices
+        bool peers = world <= 16;
+        for (int a = 0; a < world && peers; ++a)
+            for (int b = 0; b < world && peers; ++b) {
+                const int da = m->sh[a].device, db = m->sh[b].device;
+                if (da == db) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) { peers = false; break; }
+                if (hipSetDevice(da) != hipSuccess) { peers = false; break; }
+                const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
+                (void)hipGetLastError();
+            }
+        if (o.exchange == PHD_EXCHANGE_PULL && !peers) rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: PHD_EXCHANGE_PULL needs peer access between every pair of devices (at most 16 shards)");
+        m->pull = peers && (o.exchange == PHD_EXCHANGE_PULL || o.exchange == PHD_EXCHANGE_AUTO);
         for (auto& s : m->sh) {
             hipError_t e = hipSetDevice(s.device);
             if (e == hipSuccess) e = hipMalloc((void**)&s.allw, (size_t)m->N * sizeof(float));
@@ -451,6 +478,11 @@ extern "C" int phd_multi_n_shards(const phd_multi* m) { return m ? m->world : PH
 extern "C" int phd_multi_n_particles(const phd_multi* m) { return m ? m->N : PHD_ERR_INVALID_ARG; }
 extern "C" int phd_multi_uses_rccl(const phd_multi* m) { return m ? (m->rccl ? 1 : 0) : PHD_ERR_INVALID_ARG; }
 extern "C" int phd_multi_exchange_is_gathered(const phd_multi* m) { return m ? (m->gathered ? 1 : 0) : PHD_ERR_INVALID_ARG; }
+extern "C" int phd_multi_exchange(const phd_multi* m)
+{
+    if (!m) return PHD_ERR_INVALID_ARG;
+    return m->gathered ? PHD_EXCHANGE_GATHERED : (m->pull ? PHD_EXCHANGE_PULL : PHD_EXCHANGE_ALLTOALL);
+}
 extern "C" phd_filter* phd_multi_shard(phd_multi* m, int k) { return (m && k >= 0 && k < m->world) ? m->sh[k].f : nullptr; }
 
 extern "C" int phd_multi_seed(phd_multi* m, uint64_t seed)

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MULTI_LIB_PATH = os.path.join(_HERE, "libphdslam_multi.so")
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
-EXCHANGE_AUTO, EXCHANGE_GATHERED, EXCHANGE_ALLTOALL = 0, 1, 2
+EXCHANGE_AUTO, EXCHANGE_GATHERED, EXCHANGE_ALLTOALL, EXCHANGE_PULL = 0, 1, 2, 3
+EXCHANGE_NAMES = {1: "gathered", 2: "alltoall", 3: "pull"}
 
 
 class MultiOptions(C.Structure):
@@ -34,6 +35,7 @@ MULTI_SYMBOLS = {
     "phd_multi_n_particles": (_i, [_vp]),
     "phd_multi_uses_rccl": (_i, [_vp]),
     "phd_multi_exchange_is_gathered": (_i, [_vp]),
+    "phd_multi_exchange": (_i, [_vp]),
     "phd_multi_shard": (_vp, [_vp, _i]),
     "phd_multi_seed": (_i, [_vp, _u64]),
     "phd_multi_set_config": (_i, [_vp, C.POINTER(L.SlamConfig)]),
@@ -120,6 +122,11 @@ class MultiFilter:
     @property
     def gathered(self):
         return bool(mlib().phd_multi_exchange_is_gathered(self._h))
+
+    @property
+    def exchange(self):
+        """"gathered" | "pull" | "alltoall": how a resampling step moves particles between shards"""
+        return EXCHANGE_NAMES[mlib().phd_multi_exchange(self._h)]
 
     def seed(self, s):
         check(mlib().phd_multi_seed(self._h, int(s)), "phd_multi_seed")

@@ -331,6 +331,24 @@ int phd_step_local_rows_dev(phd_filter* f, phd_ackerman_control u, const phd_ack
 int phd_set_rows_target(phd_filter* f, void* d_rows);
 int phd_global_resample_gathered(phd_filter* f, const void* d_all_rows, double uniform, int world, int rank,
                                  int weights_in_rows, int32_t* idx_out);
+/* The same exchange with NO host round trip and no staging buffer, for shards whose memory the devices can read directly
+ * (one process: peer access over xGMI, or several shards on one device): after phd_global_resample_launch every shard holds
+ * the identical global indices ON THE DEVICE; phd_global_resample_pull enqueues copy_particles (src/slamtypes.h:313-333) for
+ * this shard's slots straight out of the owners' slabs — slot j <- particle idx[rank n + j] of shard idx / n, read through
+ * views[owner] (phd_peer_view_get of every shard, taken AFTER their update and BEFORE this call).  A remote parent crosses the
+ * link once per destination shard: the first of the (consecutive) slots it fills pulls it, the others copy from that slot.
+ * The caller orders the streams: every owner's update must be complete before the pull starts (the log-weight all-gather
+ * is such a point), and no owner may start its next update before every reader's pull is complete.
+ * Replaces phd_global_resample_plan + the all-to-all + phd_global_resample_end. */
+typedef struct {
+    const float* maps;        /* [n][6][cap] slabs holding the updated maps          */
+    const int32_t* counts;    /* [n]                                                 */
+    const int32_t* parent;    /* [n] slab indirection, or NULL (identity)            */
+    const phd_pose* poses;    /* [n] poses after the step's predict                  */
+    const float* cn;          /* CPHD: [n][cn_len] cardinality rows (same indirection), else NULL */
+} phd_peer_view;
+int phd_peer_view_get(phd_filter* f, phd_peer_view* out);
+int phd_global_resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank);
 
 /* ------------------------------------------------------------------------------------
  * Bench / steady-state protocol and instrumentation

@@ -32,7 +32,14 @@ extern "C" {
 typedef struct phd_multi phd_multi;
 
 enum { PHD_TRANSPORT_AUTO = 0, PHD_TRANSPORT_RCCL = 1, PHD_TRANSPORT_PEER_COPY = 2 };
-enum { PHD_EXCHANGE_AUTO = 0, PHD_EXCHANGE_GATHERED = 1, PHD_EXCHANGE_ALLTOALL = 2 };
+/* how a resampling step moves particles between shards:
+ *   GATHERED  whole shards in one in-place all-gather (small shards; no host round trip)
+ *   PULL      every shard reads its slots' parents straight out of the owners' slabs (peer access over xGMI; no host round
+ *             trip, no staging buffer, a remote parent crosses the link once per destination shard)
+ *   ALLTOALL  index download + host plan + export + ncclSend/ncclRecv pairs + import (one host round trip)
+ *   AUTO      GATHERED while n_particles * pack bytes <= gathered_limit_bytes, else PULL when every device pair has peer
+ *             access (always true for shards on one device), else ALLTOALL */
+enum { PHD_EXCHANGE_AUTO = 0, PHD_EXCHANGE_GATHERED = 1, PHD_EXCHANGE_ALLTOALL = 2, PHD_EXCHANGE_PULL = 3 };
 
 /* zero-initialise and set what you need (0 = default) */
 typedef struct {
@@ -54,6 +61,7 @@ int phd_multi_n_shards(const phd_multi* m);
 int phd_multi_n_particles(const phd_multi* m);           /* global */
 int phd_multi_uses_rccl(const phd_multi* m);             /* 1: RCCL collectives; 0: peer copies (shards share a device) */
 int phd_multi_exchange_is_gathered(const phd_multi* m);  /* the form a forced resample takes */
+int phd_multi_exchange(const phd_multi* m);              /* PHD_EXCHANGE_* in use (never AUTO) */
 phd_filter* phd_multi_shard(phd_multi* m, int k);        /* shard k's filter (inspection, tests) */
 int phd_multi_seed(phd_multi* m, uint64_t seed);
 int phd_multi_set_config(phd_multi* m, const phd_slam_config* cfg);

@@ -38,12 +38,12 @@ def run_single(cfg, w, steps, cap, M, device_rng, force_pattern):
     return out
 
 
-@pytest.mark.parametrize("shards,exchange", [(1, "gathered"), (1, "alltoall"), (2, "gathered"), (2, "alltoall"),
-                                             (4, "alltoall"), (8, "gathered")])
+@pytest.mark.parametrize("shards,exchange", [(1, "gathered"), (1, "alltoall"), (1, "pull"), (2, "gathered"), (2, "alltoall"),
+                                             (2, "pull"), (3, "pull"), (4, "alltoall"), (4, "pull"), (8, "gathered"), (8, "pull")])
 @pytest.mark.parametrize("device_rng", [False, True])
 def test_sharded_filter_equals_one_filter(shards, exchange, device_rng):
     P, S, MM = pkg(), synthetic(), mod()
-    N, G, M, steps = 64, 14, 9, 5
+    N, G, M, steps = (64, 14, 9, 5) if shards != 3 else (96, 14, 9, 5)
     w = S.make_workload(N, G, M, seed=300 + shards, n_meas_sets=steps)
     # a skewed weight vector so that the nEff trigger fires on some steps and not on others
     w["logw"] = (w["logw"] + np.linspace(0, 3.0, N).astype(np.float32)).astype(np.float32)
@@ -51,10 +51,10 @@ def test_sharded_filter_equals_one_filter(shards, exchange, device_rng):
     force = [True, False, False, True, False]
     ref = run_single(cfg, w, steps, 96, 16, device_rng, force)
     with MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=96, max_measurements=16,
-                        exchange=MM.EXCHANGE_GATHERED if exchange == "gathered" else MM.EXCHANGE_ALLTOALL) as m:
+                        exchange={"gathered": MM.EXCHANGE_GATHERED, "alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]) as m:
         assert m.n_shards == shards and m.n == N
         assert m.uses_rccl == (shards == 1)              # one shard: a one-rank RCCL communicator; more on one GPU: device copies
-        assert m.gathered == (exchange == "gathered")
+        assert m.gathered == (exchange == "gathered") and m.exchange == exchange
         m.seed(77)
         m.set_particles(w["poses"], w["logw"])
         m.set_maps(w["maps"], w["sizes"])

@@ -34,7 +34,7 @@ def main():
         G = int(rng.choice([1, 6, 14, 40]))
         M = int(rng.choice([1, 5, 9, 16]))
         steps = 4
-        exchange = str(rng.choice(["gathered", "alltoall"]))
+        exchange = str(rng.choice(["gathered", "alltoall", "pull"]))
         device_rng = bool(rng.integers(0, 2))
         over = dict(n_particles=N, resampleThresh=float(rng.choice([0.3, 0.6, 0.9])))
         if rng.random() < 0.3:
@@ -47,7 +47,7 @@ def main():
         try:
             ref = run_single(cfg, w, steps, cap, mm, device_rng, force)
             with MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=cap, max_measurements=mm,
-                                exchange=MM.EXCHANGE_GATHERED if exchange == "gathered" else MM.EXCHANGE_ALLTOALL) as m:
+                                exchange={"gathered": MM.EXCHANGE_GATHERED, "alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]) as m:
                 m.seed(77)
                 m.set_particles(w["poses"], w["logw"])
                 m.set_maps(w["maps"], w["sizes"])
