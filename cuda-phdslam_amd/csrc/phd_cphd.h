@@ -33,10 +33,11 @@ namespace phd {
 // ------------------------------------------------------------------------------------------
 struct CphdLds {
     lds_f32 cnq, cnp, lfact, lxi, I0, I1, lD, efull, cnb, scal;
+    lds_i32 kp;       // f64 sweeps: the block exponent of the parked row P_m
 };
 enum { CQ_LY0 = 0, CQ_LY1 = 1, CQ_R1 = 2 };
 
-__host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 off[10])
+__host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 off[11])
 {
     const u32 cn = align16u(4u * (u32)cn_len);
     const u32 lf = align16u(4u * (u32)((cn_len > MM + 1 ? cn_len : MM + 1) + 1));
@@ -52,19 +53,21 @@ __host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 
     off[7] = p; p += mm;  // efull
     off[8] = p; p += mm;  // cnb
     off[9] = p; p += 64u; // scal
+    off[10] = p; p += mm; // kp
     return p;
 }
 
 
 __device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
 {
-    u32 off[10];
+    u32 off[11];
     cphd_lds_layout(cn_len, MM, off);
     CphdLds Q;
     Q.cnq = (lds_f32)(base + off[0]); Q.cnp = (lds_f32)(base + off[1]); Q.lfact = (lds_f32)(base + off[2]);
     Q.lxi = (lds_f32)(base + off[3]); Q.I0 = (lds_f32)(base + off[4]); Q.I1 = (lds_f32)(base + off[5]);
     Q.lD = (lds_f32)(base + off[6]); Q.efull = (lds_f32)(base + off[7]); Q.cnb = (lds_f32)(base + off[8]);
     Q.scal = (lds_f32)(base + off[9]);
+    Q.kp = (lds_i32)(base + off[10]);
     return Q;
 }
 
@@ -294,6 +297,162 @@ __device__ __forceinline__ void cphd_esf_backward_dot(const CphdLds& Q, const fl
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 3: the two sweeps in DOUBLE for scans of up to 64 measurements (every BASELINE.json configuration).
+// The (float mantissa, int exponent) pairs above cost ~30 instructions per recursion step — align, add, renormalise for every
+// lane and every step — and each sweep is a chain of M dependent steps.  A double carries 11 bits of exponent itself: the
+// step is ONE fma per lane, P_{m+1}[a] = fma(xi_m, P_m[a-1], P_m[a]), and the range beyond 2^+-1023 is kept by a block
+// exponent per row, renormalised every sixteenth step (largest exponent of the row -> 2^0; entries 2^-1074 below the row's
+// largest flush to zero, far below anything a sum of 64 terms can see).  53-bit mantissas instead of 24: the oracle
+// (oracle/cphd_cpu.c) takes the same recursion in double and is no longer bit-identical to the device in the ESFs — the
+// two agree to ~1e-15 before the logarithm rounds to float.  The rows P_m are parked in LDS when the survivor arrays (idle
+// during this block) can hold them (M * 64 doubles <= 32 S bytes), else in the HBM scratch.
+// ------------------------------------------------------------------------------------------
+#define PHD_F64_RENORM 16      // steps between rescalings: a step grows a row by at most (1 + xi) < 2^40, 16 of them stay below 2^1023
+#define PHD_FW64 4             // waves that run the (cheap) backward recursion redundantly (one per SIMD), each taking every PHD_FW64-th inner product
+
+__device__ __forceinline__ double lane_up1(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = lane_up1((u32)b), hi = lane_up1((u32)(b >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_down1(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = lane_down1((u32)b), hi = lane_down1((u32)(b >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#define PHD_XD(k) { const u64 b = (u64)__double_as_longlong(v); const u32 lo = xor_lane_c<k>((u32)b), hi = xor_lane_c<k>((u32)(b >> 32)); \
+                    v += __longlong_as_double((long long)(((u64)hi << 32) | lo)); }
+    PHD_XD(32) PHD_XD(16) PHD_XD(8) PHD_XD(4) PHD_XD(2) PHD_XD(1)
+#undef PHD_XD
+    return v;
+}
+// biased exponent of a non-negative double (0 for zero / denormals)
+__device__ __forceinline__ int dexp_field(double v) { return (int)(((u64)__double_as_longlong(v) >> 52) & 0x7FFull); }
+// log of m 2^k for a positive double m, as a float (the form the float sweeps use: log of the mantissa + k ln 2)
+__device__ __forceinline__ float log_scaled(double v, int k)
+{
+    if (!(v > 0.0)) return -FLT_MAX;
+    int e = 0;
+    const double mant = frexp(v, &e);
+    return logf((float)mant) + (float)(e + k) * 0.69314718f;
+}
+
+// value of lane - 1 / lane + 1 with ZERO for the lane that has no such neighbour (DPP wave shifts, bound_ctrl)
+__device__ __forceinline__ double lane_up1_z(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = dpp_zero<0x138, 0xF>((u32)b), hi = dpp_zero<0x138, 0xF>((u32)(b >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_down1_z(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = dpp_zero<0x130, 0xF>((u32)b), hi = dpp_zero<0x130, 0xF>((u32)(b >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+// wave 0: forward sweep, rows P_m[0..m] parked as doubles (row m at rows + rs m) with their block exponent in Q.kp[m].
+// The sweep wave shares its SIMD with three others and gets a quarter of the issue slots whatever its priority, so the
+// time of the chain IS its instruction count: lane <-> a (P_m[a], a = 0..63; P_m[0] = 2^-kP sits in lane 0 and stays there,
+// because its shifted-in neighbour is zero), no masks (entries beyond a = m are exact zeros: 0 + xi * 0), unconditional
+// stores — one readlane, one convert, two DPP moves, one fma and one store per step.  P_M[64] (only M = 64 needs it, for
+// the full-set ESF) is xi_63 * P_63[63].  RowPtr: an LDS or a global pointer (a generic one would compile to flat stores).
+template <typename RowPtr>
+__device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowPtr rows, int rs, int M, int lane)
+{
+#pragma clang fp contract(off)
+    double P = lane == 0 ? 1.0 : 0.0;     // P_0 = [1]
+    double top = 0.0;                     // P_M[64]
+    int kP = 0;
+    const float xv = lane < M ? Q.lxi[lane] : 0.f;
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    for (int m0 = 0; m0 < M; m0 += PHD_F64_RENORM) {
+        if (lane < PHD_F64_RENORM && m0 + lane < M) Q.kp[m0 + lane] = kP;       // the block exponent of the next rows
+        const int m1 = (m0 + PHD_F64_RENORM < M) ? m0 + PHD_F64_RENORM : M;
+        for (int m = m0; m < m1; ++m) {
+            if (lane < rs) rows[(size_t)m * rs + lane] = P;                       // row m: P_m[0..m] (zeros beyond; rs >= M > m)
+            const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
+            if (m == 63) top = x * P;                                             // (lane 63 holds P_63[63])
+            P = __builtin_fma(x, lane_up1_z(P), P);                               // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
+        }
+        const int r = wave_max_i(dexp_field(P)) - 1023;                          // rescale: the row's largest exponent -> 0
+        P = __builtin_ldexp(P, -r);
+        top = __builtin_ldexp(top, -r);
+        kP += r;
+    }
+    // full set: log e_j = log P_M[j]
+    if (lane == 0) Q.efull[0] = 0.f;                                              // e_0 = 1
+    else if (lane <= M) Q.efull[lane] = log_scaled(P, kP);
+    if (M == 64 && lane == 63) Q.efull[64] = log_scaled(top, kP);
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __threadfence();
+}
+
+template <typename RowPtr>
+__device__ __forceinline__ void cphd_esf_backward_dot_f64(const CphdLds& Q, RowPtr rows, int rs, int M, int lane,
+                                                          int wave, float llam, float lam, LDS_T(double)* dsum, LDS_T(int)* dexp_)
+{
+#pragma clang fp contract(off)
+    if (wave >= PHD_FW64) return;
+    // T_M[a] = c_a = exp(I1[a]) lambda^(M-1-a) e^-lambda on a common block exponent kT
+    double T = 0.0;
+    int kf = -(1 << 28);
+    double frac = 0.0;
+    if (lane < M) {
+        const float Lg = Q.I1[lane] + ((float)(M - 1 - lane) * llam - lam);
+        if (Lg > -1e30f) {
+            const double t = (double)Lg * 1.4426950408889634;
+            const double kc = ceil(t);
+            frac = exp2(t - kc);                                     // in (0.5, 1]
+            kf = (int)kc;
+        }
+    }
+    int kT = wave_max_i(kf);
+    if (kT == -(1 << 28)) kT = 0;                                    // every c_a is zero
+    if (kf != -(1 << 28)) { const int d = kf - kT; T = d < -1100 ? 0.0 : __builtin_ldexp(frac, d); }
+    const float xv = lane < M ? Q.lxi[lane] : 0.f;
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    // this wave's inner products: m = M - 1 - wave - PHD_FW64 u; the row of the next one is requested a turn ahead.
+    // The recursion T_m[a] = T_{m+1}[a] + xi_m T_{m+1}[a+1] runs unmasked: the entries a >= m it also touches are never read
+    // again (their values stay finite between two rescalings, and the rescaling clears them).
+    int mnext = M - 1 - wave;
+    double prow = (mnext >= 0 && lane <= mnext) ? rows[(size_t)mnext * rs + lane] : 0.0;
+    int krow = mnext >= 0 ? Q.kp[mnext] : 0;
+    for (int m = M - 1; m >= 0; --m) {
+        if (m == mnext) {
+            // D_m = sum_{a=0..m} P_m[a] T_{m+1}[a]; the logarithm is taken after the sweep, by one thread per m
+            const double sm = wave_sum_d(prow * T);
+            if (lane == 0) { dsum[m] = sm; dexp_[m] = krow + kT; }
+            mnext = m - PHD_FW64;
+            prow = (mnext >= 0 && lane <= mnext) ? rows[(size_t)mnext * rs + lane] : 0.0;
+            krow = mnext >= 0 ? Q.kp[mnext] : 0;
+        }
+        if (m >= 1) {
+            const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
+            T = __builtin_fma(x, lane_down1_z(T), T);
+            if (((M - 1 - m) & (PHD_F64_RENORM - 1)) == PHD_F64_RENORM - 1) {
+                if (lane > m - 1) T = 0.0;                           // (entries the sweep no longer needs)
+                const int r = wave_max_i(dexp_field(T)) - 1023;
+                if (r > -1023) { T = __builtin_ldexp(T, -r); kT += r; }
+            }
+        }
+    }
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // barrier among a subset of the workgroup's waves (the hardware barrier counts all of them): an LDS arrival counter,
 // polled.  Every participating wave calls it the same number of times; `target` is its running arrival count.
 __device__ __forceinline__ void waves_sync(LDS_T(int)* ctr, int n_waves, int& target, int lane)
@@ -340,6 +499,93 @@ __device__ __forceinline__ void cphd_nsums_fast(const CphdLds& Q, int M, int Nma
     }
 }
 
+// eight per-lane maxima reduced over the wave in one transposing pass (the max twin of reduce8_over_wave, phd_pass1.h):
+// lane l ends with the wave maximum of a[l >> 3]
+__device__ __forceinline__ float max8_over_wave(float (&a)[8], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 4]), false, false);
+        a[i] = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 2]), false, false);
+        a[i] = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    }
+    const bool hi8 = (lane & 8) != 0;
+    const float keep = hi8 ? a[1] : a[0], send = hi8 ? a[0] : a[1];
+    float v = fmaxf(keep, __uint_as_float(dpp_mov<0x128, 0xF>(__float_as_uint(send), __float_as_uint(send))));   // row_ror:8
+    v = fmaxf(v, __uint_as_float(dpp_mov<0x141, 0xF>(__float_as_uint(v), __float_as_uint(v))));                  // row_half_mirror
+    v = fmaxf(v, __uint_as_float(dpp_mov<0x1B, 0xF>(__float_as_uint(v), __float_as_uint(v))));                   // quad_perm [3,2,1,0]
+    v = fmaxf(v, __uint_as_float(dpp_mov<0xB1, 0xF>(__float_as_uint(v), __float_as_uint(v))));                   // quad_perm [1,0,3,2]
+    return v;
+}
+
+// cphd_nsums_fast for cardinality rows of up to 256 entries with EIGHT j per trip: the two wave reductions of a log-sum-exp
+// (maximum, sum) are 2 x 18 instructions per j done one j at a time — more than the terms themselves; transposing
+// reductions do eight of each in ~22.  A wave takes the contiguous range [j_lo, j_hi) of j: the first eight this way, what
+// is left (two of the 66 values of a 64-measurement scan over seven waves) the plain way.  Same sums, another fixed tree.
+__device__ __forceinline__ void cphd_nsums_fast8(const CphdLds& Q, int M, int Nmax, int lane, int j_lo, int j_hi, float lWq)
+{
+#pragma clang fp contract(off)
+    const float LOG0F = -FLT_MAX;
+    int j0 = j_lo;
+    if (j_hi - j0 >= 8) {
+        float tv[8][4], mx[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q;
+            mx[q] = LOG0F;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = j + lane + 64 * c;
+                tv[q][c] = LOG0F;
+                if (n <= Nmax) { tv[q][c] = Q.cnq[n] - Q.lfact[n - j]; mx[q] = fmaxf(mx[q], tv[q][c]); }
+            }
+        }
+        const float mxw = max8_over_wave(mx, lane);                  // lane l: the maximum of j0 + (l >> 3)
+        float sacc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float m = lane_f(mxw, 8 * q);
+            sacc[q] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (j0 + q + lane + 64 * c <= Nmax) sacc[q] += __expf(tv[q][c] - m);
+        }
+        const float sw = reduce8_over_wave(sacc, lane);              // lane l: the sum of j0 + (l >> 3)
+        if ((lane & 7) == 0) {
+            const int j = j0 + (lane >> 3);
+            const float v = (j <= Nmax) ? (safe_log(sw) + mxw) - (float)j * lWq : LOG0F;
+            if (j <= M) Q.I0[j] = v;
+            if (j >= 1) Q.I1[j - 1] = v;
+        }
+        j0 += 8;
+    }
+    for (int j = j0; j < j_hi; ++j) {
+        float tv[4];
+        float mx = LOG0F;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = j + lane + 64 * c;
+            tv[c] = LOG0F;
+            if (n <= Nmax) { tv[c] = Q.cnq[n] - Q.lfact[n - j]; mx = fmaxf(mx, tv[c]); }
+        }
+        mx = wave_max_f(mx);
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (j + lane + 64 * c <= Nmax) sacc += __expf(tv[c] - mx);
+        sacc = wave_sum(sacc);
+        if (lane == 0) {
+            const float v = (j <= Nmax) ? (safe_log(sacc) + mx) - (float)j * lWq : LOG0F;
+            if (j <= M) Q.I0[j] = v;
+            if (j >= 1) Q.I1[j - 1] = v;
+        }
+    }
+}
+
 template <int CH>
 __device__ __forceinline__ void cphd_nsums(const CphdLds& Q, int M, int Nmax, int lane, int wave, int n_waves, float lWq, float lW1)
 {
@@ -374,12 +620,13 @@ __device__ __forceinline__ void cphd_nsums(const CphdLds& Q, int M, int Nmax, in
 __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const DevConfig& cfg, int M, int MM, int cn_len,
                                         const float* __restrict__ lfact_g, int lfact_len, const float* __restrict__ cn_prior,
                                         float* __restrict__ cn_out, float2* __restrict__ T_scratch, float w_all, float pdw,
-                                        int tid, u64* cq)
+                                        int tid, u64* cq, int S_cap, u64* stg = nullptr)
 {
 #pragma clang fp contract(off)
     // cq (diagnostic instantiation, thread 0): time of [staging + birth cardinality, forward sweep beside the cardinality work,
     // backward sweep + inner products, rest]
 #define CQSTAMP(k) do { if (cq && tid == 0) cq[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GSTAMP(k, t) do { if (stg && tid == (t)) stg[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
     CQSTAMP(0);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const int Nmax = cn_len - 1;
@@ -404,15 +651,43 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     const int tiles = (M + 63) >> 6;
     const bool finite_w = lWq > -1e29f && lW1 > -1e29f;     // (an empty map has Wq = 0, an empty map without births W1 = 0)
     CQSTAMP(1);
+    GSTAMP(29, 0);
+    // M <= 64: the sweeps in double (cphd_esf_*_f64); their rows live in the survivor arrays — idle until this block has
+    // produced the weights — when those hold M rows of 64 doubles, else in the HBM scratch (row stride MM)
+    const bool rows_in_lds = tiles == 1 && (size_t)32 * S_cap >= (size_t)M * 64 * 8;
+    LDS_T(double)* const rows_l = (LDS_T(double)*)L.w;
+    double* const rows_g = (double*)T_scratch;
     if (wave == 0) {
-        if (tiles == 1) cphd_esf_forward_park<1>(Q, T_scratch, M, lane);
+        if (tiles == 1 && rows_in_lds) cphd_esf_forward_park_f64(Q, rows_l, 64, M, lane);
+        else if (tiles == 1) cphd_esf_forward_park_f64(Q, rows_g, MM, M, lane);
         else if (tiles == 2) cphd_esf_forward_park<2>(Q, T_scratch, M, lane);
         else cphd_esf_forward_park<4>(Q, T_scratch, M, lane);
+        GSTAMP(16, 0);   // forward sweep done
     } else {
         LDS_T(int)* sctr = (LDS_T(int)*)&L.ctr[CTR_WSYNC];
         int target = 0;
         const int t7 = tid - 64, T7 = PHD_T - 64, w7 = wave - 1, W7 = PHD_NW - 1;
-        // predicted cardinality (.bak:518-545)
+        // predicted cardinality (.bak:518-545): prior (*) Binomial(M, birthWeight).  The log-domain form costs two passes of
+        // (two LDS reads, add, max | sub, exp, add) per term, 2 x 65 terms per n: 6 us.  In the LINEAR domain the convolution
+        // is one fma per term; doubles, scaled by the prior's maximum, keep everything within e^-700 of that maximum (what
+        // lies below is zero for every sum taken from these numbers) — when the idle zpart / I0 / I1 arrays can hold them.
+        const bool lin = (size_t)8 * cn_len <= (size_t)32 * MM;
+        if (lin) {
+            LDS_T(double)* const qd = (LDS_T(double)*)L.zpart;       // [cn_len] exp(prior - max)
+            LDS_T(double)* const bd = (LDS_T(double)*)Q.I0;          // [Kb + 1] Binomial pmf (I0 and I1 are written after this phase)
+            float qmax = -FLT_MAX;
+            for (int n = lane; n <= Nmax; n += 64) qmax = fmaxf(qmax, Q.cnq[n]);   // every wave the same maximum: no exchange
+            qmax = wave_max_f(qmax);
+            for (int n = t7; n <= Nmax; n += T7) qd[n] = Q.cnq[n] > -1e30f ? exp((double)(Q.cnq[n] - qmax)) : 0.0;
+            for (int k = t7; k <= Kb; k += T7) bd[k] = exp((double)Q.cnb[k]);
+            waves_sync(sctr, W7, target, lane);
+            for (int n = t7; n <= Nmax; n += T7) {
+                const int kmax = n < Kb ? n : Kb;
+                double s = 0.0;
+                for (int k = 0; k <= kmax; ++k) s = __builtin_fma(bd[k], qd[n - k], s);
+                Q.cnp[n] = s > 0.0 ? log_scaled(s, 0) + qmax : LOG0F;
+            }
+        } else
         for (int n = t7; n <= Nmax; n += T7) {
             const int kmax = n < Kb ? n : Kb;
             float mx = Q.cnb[0] + Q.cnq[n];
@@ -421,7 +696,9 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
             for (int k = 0; k <= kmax; ++k) s += __expf(Q.cnb[k] + Q.cnq[n - k] - mx);
             Q.cnp[n] = safe_log(s) + mx;
         }
+        GSTAMP(17, 64);  // predicted cardinality done (wave 1)
         waves_sync(sctr, W7, target, lane);
+        GSTAMP(18, 64);
         // I_u[j] = log sum_n p(n) P(n,j+u) Wq^(n-j-u) / W1^n.  Since P(n,j+1) Wq^(n-j-1) is the u = 0 term of j+1,
         // I_1[j] = I_0[j+1] (the same floating-point expression): one family J[j] = I_0[j], j = 0..M+1.
         // Wave per j, lanes over n; the terms stay in registers between the max and the sum pass (n <= 1023).
@@ -429,7 +706,13 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
         if (finite_w) {
             for (int n = t7; n <= Nmax; n += T7) Q.cnq[n] = Q.cnp[n] + Q.lfact[n] + (float)n * (lWq - lW1);   // B_n
             waves_sync(sctr, W7, target, lane);
-            if (cn_len <= 256) cphd_nsums_fast<4>(Q, M, Nmax, lane, w7, W7, lWq);
+            GSTAMP(19, 64);  // B_n done
+            if (cn_len <= 256) {
+                const int per = (M + 2 + W7 - 1) / W7;                // j = 0 .. M + 1 in contiguous ranges
+                const int jl = w7 * per, jh = (jl + per < M + 2) ? jl + per : M + 2;
+                if (per <= 16) cphd_nsums_fast8(Q, M, Nmax, lane, jl, jh, lWq);
+                else cphd_nsums_fast<4>(Q, M, Nmax, lane, w7, W7, lWq);
+            }
             else if (cn_len <= 512) cphd_nsums_fast<8>(Q, M, Nmax, lane, w7, W7, lWq);
             else cphd_nsums_fast<16>(Q, M, Nmax, lane, w7, W7, lWq);
         } else {
@@ -437,9 +720,11 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
             else if (cn_len <= 512) cphd_nsums<8>(Q, M, Nmax, lane, w7, W7, lWq, lW1);
             else cphd_nsums<16>(Q, M, Nmax, lane, w7, W7, lWq, lW1);
         }
+        GSTAMP(20, 64);      // n-sums done (wave 1)
     }
     __syncthreads();
     CQSTAMP(2);
+    GSTAMP(30, 0);
     // ESFs (.bak:1224-1272).  The .bak runs one full recursion per left-out measurement (O(M^3)); here
     //   e(Xi \ m) = P_m (*) S_{m+1}   (ESFs of the roots before and after m), so
     //   <Y1[Z\m],p> = sum_a P_m[a] T_{m+1}[a],  T_{m+1}[a] = sum_b S_{m+1}[b] c_{a+b},  c_j = exp(I1[j]) lambda^(M-1-j) e^-lambda
@@ -449,19 +734,56 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // one inner product per measurement.  Values span hundreds of decades, so each is a float mantissa with its own
     // integer exponent (m 2^k): align with v_ldexp, renormalise with v_frexp — exact operations around one correctly
     // rounded multiply and add (the oracle does the same).  Wave PHD_FW, idle in the sweep, takes <Y0,p> and <Y1,p>.
-    if (wave == PHD_FW) cphd_full_set(Q, M, lane, llam, lam);
-    if (tiles == 1) cphd_esf_backward_dot<1>(Q, T_scratch, M, lane, wave, llam, lam);
+    // (the inner products' sums and exponents wait in the — still unused — logZ / zpart arrays for their logarithms)
+    LDS_T(double)* const dsum = (LDS_T(double)*)L.zpart;
+    LDS_T(int)* const dexp_ = (LDS_T(int)*)L.logZ;
+    if (tiles != 1 && wave == PHD_FW) cphd_full_set(Q, M, lane, llam, lam);
+    if (tiles == 1) {
+        if (rows_in_lds) cphd_esf_backward_dot_f64(Q, (const LDS_T(double)*)rows_l, 64, M, lane, wave, llam, lam, dsum, dexp_);
+        else cphd_esf_backward_dot_f64(Q, (const double*)rows_g, MM, M, lane, wave, llam, lam, dsum, dexp_);
+        GSTAMP(21, 0);       // wave 0's share of the backward sweep done
+        GSTAMP(22, 192);     // wave 3's
+        if (wave == PHD_NW - 1) cphd_full_set(Q, M, lane, llam, lam);   // (after its share of the sweep: every wave takes part in it)
+    }
     else if (tiles == 2) cphd_esf_backward_dot<2>(Q, T_scratch, M, lane, wave, llam, lam);
     else cphd_esf_backward_dot<4>(Q, T_scratch, M, lane, wave, llam, lam);
     __syncthreads();
     CQSTAMP(3);
     const float lY0 = Q.scal[CQ_LY0];
+    if (tiles == 1) {
+        for (int m = tid; m < M; m += PHD_T) Q.lD[m] = log_scaled(dsum[m], dexp_[m]);       // log <Y1[Z \ m], p>
+        __syncthreads();                                                                  // (logZ aliases the exponents)
+    }
     for (int m = tid; m < M; m += PHD_T) L.logZ[m] = -((llam - lkap) + Q.lD[m] - lY0);      // .bak:1434-1437
     if (tid == 0) Q.scal[CQ_R1] = expf(Q.scal[CQ_LY1] - lY0);                               // .bak:1452-1455
     // updated cardinality (.bak:1409-1411): p(n) Y0(n) / <Y0,p>.  With B_n as above and a_j = log e_j + (M-j) log lambda
     // - lambda - j log Wq (in the cnb array, free by now) the term is B_n + a_j - log (n-j)!: the sum over j costs two LDS
     // reads and a subtraction per term
-    if (finite_w) {
+    if (finite_w && (size_t)8 * cn_len <= (size_t)32 * MM) {
+        // the same sum in the LINEAR domain (doubles): with a~_j = exp(a_j - max a) and the factorial ratio carried as a
+        // running product, sum_j exp(a_j - log (n-j)!) = exp(max a) / (n-jm)! * sum_j a~_j r_j,  r_jm = 1, r_{j-1} = r_j / (n-j+1)
+        // (jm = min(n, M): the largest term's factorial is the unit, every other ratio is below one) — a multiply and an fma
+        // per term instead of two passes with an exponential; 1/d comes from a table in the (idle again) zpart array
+        LDS_T(double)* const inv = (LDS_T(double)*)L.zpart;          // [cn_len] 1 / d
+        LDS_T(double)* const ad = (LDS_T(double)*)Q.I0;              // [M + 1] exp(a_j - max a) (I0 / I1 are consumed)
+        for (int j = tid; j <= M; j += PHD_T) Q.cnb[j] = Q.efull[j] + ((float)(M - j) * llam - lam) - (float)j * lWq;
+        for (int d = tid; d <= Nmax; d += PHD_T) inv[d] = d ? 1.0 / (double)d : 0.0;
+        __syncthreads();
+        float amax = -FLT_MAX;
+        for (int j = lane; j <= M; j += 64) amax = fmaxf(amax, Q.cnb[j]);     // every wave the same maximum
+        amax = wave_max_f(amax);
+        for (int j = tid; j <= M; j += PHD_T) ad[j] = Q.cnb[j] > -1e30f ? exp((double)(Q.cnb[j] - amax)) : 0.0;
+        __syncthreads();
+        for (int n = tid; n <= Nmax; n += PHD_T) {
+            const int jm = n < M ? n : M;
+            double r = 1.0, sd = ad[jm];
+            for (int j = jm - 1; j >= 0; --j) {
+                r *= inv[n - j];
+                sd = __builtin_fma(ad[j], r, sd);
+            }
+            cn_out[n] = sd > 0.0 ? Q.cnq[n] + ((log_scaled(sd, 0) + amax) - Q.lfact[n - jm]) - lY0 : LOG0F;
+        }
+    } else if (finite_w) {
         for (int j = tid; j <= M; j += PHD_T) Q.cnb[j] = Q.efull[j] + ((float)(M - j) * llam - lam) - (float)j * lWq;
         __syncthreads();
         for (int n = tid; n <= Nmax; n += PHD_T) {
@@ -492,6 +814,7 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     __syncthreads();
     CQSTAMP(4);
 #undef CQSTAMP
+#undef GSTAMP
 }
 
 } // namespace phd

@@ -58,7 +58,7 @@ size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).tot
 int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
 size_t cphd_lds_bytes(int cn_len, int MM)
 {
-    u32 off[10];
+    u32 off[11];
     return cphd_lds_layout(cn_len, MM, off);
 }
 
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         __syncthreads();
         cphd_block(L, Q, cfg, M, A.MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
                    A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid,
-                   STAMPS ? cq : nullptr);
+                   STAMPS ? cq : nullptr, S_cap, STAMPS ? st : nullptr);
         const float r1 = Q.scal[CQ_R1];
         // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
         for (int m0 = 0; m0 < M; m0 += PHD_T) {

@@ -115,6 +115,99 @@ static void esf_xf(const float* xi, int M, int skip, float* le)
     free(e);
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* The same recursions in DOUBLE with a block exponent per row (scans of up to 64 measurements; round 3).
+ * A step is one fused multiply-add per entry, e_j <- fma(xi_m, e_{j-1}, e_j); every sixteenth step the row is rescaled by a
+ * power of two so that its largest entry sits at 2^0 (exact; entries 2^-1074 below the largest flush to zero), the shift
+ * accumulated in an integer.  The device (cuda-phdslam_amd/csrc/phd_cphd.h, cphd_esf_*_f64) runs the same steps, the same
+ * rescaling schedule and the same fma; only the order of the 64-term sums of the inner products differs (a wave's
+ * butterfly there, index order here), i.e. agreement to ~1e-15 before the logarithm is rounded to float. */
+/* ------------------------------------------------------------------------------------ */
+#define F64_RENORM 16
+
+static int dexp_field(double v) { uint64_t b; memcpy(&b, &v, 8); return (int)((b >> 52) & 0x7FF); }
+
+static float log_scaled(double v, int k)
+{
+    if (!(v > 0.0)) return LOG0;
+    int e = 0;
+    const double mant = frexp(v, &e);
+    return logf((float)mant) + (float)(e + k) * 0.69314718f;
+}
+
+/* rescale row[0..n) so that its largest exponent becomes 0 (biased 1023); returns the shift taken out */
+static int row_renorm(double* row, int n)
+{
+    int r = 0;
+    for (int a = 0; a < n; a++) { const int f = dexp_field(row[a]); if (f > r) r = f; }
+    r -= 1023;
+    if (r <= -1023) return 0;                                        /* an all-zero row */
+    for (int a = 0; a < n; a++) row[a] = ldexp(row[a], -r);
+    return r;
+}
+
+/* log e_j(xi[0..M)), j = 0..M */
+static void esf_f64(const float* xi, int M, float* le)
+{
+    double P[66];
+    int kP = 0;
+    P[0] = 1.0;
+    for (int j = 1; j <= M; j++) P[j] = 0.0;
+    for (int m = 0; m < M; m++) {
+        for (int j = m + 1; j >= 1; j--) P[j] = fma((double)xi[m], P[j - 1], P[j]);
+        if ((m & (F64_RENORM - 1)) == F64_RENORM - 1) kP += row_renorm(P, M + 1);
+    }
+    le[0] = 0.f;
+    for (int j = 1; j <= M; j++) le[j] = log_scaled(P[j], kP);
+}
+
+/* lz[m] = -((llam - lkap) + log <Y1[Z\m],p> - lY0) for every m, prefix/suffix form in double */
+static void leave_one_out_f64(const float* xi, const float* I1, int M, float llam, float lam, float lkap, float lY0, float* lz)
+{
+    double* rows = (double*)malloc(sizeof(double) * (size_t)M * 65);
+    int kp[64];
+    double P[66];
+    int kP = 0;
+    P[0] = 1.0;
+    for (int j = 1; j <= M; j++) P[j] = 0.0;
+    for (int m = 0; m < M; m++) {                                    /* forward: park P_m[0..m] */
+        for (int a = 0; a <= m; a++) rows[(size_t)m * 65 + a] = P[a];
+        kp[m] = kP;
+        for (int j = m + 1; j >= 1; j--) P[j] = fma((double)xi[m], P[j - 1], P[j]);
+        if ((m & (F64_RENORM - 1)) == F64_RENORM - 1) kP += row_renorm(P, M + 1);
+    }
+    /* T_M[a] = c_a = exp(I1[a]) lambda^(M-1-a) e^-lambda on a common block exponent */
+    double T[65], frac[64];
+    int kf[64], kT = -(1 << 28);
+    for (int a = 0; a < M; a++) {
+        const float Lg = I1[a] + ((float)(M - 1 - a) * llam - lam);
+        kf[a] = -(1 << 28); frac[a] = 0.0;
+        if (Lg > -1e30f) {
+            const double t = (double)Lg * 1.4426950408889634;
+            const double kc = ceil(t);
+            frac[a] = exp2(t - kc);
+            kf[a] = (int)kc;
+        }
+        if (kf[a] > kT) kT = kf[a];
+    }
+    if (kT == -(1 << 28)) kT = 0;
+    for (int a = 0; a < M; a++) {
+        T[a] = 0.0;
+        if (kf[a] != -(1 << 28)) { const int d = kf[a] - kT; T[a] = d < -1100 ? 0.0 : ldexp(frac[a], d); }
+    }
+    T[M] = 0.0;
+    for (int m = M - 1; m >= 0; m--) {
+        double s = 0.0;
+        for (int a = 0; a <= m; a++) s += rows[(size_t)m * 65 + a] * T[a];
+        lz[m] = -((llam - lkap) + log_scaled(s, kp[m] + kT) - lY0);
+        if (m >= 1) {
+            for (int a = 0; a <= m - 1; a++) T[a] = fma((double)xi[m], T[a + 1], T[a]);
+            if (((M - 1 - m) & (F64_RENORM - 1)) == F64_RENORM - 1) kT += row_renorm(T, M);
+        }
+    }
+    free(rows);
+}
+
 /*
  * The cardinality-dependent terms of one particle's CPHD update.
  *   cn_prior[cn_len]  log cardinality before the births of this step
@@ -170,7 +263,8 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
         I1[j] = lse_n(t, c);
     }
     /* 4. full ESF, <Y0,p>, <Y1,p>;  (M-j)! p_K(M-j) = lambda^(M-j) e^-lambda for Poisson clutter (.bak:398-400) */
-    esf_xf(lxi, M, -1, e);
+    if (M <= 64 && !g_reference_esf) esf_f64(lxi, M, e);
+    else esf_xf(lxi, M, -1, e);
     for (int j = 0; j <= M; j++) t[j] = e[j] + I0[j] + ((float)(M - j) * llam - clutter_rate);
     const float lY0 = lse_n(t, M + 1);
     for (int j = 0; j <= M; j++) t[j] = e[j] + I1[j] + ((float)(M - j) * llam - clutter_rate);
@@ -184,6 +278,9 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
             const float lD = lse_n(t, M);
             lz[m] = -((llam - lkap) + lD - lY0);
         }
+    } else if (M <= 64) {
+        /* the O(M^2) prefix/suffix form below, in double with block exponents (what the device runs for M <= 64) */
+        leave_one_out_f64(lxi, I1, M, llam, clutter_rate, lkap, lY0, lz);
     } else {
         /* O(M^2): e(Xi \ m) = P_m (*) S_{m+1} (ESFs of the roots before and after m), hence
          *   <Y1[Z\m],p> = sum_a P_m[a] T_{m+1}[a],   T_{m+1}[a] = sum_b S_{m+1}[b] c_{a+b},

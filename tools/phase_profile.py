@@ -48,6 +48,11 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
             print("   CPHD block (inside 'pass1 normalisers'): staging + birth cardinality %.2f us, forward ESF sweep (wave 0) beside predicted "
                   "cardinality + n-sums (waves 1-7) %.2f us, backward sweep + inner products %.2f us, weights + cardinality update %.2f us"
                   % tuple(r[:, k].mean() * 0.01 for k in range(4)))
+            if st[:, 16].any():
+                # stamps of other waves (100 MHz), relative to the start of the concurrent phase / of the backward sweep
+                g = [((st[:, k] - st[:, 29]) * 0.01).mean() for k in range(16, 21)] + [((st[:, k] - st[:, 30]) * 0.01).mean() for k in (21, 22)]
+                print("   (us after the start of the concurrent phase) forward sweep done %.2f | predicted cardinality %.2f, sync %.2f, B_n %.2f, "
+                      "n-sums done %.2f | (us after the start of the backward phase) wave 0 done %.2f, wave 3 done %.2f" % tuple(g))
             continue
         print("   rounds: %.1f per particle; matrix %.2f us, resolve %.2f us, assign %.2f us (sums over rounds)" %
               (r[:, 3].mean(), r[:, 0].mean() * 0.01, r[:, 1].mean() * 0.01, r[:, 2].mean() * 0.01))
