@@ -811,6 +811,8 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
         }
         cn_out[n] = Q.cnp[n] + (safe_log(s) + mx) - lY0;
     }
+    // the bucket counts of the merge's counting sort (phd_lds.h): the `tr` plane held sweep rows until now
+    for (int b = tid; b < S_cap; b += PHD_T) ((LDS_T(u32)*)L.tr)[b] = 0u;
     __syncthreads();
     CQSTAMP(4);
 #undef CQSTAMP

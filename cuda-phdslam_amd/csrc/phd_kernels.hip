@@ -172,6 +172,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     STAMP(0);
 
     if (tid < 32) L.ctr[tid] = 0;
+    const BucketMap bm = bucket_map(cfg.minFeatureWeight, S_cap);   // the merge's counting sort counts at emission (phd_lds.h)
+    if (!CPHD) for (int b = tid; b < S_cap; b += PHD_T) ((LDS_T(u32)*)L.tr)[b] = 0u;   // (CPHD: the block below parks its rows here and clears afterwards)
     // measurements -> LDS (the reference keeps them in __constant__ Z[256], src/phdfilter.cu:120)
     for (int m = tid; m < M; m += PHD_T) {
         phd_measurement z = A.z[m];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                 const bool keep = (cls == 2) || (cls == 1 && !(wnd < cfg.minFeatureWeight));
                 const int slot = alloc_slots(keep, L.ctr);
                 if (keep) store_survivor(L, slot, S_cap, cls == 2 ? w : wnd, mx, my, pxx, pxy, pyy,
-                                         cls == 2 ? NEAR_U_BASE + i : nd_j, sp);
+                                         cls == 2 ? NEAR_U_BASE + i : nd_j, sp, bm);
             }
             n_in += tot_in; n_out0 += tot_out;
             __syncthreads();
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const bool keep = mv && !(wb < cfg.minFeatureWeight);
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
-                                     L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp);
+                                     L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp, bm);
         }
         // missed detections of the in-range features: w (1 - pd) r1 (.bak:1445-1460)
         for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const bool keep = jv && !(wnd < cfg.minFeatureWeight);
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) store_survivor(L, slot, S_cap, wnd, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i], in[4 * cap + i],
-                                     in[5 * cap + i], j, sp);
+                                     in[5 * cap + i], j, sp, bm);
         }
         // nearly-in-range features (pD = 0): weight w r1, join the merge unpruned like HEAD (:3242-3257)
         const int n_near = L.ctr[CTR_NNEAR];
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const int i = L.out_idx[cap - 1 - (kv ? k : 0)];
             const int slot = alloc_slots(kv, L.ctr);
             if (kv) store_survivor(L, slot, S_cap, in[0 * cap + i] * r1, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i],
-                                   in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i, sp);
+                                   in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i, sp, bm);
         }
         if (tid == 0) {
             if (FUSEW) { // as in the PHD branch below: the last hand-off store, then the ticket
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const bool keep = !(wb < cfg.minFeatureWeight);
         const int slot = alloc_slots(keep, L.ctr);
         if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
-                                 L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp);
+                                 L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp, bm);
     }
     {
         float lz_sum, pdw;
@@ -426,7 +428,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const bool keep = tv && !(w < cfg.minFeatureWeight);                                      // :2314
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
-                if (slot < S_cap) { L.w[slot] = w; L.u[slot] = n_in + m * n_in + j; }
+                if (slot < S_cap) {
+                    L.w[slot] = w; L.u[slot] = n_in + m * n_in + j;
+                    __hip_atomic_fetch_add((LDS_T(u32)*)L.tr + bucket_of(bm, w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 else {   // past the LDS capacity: the complete record goes to the spill list (no finalise pass there)
                     const v4f K = L.f_k[j], Pn = L.f_p[j];
                     spill_store(sp, L, slot, w, Pn.w + K.x * i0 + K.z * i1, L.f_my[j] + K.y * i0 + K.w * i1, Pn.x, Pn.y, Pn.z,
@@ -455,7 +460,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             // covariance are filled in by the dense finalise pass below, one lane per survivor
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
-                if (slot < S_cap) { L.w[slot] = w; L.u[slot] = n_in + m * n_in + j; }
+                if (slot < S_cap) {
+                    L.w[slot] = w; L.u[slot] = n_in + m * n_in + j;
+                    __hip_atomic_fetch_add((LDS_T(u32)*)L.tr + bucket_of(bm, w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 else {
                     const v4f K = L.f_k[jj], Pn = L.f_p[jj];
                     spill_store(sp, L, slot, w, Pn.w + K.x * i0 + K.z * i1, L.f_my[jj] + K.y * i0 + K.w * i1, Pn.x, Pn.y, Pn.z,
@@ -558,8 +566,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     // ---- merge ----------------------------------------------------------------------------------------
     const int n_update = n_in * (M + 1) + M;
     const bool packed = (n_update + n_map <= 0xFFFF) && (S_cap <= 0x10000);
-    if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed);
-    else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed);
+    if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
+    else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
     int k_out = L.ctr[CTR_KOUT];
     if (k_out > cap) { k_out = cap; status |= PHD_STATUS_MAP_OVERFLOW; }
     // append the untouched out-of-range features (src/phdfilter.cu:3311-3318)

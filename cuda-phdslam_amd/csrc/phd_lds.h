@@ -150,6 +150,35 @@ enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4,
        CTR_NCAND = 25 /* pass 1: terms listed for pass 2 */, CTR_WSYNC = 26 /* CPHD block: arrival counter of waves_sync */,
        CTR_NNEAR = 30 };
 
+// The merge's first sort is a counting sort on the weight key (phd_sort.h).  Its bucket of a survivor is a FIXED function of
+// the weight — the orderable bit pattern of a float is a log scale: (key(64) - key(w)) >> shift, clamped, with the shift
+// chosen from min_feature_weight so that the weights the prune lets through spread over the S buckets — so every emission
+// site counts its survivor's bucket as it stores it (one LDS atomic), and the sort starts from finished counts: no key pass,
+// no range reduction, no counting pass (two barriers less).  The counts live in the `tr` plane, unused until the sort.
+struct BucketMap { u32 kref; int shift; int nb; };
+__device__ __forceinline__ u32 orderable_key(float w)
+{
+    const u32 b = __float_as_uint(w);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ BucketMap bucket_map(float min_weight, int S)
+{
+    BucketMap m;
+    m.nb = S;
+    m.kref = orderable_key(64.f);
+    const float wlo = (min_weight > 1e-30f) ? min_weight * 0.125f : 1e-12f;
+    const u32 range = m.kref - orderable_key(wlo);
+    const int bits = 32 - __clz((int)range), lognb = 31 - __clz(S);
+    m.shift = bits > lognb ? bits - lognb : 0;
+    return m;
+}
+__device__ __forceinline__ int bucket_of(const BucketMap& m, float w)
+{
+    const u32 k = orderable_key(w);
+    const u32 d = k > m.kref ? 0u : (m.kref - k) >> m.shift;
+    return d < (u32)m.nb ? (int)d : m.nb - 1;
+}
+
 // append one survivor; slot allocation is wave-aggregated (one LDS atomic per wave per call site)
 __device__ __forceinline__ int alloc_slots(bool keep, lds_i32 ctr)
 {
@@ -185,12 +214,13 @@ __device__ __forceinline__ void spill_store(const SpillRef& sp, const Lds& L, in
 }
 
 __device__ __forceinline__ void store_survivor(const Lds& L, int slot, int S, float w, float mx, float my, float xx,
-                                               float xy, float yy, int u, const SpillRef& sp)
+                                               float xy, float yy, int u, const SpillRef& sp, const BucketMap& bm)
 {
     if (slot < S) {
         L.w[slot] = w; L.mx[slot] = mx; L.my[slot] = my;
         L.xx[slot] = xx; L.xy[slot] = xy; L.yy[slot] = yy;
         L.u[slot] = u;
+        __hip_atomic_fetch_add((LDS_T(u32)*)L.tr + bucket_of(bm, w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         spill_store(sp, L, slot, w, mx, my, xx, xy, yy, u);
     }

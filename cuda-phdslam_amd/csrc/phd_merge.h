@@ -425,7 +425,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
 // ------------------------------------------------------------------------------------------
 template <bool HELLINGER, bool STAMPS>
 __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv, const DevConfig& cfg, float* __restrict__ out_slab,
-                             int cap, int tid, u64* st, int n_update, bool packed)
+                             int cap, int tid, u64* st, int n_update, bool packed, const BucketMap& bm)
 {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
     const float T = cfg.minSeparation;
@@ -439,7 +439,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // ---- sort 1: (weight desc, slab index asc); leaves the survivors as the float4 arrays gA / gB ----
     int n_pad = 2;
     while (n_pad < S) n_pad <<= 1;
-    if (bucket_sort_survivors(L, S, S_cap, tid, lane, wave, n_update, Tpre, HELLINGER)) { /* counting sort did it */ }
+    if (bucket_sort_survivors(L, S, S_cap, tid, lane, wave, n_update, Tpre, HELLINGER, bm)) { /* counting sort did it */ }
     else {
         if (n_pad <= PHD_T) rank_sort_survivors(L, S, tid, n_update);
         else if (n_pad <= 2 * PHD_T) sort_survivors<2>(L, S, n_pad, tid, n_update, packed);

@@ -263,56 +263,13 @@ __device__ __forceinline__ void planes_to_aos(const Lds& L, int S, int tid, floa
 }
 
 // (writes the sorted survivors as the float4 arrays gA / gB — see Lds)
+// The bucket counts arrive finished in the `tr` plane: every emission site counted its survivor (store_survivor, phd_lds.h).
 __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S_cap, int tid, int lane, int wave, int n_update,
-                                                      float Tpre, bool hellinger)
+                                                      float Tpre, bool hellinger, const BucketMap& bm)
 {
-    lds_u32 cntc = L.pay;             // per bucket: count -> (placed << 16) | start
-    lds_u32 members = (lds_u32)L.u;   // bucket segments in arrival order (the slab indices live in the keys by then)
+    lds_u32 cntc = (lds_u32)L.tr;     // per bucket: count -> (placed << 16) | start
+    lds_u32 members = L.pay;          // bucket segments in arrival order
     const int NB = S_cap;             // buckets: a power of two >= 512
-    u32 mh[4], ml[4];
-    int bk[4];
-    u32 kmn = 0xFFFFFFFFu, kmx = 0u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = tid + e * PHD_T;
-        mh[e] = 0u; ml[e] = 0u; bk[e] = 0;
-        if (i < S) {
-            const int u0 = L.u[i];
-            mh[e] = orderable(L.w[i]);
-            ml[e] = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
-            L.khi[i] = mh[e]; L.klo[i] = ml[e];
-            kmn = mh[e] < kmn ? mh[e] : kmn;
-            kmx = mh[e] > kmx ? mh[e] : kmx;
-        }
-    }
-    for (int b = tid; b < NB; b += PHD_T) cntc[b] = 0u;
-    // workgroup range of the weight keys
-    {
-        u32 o;
-        o = xor_lane_c<32>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<32>(kmx); kmx = o > kmx ? o : kmx;
-        o = xor_lane_c<16>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<16>(kmx); kmx = o > kmx ? o : kmx;
-        o = xor_lane_c<8>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<8>(kmx); kmx = o > kmx ? o : kmx;
-        o = xor_lane_c<4>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<4>(kmx); kmx = o > kmx ? o : kmx;
-        o = xor_lane_c<2>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<2>(kmx); kmx = o > kmx ? o : kmx;
-        o = xor_lane_c<1>(kmn); kmn = o < kmn ? o : kmn; o = xor_lane_c<1>(kmx); kmx = o > kmx ? o : kmx;
-    }
-    if (lane == 0) { L.ctr[CTR_TMP + wave] = (int)kmn; L.ctr[CTR_TMP + PHD_NW + wave] = (int)kmx; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < PHD_NW; ++w) {
-        const u32 a = (u32)L.ctr[CTR_TMP + w], b = (u32)L.ctr[CTR_TMP + PHD_NW + w];
-        kmn = a < kmn ? a : kmn;
-        kmx = b > kmx ? b : kmx;
-    }
-    const u32 range = kmx - kmn;
-    const int bits = range ? 32 - __clz((int)range) : 0, lognb = 31 - __clz(NB);
-    const int shift = bits > lognb ? bits - lognb : 0;          // (range >> shift) < NB; bucket 0 holds the largest weights
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = tid + e * PHD_T;
-        if (i < S) { bk[e] = (int)((kmx - mh[e]) >> shift); atomicAdd((u32*)&cntc[bk[e]], 1u); }
-    }
-    __syncthreads();
     // exclusive scan over the buckets (thread t owns buckets [t per, (t + 1) per)), and the largest bucket
     {
         const int per = NB / PHD_T;                               // 1, 2 or 4
@@ -336,17 +293,27 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
             if (w < wave) woff += c;
             bmax = m > bmax ? m : bmax;
         }
-        if (bmax > 128u) { __syncthreads(); return false; }       // uniform
+        if (bmax > 128u) { __syncthreads(); return false; }       // uniform: crowded bucket (many equal weights) -> the network
         u32 run = woff + incl - local;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (e < per) { cntc[lo + e] = run; run += v[e]; }
     }
     __syncthreads();
+    // keys (weight | ~slab index) and the bucket segments
+    u32 mh[4], ml[4];
+    int bk[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = tid + e * PHD_T;
+        mh[e] = 0u; ml[e] = 0u; bk[e] = 0;
         if (i < S) {
+            const int u0 = L.u[i];
+            const float w = L.w[i];
+            mh[e] = orderable(w);
+            ml[e] = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
+            L.khi[i] = mh[e]; L.klo[i] = ml[e];
+            bk[e] = bucket_of(bm, w);
             const u32 old = atomicAdd((u32*)&cntc[bk[e]], 0x10000u);
             members[(old & 0xFFFFu) + (old >> 16)] = (u32)i;
         }
@@ -378,7 +345,7 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
         rw[e] = rmx[e] = rmy[e] = rxx[e] = rxy[e] = ryy[e] = 0.f;
         if (i < S) { rw[e] = L.w[i]; rmx[e] = L.mx[i]; rmy[e] = L.my[i]; rxx[e] = L.xx[i]; rxy[e] = L.xy[i]; ryy[e] = L.yy[i]; }
     }
-    __syncthreads(); // every read of the old order (and of the member lists, which sit in u) precedes the writes below
+    __syncthreads(); // every read of the old order (and of the counts, which sit in the tr plane) precedes the writes below
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = tid + e * PHD_T;
