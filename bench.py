@@ -776,7 +776,11 @@ def main():
         # a labelled secondary.  Skipped (the Python host stays the headline, with the reason) when rank 0 cannot see N
         # devices, in the share-GPU / one-rank dry runs, or if the C++ host fails.
         if world > 1 and not share and not one_rank and cfg_id == 4:
-            dist.barrier()
+            # the other ranks wait on the HOST (a gloo group): an RCCL barrier would keep a polling kernel resident on every
+            # GPU rank 0 is about to measure
+            host_group = dist.new_group(backend="gloo")
+            torch.cuda.synchronize()
+            dist.barrier(group=host_group)
             cpp, why = None, None
             if rank == 0:
                 if torch.cuda.device_count() < world:
@@ -787,7 +791,7 @@ def main():
                     except Exception as e:                            # the scaling record must survive: fall back, say why
                         why = "C++ host failed: %s" % (str(e)[:300],)
                     torch.cuda.set_device(local_rank)
-            dist.barrier()
+            dist.barrier(group=host_group)
             if rank == 0:
                 if cpp is not None:
                     res["note"] = ("the same sharded step driven from Python (cuda-phdslam_amd/dist.py, one process per GPU over "

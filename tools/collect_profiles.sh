@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the summaries of one tools/gpu_round.sh visit from gpurun_out/ (scratch) into profiles/ (tracked): bash tools/collect_profiles.sh <tag> [prefix]
-tag=${1:?tag}; pre=${2:-r02}
+tag=${1:?tag}; pre=${2:-r03}
 g=gpurun_out; p=profiles
 cp $g/pmc_traffic_cfg2.json $g/pmc_traffic_cfg3.json $g/pmc_sq_cfg2.json $g/pmc_sq_cfg3.json $p/
 cp $g/gpu_tests_$tag.log $p/${pre}_gpu_tests.log
@@ -15,4 +15,6 @@ for ex in gathered alltoall; do
   cp $g/bench_cfg2_onerank_${ex}_$tag.json $p/${pre}_bench_cfg2_onerank_rccl_python_host_$ex.json
   cp $g/bench_cfg2_cpp_multi_onerank_${ex}_$tag.json $p/${pre}_bench_cfg2_onerank_rccl_cpp_host_$ex.json
 done
+cp $g/bench_gpus2_$tag.json $p/${pre}_bench_gpus2_unlaunched_share_gpu.json
+for ex in pull alltoall; do cp $g/bench_cfg4_cpp_multi_onerank_${ex}_$tag.json $p/${pre}_bench_cfg4_onerank_rccl_cpp_host_$ex.json; done
 ls $p | wc -l

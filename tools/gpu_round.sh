@@ -24,7 +24,14 @@ python tools/phase_profile.py 2 3 5 > gpurun_out/phase_$tag.log 2>&1
 [ -n "$quick" ] && exit 0
 (python tools/e2e_run.py 256; python tools/e2e_run.py 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/e2e_$tag.log
 cat gpurun_out/e2e_$tag.log
-# the N > 1 paths on this one GPU: two ranks sharing device 0 (gloo transport) on the configs[3] split, one-rank RCCL
+# the N > 1 paths on this one GPU: `--gpus 2` with no launcher (the C++ multi-device host, both shards on device 0), two ranks
+# sharing device 0 under the launcher (gloo transport) on the configs[3] split, one-rank RCCL
+PHD_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 20 --warmup 5 2> gpurun_out/bench_gpus2_$tag.err | tail -1 > gpurun_out/bench_gpus2_$tag.json
+cut -c1-300 gpurun_out/bench_gpus2_$tag.json
+for ex in pull alltoall; do
+  PHD_BENCH_EXCHANGE=$ex PHD_BENCH_CPP_MULTI=1 python bench.py --config 4 --steps 100 --warmup 10 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_cpp_multi_onerank_${ex}_$tag.json
+  cut -c1-200 gpurun_out/bench_cfg4_cpp_multi_onerank_${ex}_$tag.json
+done
 PHD_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 2 --steps 5 --warmup 2 --preroll-ms 0 2> gpurun_out/bench_share2_$tag.err | grep metric > gpurun_out/bench_share2_$tag.json
 cut -c1-400 gpurun_out/bench_share2_$tag.json
