@@ -106,8 +106,8 @@ int main(int argc, char** argv)
     for (size_t k = 0; k < n_meas_steps; ++k) max_m = sizes[k] > max_m ? sizes[k] : max_m;
     if (n_devices > 0 || n_shards > 0) {
         // ---- the sharded filter (run_synth's loop, src/main.cpp:1178-1312, over include/phdslam_multi.h) ----
-        if (config.followTrajectory || config.nPredictParticles > 1 || config.filterType == 1 || log7) {
-            fprintf(stderr, "--devices: follow_trajectory, n_predict_particles > 1, filter_type = 1 and --log7 run on a single device\n");
+        if (config.followTrajectory || config.filterType == 1 || log7) {
+            fprintf(stderr, "--devices: follow_trajectory, filter_type = 1 and --log7 run on a single device\n");
             return 2;
         }
         if (n_devices <= 0) n_devices = 1;
@@ -121,13 +121,18 @@ int main(int argc, char** argv)
         mo.max_measurements = max_m < PHD_MAX_MEASUREMENTS ? max_m : PHD_MAX_MEASUREMENTS;
         phd_multi* m = nullptr;
         CHK(phd_multi_create(&config, &mo, &m));
-        const int N = config.n_particles;
-        printf("sharded filter: %d particles over %d shards on %d device(s), transport %s, exchange %s\n", N, n_shards, n_devices,
-               phd_multi_uses_rccl(m) ? "RCCL" : "device copies", phd_multi_exchange_is_gathered(m) ? "whole-shard all-gather" : "all-to-all");
-        std::vector<phd_pose> poses((size_t)N);
-        std::vector<float> logw((size_t)N);
+        const int N0 = config.n_particles;
+        // particle shotgun (n_predict_particles = k, src/phdfilter.cu:1185-1238): the set grows k-fold per predict, up to 5 n k
+        const int kshot_m = config.nPredictParticles > 1 ? config.nPredictParticles : 1;
+        const size_t N_max = (size_t)N0 * (kshot_m > 1 ? 5 * kshot_m : 1);
+        const int ex = phd_multi_exchange(m);
+        printf("sharded filter: %d particles over %d shards on %d device(s), transport %s, exchange %s\n", N0, n_shards, n_devices,
+               phd_multi_uses_rccl(m) ? "RCCL" : "device copies",
+               ex == PHD_EXCHANGE_GATHERED ? "whole-shard all-gather" : ex == PHD_EXCHANGE_PULL ? "direct reads of the owners' slabs" : "all-to-all");
+        std::vector<phd_pose> poses(N_max);
+        std::vector<float> logw(N_max);
         std::vector<phd_gaussian2d> map((size_t)mo.map_capacity), eap(4 * (size_t)mo.map_capacity);
-        std::vector<phd_ackerman_noise> noise((size_t)N);
+        std::vector<phd_ackerman_noise> noise(N_max);
         const std::string timefile = out_dir + "/loopTime.log";
         printf("STARTING SIMULATION\n");
         size_t z_idx = 0, c_idx = 0;
@@ -159,7 +164,9 @@ int main(int argc, char** argv)
                 // (subdivide_predict > 1: the extra predicts carry no scan)
                 const int sub = config.subdividePredict > 0 ? config.subdividePredict : 1;
                 for (int s = 0; s < sub; ++s) {
-                    for (int i = 0; i < N; ++i) {                                            // phdfilter.cu:1147-1152
+                    const int n_pred = phd_multi_n_particles_now(m) * kshot_m;               // one draw per PREDICTED particle
+                    if ((size_t)n_pred > N_max) { fprintf(stderr, "particle count would exceed 5 n_particles n_predict_particles\n"); return 1; }
+                    for (int i = 0; i < n_pred; ++i) {                                       // phdfilter.cu:1147-1152
                         noise[i].n_alpha = (float)(config.stdAlpha * randn());
                         noise[i].n_encoder = (float)(config.stdEncoder * randn());
                     }
@@ -177,6 +184,7 @@ int main(int argc, char** argv)
                 if (rc == PHD_ERR_NAN) { printf("nan weights detected! exiting...\n"); break; }
                 if (rc != PHD_OK) die("phd_multi_state_snapshot");
             }
+            const int N = phd_multi_n_particles_now(m);
             if ((config.mapEstimate & 2) && N > 1) {                                         // :363-379
                 int32_t n_eap = 0;
                 int rc = phd_multi_expected_map(m, eap.data(), (int)eap.size(), &n_eap);
@@ -189,7 +197,7 @@ int main(int argc, char** argv)
                 }
             }
             const double u = randu01();
-            const int did = (M > 0 && rep.neff <= config.resampleThresh) ? 1 : 0;            // :1286
+            const int did = ((M > 0 && rep.neff <= config.resampleThresh) || N > 5 * N0) ? 1 : 0;   // :1286
             if (did) CHK(phd_multi_resample(m, u));
             CHK(phd_write_state_log(out_dir.c_str(), n, &expected, map.data(), n_map, logw.data(), poses.data(), N, config.maxCardinality));
             gettimeofday(&t1, nullptr);

@@ -154,6 +154,12 @@ struct phd_filter {
     int64_t t_n[PHD_K_COUNT] = {0, 0, 0};
 };
 
+// a shard of a sharded filter whose particle set has grown (particle shotgun, n_predict_particles > 1): every shard grows by the
+// same factor, so the CURRENT global count and this shard's current offset follow from its own current count
+static int shard_world(const phd_filter* f) { return f->n_base > 0 ? std::max(f->n_global / f->n_base, 1) : 1; }
+static int ng_cur(const phd_filter* f) { return shard_world(f) * f->n; }
+static int off_cur(const phd_filter* f) { return f->n_base > 0 ? (f->global_offset / f->n_base) * f->n : 0; }
+
 static void fill_devcfg(const phd_slam_config& c, DevConfig& d)
 {
     d.dt = c.dt;
@@ -258,16 +264,18 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         f->own_stream = true;
     }
     const size_t slab = (size_t)f->n_max * 6 * f->cap;
+    // buffers that hold the GLOBAL particle set of a sharded filter: with the particle shotgun the global set grows like the shard
+    const size_t gmax = std::max<size_t>(std::max(f->n_max, f->n_global), (size_t)shard_world(f) * f->n_max);
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
     for (int k = 0; k < 2; ++k) { A(dalloc(&f->maps[k], slab)); A(dalloc(&f->counts[k], f->n_max)); }
     for (int k = 0; k < 3; ++k) { A(dalloc(&f->parent[k], f->n_max)); A(dalloc(&f->pose[k], f->n_max)); }
-    A(dalloc(&f->logw, f->n_max)); A(dalloc(&f->logw_alt, f->n_max)); A(dalloc(&f->logw_scratch, std::max(f->n_max, f->n_global)));
+    A(dalloc(&f->logw, f->n_max)); A(dalloc(&f->logw_alt, f->n_max)); A(dalloc(&f->logw_scratch, gmax));
     A(dalloc(&f->logw_raw, f->n_max)); A(dalloc(&f->dlogw, f->n_max));
     A(dalloc(&f->d_z, f->MM)); A(dalloc(&f->d_noise, f->n_max));
-    A(dalloc(&f->d_uniforms, std::max(f->n_max, f->n_global)));
-    A(dalloc(&f->cdf, std::max(f->n_max, f->n_global)));
-    A(dalloc(&f->idx, std::max(f->n_max, f->n_global)));
+    A(dalloc(&f->d_uniforms, gmax));
+    A(dalloc(&f->cdf, gmax));
+    A(dalloc(&f->idx, gmax));
     A(dalloc(&f->report, 8));
     f->status = f->report; f->max_surv = (int*)f->report + 1; f->max_map = (int*)f->report + 2;
     f->neff = (float*)f->report + 3; f->did = (int*)f->report + 4;
@@ -276,7 +284,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->d_plan, 2 * (size_t)f->n_max));
     A(hipHostMalloc((void**)&f->h_plan, 2 * (size_t)f->n_max * sizeof(int)));
     A(dalloc(&f->ticket, 1));
-    A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, std::max(f->n_max, f->n_global)));
+    A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, gmax));
     if (f->spill_cap) {
         A(dalloc(&f->spill_rec, (size_t)f->n_max * 2 * f->spill_cap * 8));
         A(dalloc(&f->spill_meta, (size_t)f->n_max * 8));
@@ -623,9 +631,11 @@ static int do_predict(phd_filter* f, phd_ackerman_control u, const phd_ackerman_
         if ((long long)f->n * k > f->n_max)
             return fail(PHD_ERR_CAPACITY, "particle count would exceed 5*n_particles*n_predict_particles: resample first (src/main.cpp:1286)");
         const int pnext = (f->pose_cur + 1) % 3;
+        DevConfig dc = f->dcfg;
+        dc.particleOffset = off_cur(f) * k;                 // a shard's first predicted particle in the GLOBAL predicted ordering
         t_begin(f, PHD_K_PREDICT);
         HIPCHK(launch_predict_shotgun(f->pose[f->pose_cur], f->pose[pnext], f->n * k, k, u, d_noise, f->seed, f->counter,
-                                      f->dcfg, f->parent[f->pcur], f->parent[f->pcur ^ 1], f->logw, f->logw_alt, f->stream));
+                                      dc, f->parent[f->pcur], f->parent[f->pcur ^ 1], f->logw, f->logw_alt, f->stream));
         t_end(f);
         f->counter++;
         f->pose_cur = pnext;
@@ -1229,7 +1239,7 @@ extern "C" int phd_step_local_dev(phd_filter* f, phd_ackerman_control u, const p
 extern "C" int phd_global_normalize(phd_filter* f, const float* d_all_logw, int n_global, float* neff_out)
 {
     CHECK_F(f);
-    if (n_global != f->n_global) return fail(PHD_ERR_INVALID_ARG, "phd_global_normalize: n_global mismatch");
+    if (n_global != ng_cur(f)) return fail(PHD_ERR_INVALID_ARG, "phd_global_normalize: n_global mismatch");
     WeightArgs w;
     memset(&w, 0, sizeof(w));
     w.logw_in = d_all_logw;
@@ -1245,7 +1255,7 @@ extern "C" int phd_global_normalize(phd_filter* f, const float* d_all_logw, int 
     HIPCHK(launch_weights(w, f->stream));
     t_end(f);
     if (!f->frozen)
-        HIPCHK(hipMemcpyAsync(f->logw, f->logw_scratch + f->global_offset, f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+        HIPCHK(hipMemcpyAsync(f->logw, f->logw_scratch + off_cur(f), f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
     if (neff_out) {
         HIPCHK(hipMemcpyAsync(neff_out, f->neff, sizeof(float), hipMemcpyDeviceToHost, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
@@ -1393,14 +1403,14 @@ static int ensure_send_buffer(phd_filter* f, size_t need)
 extern "C" int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_logw, double uniform, int32_t** d_idx_out)
 {
     CHECK_F(f);
-    const int ng = f->n_global;
+    const int ng = ng_cur(f);                     // (a grown set — particle shotgun — is resampled back to global_particles)
     WeightArgs w;
     memset(&w, 0, sizeof(w));
     w.u0 = uniform;
     w.logw_in = d_all_raw_logw ? d_all_raw_logw : f->logw_scratch;
     w.logw = f->logw_scratch;
     w.n = ng;
-    w.n_new = ng;
+    w.n_new = f->n_global;
     w.mode = (d_all_raw_logw ? WM_NORMALIZE : 0) | WM_RESAMPLE_FORCE;
     w.uniforms = f->d_uniforms;
     w.n_uniforms = 1;
@@ -1408,7 +1418,7 @@ extern "C" int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_
     w.idx_out = f->idx;
     w.neff_out = f->neff;
     w.did_resample = f->did;
-    w.n_weight_norm = ng;
+    w.n_weight_norm = f->n_global;
     t_begin(f, PHD_K_WEIGHTS);
     HIPCHK(launch_weights(w, f->stream));
     t_end(f);
@@ -1423,6 +1433,7 @@ extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int w
     if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
         return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_plan: world/rank do not match the filter's shard");
     if (!idx || !send_counts || !recv_counts || !d_send_buffer) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_plan: null argument");
+    if (f->n != f->n_base) return fail(PHD_ERR_UNSUPPORTED, "phd_global_resample_plan: a grown particle set (n_predict_particles > 1) migrates by phd_global_resample_pull");
     const int n = f->n, off = rank * n;
     f->plan_local_parent.assign(n, -1);
     f->plan_send.clear();
@@ -1531,16 +1542,19 @@ extern "C" int phd_peer_view_get(phd_filter* f, phd_peer_view* out)
 extern "C" int phd_global_resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank)
 {
     CHECK_F(f);
-    if (world < 1 || world > PHD_MAX_PEERS || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
+    if (world < 1 || world > PHD_MAX_PEERS || rank < 0 || rank >= world || f->n_global != f->n_base * world || f->global_offset != rank * f->n_base)
         return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_pull: world/rank do not match the filter's shard");
     if (!views) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_pull: null views");
-    const int n = f->n;
+    // n_src: particles every shard holds NOW (grown by the particle shotgun, the same factor everywhere); n_dst: what it holds
+    // after the resample (src/main.cpp:1289 resamples back to n_particles)
+    const int n_src = f->n, n_dst = f->n_base;
     const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3; // a frozen fused predict parks the predicted poses in +1
-    HIPCHK(launch_resample_pull(views, world, f->idx, rank * n, n, rank, f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext],
-                                f->cap, f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
+    HIPCHK(launch_resample_pull(views, world, f->idx, rank * n_dst, n_src, n_dst, rank, f->maps[f->cur ^ 1], f->counts[f->cur ^ 1],
+                                f->pose[pnext], f->cap, f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
                                 f->frozen ? nullptr : f->parent[f->pcur ^ 1], f->cphd ? f->cn[f->cur ^ 1] : nullptr, f->cn_len,
                                 f->stream));
     if (f->frozen) return PHD_OK; // bench protocol: the exchange ran, the snapshot stays
+    f->n = n_dst;
     f->cur ^= 1;
     f->pose_cur = (f->pose_cur + 1) % 3;
     f->pcur ^= 1;
@@ -1622,6 +1636,7 @@ extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_row
     if (world < 1 || rank < 0 || rank >= world || f->n_global != f->n * world || f->global_offset != rank * f->n)
         return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_gathered: world/rank do not match the filter's shard");
     if (!d_all_rows) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_gathered: null rows");
+    if (f->n != f->n_base) return fail(PHD_ERR_UNSUPPORTED, "phd_global_resample_gathered: a grown particle set (n_predict_particles > 1) migrates by phd_global_resample_pull");
     const int ng = f->n_global, n = f->n, off = rank * n;
     const size_t pack = phd_particle_pack_bytes(f);
     WeightArgs w;

@@ -127,7 +127,7 @@ int update_fuse_max_particles();
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
 #define PHD_MAX_PEERS 16        // shards whose memory one pull kernel can read (phd_global_resample_pull)
-hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n, int rank, float* dst,
+hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank, float* dst,
                                 int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,
                                 float* cn_dst, int cn_len, hipStream_t st);
 hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st);   // no-op unless a.spill_rec

@@ -846,6 +846,7 @@ __global__ void phd_resample_end_kernel(const float* __restrict__ src, const int
 // remote parent from that first slot, which is local by then.  The tail of copy_particles rides along: weights <- -log N
 // (:327), the next step's indirection <- identity.
 struct PeerViews { phd_peer_view v[PHD_MAX_PEERS]; };
+// (n: particles per OWNING shard — the divisor of the owner arithmetic; the grid is this shard's slot count)
 __global__ void phd_resample_pull_kernel(PeerViews V, const int* __restrict__ idx, int off, int n, int rank, int phase,
                                          float* __restrict__ dst, int* __restrict__ counts_dst, phd_pose* __restrict__ pose_dst,
                                          int cap, float* __restrict__ logw_fill, float nlw, int* __restrict__ parent_next,
@@ -1187,16 +1188,16 @@ hipError_t launch_resample_end(const float* src, const int* counts_src, const in
     return hipGetLastError();
 }
 
-hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n, int rank, float* dst,
+hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank, float* dst,
                                 int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,
                                 float* cn_dst, int cn_len, hipStream_t st)
 {
-    if (n <= 0) return hipSuccess;
+    if (n_dst <= 0) return hipSuccess;
     if (world > PHD_MAX_PEERS) return hipErrorInvalidValue;
     PeerViews V = {};
     for (int k = 0; k < world; ++k) V.v[k] = views[k];
     for (int phase = 0; phase < (world > 1 ? 2 : 1); ++phase)
-        hipLaunchKernelGGL(phd_resample_pull_kernel, dim3(n), dim3(256), 0, st, V, idx, off, n, rank, phase, dst, counts_dst, pose_dst,
+        hipLaunchKernelGGL(phd_resample_pull_kernel, dim3(n_dst), dim3(256), 0, st, V, idx, off, n_src, rank, phase, dst, counts_dst, pose_dst,
                            cap, logw_fill, nlw, parent_next, cn_dst, cn_len);
     return hipGetLastError();
 }

@@ -72,6 +72,7 @@ struct Shard {
 struct phd_multi {
     phd_slam_config cfg;
     int world = 0, N = 0, n = 0, cap = 0, MM = 0;
+    int kpred = 1, n_max = 0;          // particle shotgun (n_predict_particles): every shard's set grows k-fold per predict, up to n_max
     size_t pack = 0, gathered_limit = 32u << 20;
     bool rccl = false, gathered = false, frozen = false;
     bool pull = false;                  // migrants are read straight out of the owners' slabs (phd_global_resample_pull)
@@ -89,6 +90,9 @@ struct phd_multi {
 };
 
 namespace {
+
+// particles every shard holds NOW (n, or more between a shotgun predict and the resample that follows)
+int ncur(const phd_multi* m) { return phd_n_particles(m->sh[0].f); }
 
 // phase marks (timing pass only): an event on shard 0's stream; phase = what the span ENDING at this mark was
 int t_mark(phd_multi* m, int phase)
@@ -296,7 +300,12 @@ int update_stage(phd_multi* m, const phd_ackerman_control* u)
     std::vector<const void*> src(W);
     std::vector<void*> dst(W);
     for (int k = 0; k < W; ++k) {
-        if (u) PHDCHK(phd_step_local_dev(m->sh[k].f, *u, m->have_noise ? m->sh[k].d_noise : nullptr, m->sh[k].d_z, M));
+        if (u && m->kpred > 1) {
+            // particle shotgun (src/phdfilter.cu:1185-1238): the staged calls — the predict multiplies every shard's set by k
+            PHDCHK(phd_predict_ackerman_dev(m->sh[k].f, *u, m->have_noise ? m->sh[k].d_noise : nullptr));
+            PHDCHK(phd_update_local_dev(m->sh[k].f, m->sh[k].d_z, M));
+        }
+        else if (u) PHDCHK(phd_step_local_dev(m->sh[k].f, *u, m->have_noise ? m->sh[k].d_noise : nullptr, m->sh[k].d_z, M));
         else PHDCHK(phd_update_local_dev(m->sh[k].f, m->sh[k].d_z, M));                // no motion (step 0, src/main.cpp:1244)
         float* raw = nullptr;
         PHDCHK(phd_raw_logweights_dev(m->sh[k].f, &raw));
@@ -304,7 +313,7 @@ int update_stage(phd_multi* m, const phd_ackerman_control* u)
         dst[k] = m->sh[k].allw;
     }
     PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
-    PHDCHK(all_gather(m, src, dst, (size_t)m->n * sizeof(float)));
+    PHDCHK(all_gather(m, src, dst, (size_t)ncur(m) * sizeof(float)));
     return t_mark(m, PHD_MULTI_PHASE_ALL_GATHER);
 }
 
@@ -322,13 +331,13 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
     const int world = o.n_shards > 0 ? o.n_shards : ndev;
     if (cfg->n_particles <= 0 || cfg->n_particles % world)
         return fail(PHD_ERR_INVALID_ARG, "phd_multi_create: n_particles must be a positive multiple of the shard count");
-    if (cfg->nPredictParticles > 1)
-        return fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: the particle shotgun (n_predict_particles > 1) is single-device");
     phd_multi* m = new phd_multi();
     m->cfg = *cfg;
     m->world = world;
     m->N = cfg->n_particles;
     m->n = m->N / world;
+    m->kpred = cfg->nPredictParticles > 1 ? cfg->nPredictParticles : 1;
+    m->n_max = m->kpred > 1 ? 5 * m->n * m->kpred : m->n;        // as phd_create sizes a shard (src/main.cpp:1286: resample above 5 n)
     if (o.gathered_limit_bytes) m->gathered_limit = o.gathered_limit_bytes;
     m->sh.resize(world);
     bool distinct = true;
@@ -382,12 +391,17 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
             }
         if (o.exchange == PHD_EXCHANGE_PULL && !peers) rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: PHD_EXCHANGE_PULL needs peer access between every pair of devices (at most 16 shards)");
         m->pull = peers && (o.exchange == PHD_EXCHANGE_PULL || o.exchange == PHD_EXCHANGE_AUTO);
+        if (m->kpred > 1) {
+            // the particle shotgun on shards: the grown set is resampled back by the PULL exchange (the other forms pack n particles)
+            if (!m->pull) rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: n_predict_particles > 1 on shards needs the PULL exchange (peer access between the devices)");
+            m->gathered = false;
+        }
         for (auto& s : m->sh) {
             hipError_t e = hipSetDevice(s.device);
-            if (e == hipSuccess) e = hipMalloc((void**)&s.allw, (size_t)m->N * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void**)&s.allw, (size_t)world * m->n_max * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&s.recv, (size_t)std::max(m->n, 1) * m->pack);
             if (e == hipSuccess) e = hipMalloc((void**)&s.d_z, (size_t)m->MM * sizeof(phd_measurement));
-            if (e == hipSuccess) e = hipMalloc((void**)&s.d_noise, (size_t)m->n * sizeof(phd_ackerman_noise));
+            if (e == hipSuccess) e = hipMalloc((void**)&s.d_noise, (size_t)m->n_max * sizeof(phd_ackerman_noise));
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
             if (e != hipSuccess) { rc = fail(PHD_ERR_HIP, std::string("phd_multi_create: ") + hipGetErrorString(e)); break; }
@@ -476,6 +490,7 @@ extern "C" int phd_multi_destroy(phd_multi* m)
 
 extern "C" int phd_multi_n_shards(const phd_multi* m) { return m ? m->world : PHD_ERR_INVALID_ARG; }
 extern "C" int phd_multi_n_particles(const phd_multi* m) { return m ? m->N : PHD_ERR_INVALID_ARG; }
+extern "C" int phd_multi_n_particles_now(const phd_multi* m) { return m ? m->world * ncur(m) : PHD_ERR_INVALID_ARG; }
 extern "C" int phd_multi_uses_rccl(const phd_multi* m) { return m ? (m->rccl ? 1 : 0) : PHD_ERR_INVALID_ARG; }
 extern "C" int phd_multi_exchange_is_gathered(const phd_multi* m) { return m ? (m->gathered ? 1 : 0) : PHD_ERR_INVALID_ARG; }
 extern "C" int phd_multi_exchange(const phd_multi* m)
@@ -520,19 +535,21 @@ extern "C" int phd_multi_sync(phd_multi* m)
 extern "C" int phd_multi_set_particles(phd_multi* m, const phd_pose* poses, const float* log_weights, int n)
 {
     CHECK_M(m);
-    if (n != m->N) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_particles: n != n_particles");
+    const int nc = ncur(m);
+    if (n != m->world * nc) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_particles: n != the current particle count");
     for (int k = 0; k < m->world; ++k)
-        PHDCHK(phd_set_particles(m->sh[k].f, poses ? poses + (size_t)k * m->n : nullptr,
-                                 log_weights ? log_weights + (size_t)k * m->n : nullptr, m->n));
+        PHDCHK(phd_set_particles(m->sh[k].f, poses ? poses + (size_t)k * nc : nullptr,
+                                 log_weights ? log_weights + (size_t)k * nc : nullptr, nc));
     return PHD_OK;
 }
 
 extern "C" int phd_multi_get_particles(phd_multi* m, phd_pose* poses_out, float* log_weights_out)
 {
     CHECK_M(m);
+    const int nc = ncur(m);
     for (int k = 0; k < m->world; ++k)
-        PHDCHK(phd_get_particles(m->sh[k].f, poses_out ? poses_out + (size_t)k * m->n : nullptr,
-                                 log_weights_out ? log_weights_out + (size_t)k * m->n : nullptr));
+        PHDCHK(phd_get_particles(m->sh[k].f, poses_out ? poses_out + (size_t)k * nc : nullptr,
+                                 log_weights_out ? log_weights_out + (size_t)k * nc : nullptr));
     return PHD_OK;
 }
 
@@ -541,9 +558,10 @@ extern "C" int phd_multi_set_maps(phd_multi* m, const phd_gaussian2d* concat, co
     CHECK_M(m);
     if (!sizes) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_maps: null sizes");
     size_t off = 0;
+    const int nc = ncur(m);
     for (int k = 0; k < m->world; ++k) {
-        PHDCHK(phd_set_maps(m->sh[k].f, concat ? concat + off : nullptr, sizes + (size_t)k * m->n));
-        for (int p = 0; p < m->n; ++p) off += (size_t)sizes[(size_t)k * m->n + p];
+        PHDCHK(phd_set_maps(m->sh[k].f, concat ? concat + off : nullptr, sizes + (size_t)k * nc));
+        for (int p = 0; p < nc; ++p) off += (size_t)sizes[(size_t)k * nc + p];
     }
     return PHD_OK;
 }
@@ -552,21 +570,22 @@ extern "C" int phd_multi_get_map_sizes(phd_multi* m, int32_t* sizes_out)
 {
     CHECK_M(m);
     if (!sizes_out) return fail(PHD_ERR_INVALID_ARG, "null output");
-    for (int k = 0; k < m->world; ++k) PHDCHK(phd_get_map_sizes(m->sh[k].f, sizes_out + (size_t)k * m->n));
+    for (int k = 0; k < m->world; ++k) PHDCHK(phd_get_map_sizes(m->sh[k].f, sizes_out + (size_t)k * ncur(m)));
     return PHD_OK;
 }
 
 extern "C" int phd_multi_get_maps(phd_multi* m, phd_gaussian2d* concat_out, size_t concat_capacity, int32_t* sizes_out)
 {
     CHECK_M(m);
-    std::vector<int32_t> sizes((size_t)m->N);
+    const int nc = ncur(m);
+    std::vector<int32_t> sizes((size_t)m->world * nc);
     PHDCHK(phd_multi_get_map_sizes(m, sizes.data()));
     if (sizes_out) memcpy(sizes_out, sizes.data(), sizes.size() * sizeof(int32_t));
     if (!concat_out) return PHD_OK;
     size_t off = 0;
     for (int k = 0; k < m->world; ++k) {
         size_t tot = 0;
-        for (int p = 0; p < m->n; ++p) tot += (size_t)sizes[(size_t)k * m->n + p];
+        for (int p = 0; p < nc; ++p) tot += (size_t)sizes[(size_t)k * nc + p];
         if (off + tot > concat_capacity) return fail(PHD_ERR_CAPACITY, "phd_multi_get_maps: output buffer too small");
         PHDCHK(phd_get_maps(m->sh[k].f, concat_out + off, concat_capacity - off, nullptr));
         off += tot;
@@ -584,7 +603,9 @@ extern "C" int phd_multi_upload_inputs(phd_multi* m, const phd_ackerman_noise* n
         Shard& s = m->sh[k];
         HIPCHK(hipSetDevice(s.device));
         if (M > 0) HIPCHK(hipMemcpyAsync(s.d_z, z, (size_t)M * sizeof(phd_measurement), hipMemcpyHostToDevice, s.stream));
-        if (noise) HIPCHK(hipMemcpyAsync(s.d_noise, noise + (size_t)k * m->n, (size_t)m->n * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, s.stream));
+        // (n_predict_particles = k: one draw per PREDICTED particle, k per prior particle, in global predicted order)
+        const size_t nn = (size_t)ncur(m) * m->kpred;
+        if (noise) HIPCHK(hipMemcpyAsync(s.d_noise, noise + (size_t)k * nn, nn * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, s.stream));
     }
     m->n_meas = M;
     m->have_noise = noise != nullptr;
@@ -599,7 +620,10 @@ static int step_resident_body(phd_multi* m, phd_ackerman_control u, double unifo
     PHDCHK(peer_wait_consumed(m));
     PHDCHK(t_mark(m, 0));                               // start of the step
     if (M <= 0) {                                       // no scan: predict only (src/main.cpp:1244-1260); no resample (:1286)
-        for (auto& s : m->sh) PHDCHK(phd_step_local_dev(s.f, u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
+        for (auto& s : m->sh) {
+            if (m->kpred > 1) PHDCHK(phd_predict_ackerman_dev(s.f, u, m->have_noise ? s.d_noise : nullptr));
+            else PHDCHK(phd_step_local_dev(s.f, u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
+        }
         return t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP);
     }
     if (m->gathered && force_resample) {
@@ -628,10 +652,11 @@ static int step_resident_body(phd_multi* m, phd_ackerman_control u, double unifo
     if (!resample) {
         // the reference's trigger: global normalisation (adopted by every shard), nEff read back from shard 0 only
         float neff = 0.f;
+        const int n_now = W * ncur(m);
         for (int k = W - 1; k >= 0; --k)
-            PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->N, k == 0 ? &neff : nullptr));
+            PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, n_now, k == 0 ? &neff : nullptr));
         PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
-        resample = neff <= m->cfg.resampleThresh;                                    // src/main.cpp:1286
+        resample = neff <= m->cfg.resampleThresh || n_now > 5 * m->N;                // src/main.cpp:1286
         if (!resample) return PHD_OK;
     }
     if (did_resample_out) *did_resample_out = 1;
@@ -695,27 +720,28 @@ extern "C" int phd_multi_state_snapshot(phd_multi* m, phd_pose* expected_out, ph
     std::vector<float> lw;
     phd_pose* poses = poses_out;
     float* logw = log_weights_out;
-    if (!poses) { pp.resize((size_t)m->N); poses = pp.data(); }
-    if (!logw) { lw.resize((size_t)m->N); logw = lw.data(); }
+    const int nc = ncur(m), Nc = m->world * nc;
+    if (!poses) { pp.resize((size_t)Nc); poses = pp.data(); }
+    if (!logw) { lw.resize((size_t)Nc); logw = lw.data(); }
     PHDCHK(phd_multi_get_particles(m, poses, logw));
     // src/main.cpp:331-356: weighted-mean pose, arg-max weight (first maximum)
     double acc[6] = {0, 0, 0, 0, 0, 0};
     float best = -3.4028235e38f;
     int bi = -1;
-    for (int i = 0; i < m->N; ++i) {
+    for (int i = 0; i < Nc; ++i) {
         const double w = exp((double)logw[i]);
         acc[0] += w * poses[i].px; acc[1] += w * poses[i].py; acc[2] += w * poses[i].ptheta;
         acc[3] += w * poses[i].vx; acc[4] += w * poses[i].vy; acc[5] += w * poses[i].vtheta;
         if (logw[i] > best) { best = logw[i]; bi = i; }
     }
     if (bi < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
-    if (m->N == 1) *expected_out = poses[0];                                           // src/main.cpp:381-384
+    if (Nc == 1) *expected_out = poses[0];                                           // src/main.cpp:381-384
     else {
         expected_out->px = (float)acc[0]; expected_out->py = (float)acc[1]; expected_out->ptheta = (float)acc[2];
         expected_out->vx = (float)acc[3]; expected_out->vy = (float)acc[4]; expected_out->vtheta = (float)acc[5];
     }
     if (particle_out) *particle_out = bi;
-    PHDCHK(phd_get_map(m->sh[bi / m->n].f, bi % m->n, map_out, capacity, n_map_out));
+    PHDCHK(phd_get_map(m->sh[bi / nc].f, bi % nc, map_out, capacity, n_map_out));
     if (report_out) {
         phd_step_report tot;
         memset(&tot, 0, sizeof(tot));
@@ -780,11 +806,14 @@ extern "C" int phd_multi_update(phd_multi* m, const phd_ackerman_control* u, con
     PHDCHK(phd_multi_upload_inputs(m, noise, z, n_meas));
     PHDCHK(peer_wait_consumed(m));
     if (m->n_meas <= 0) {
-        if (u) for (auto& s : m->sh) PHDCHK(phd_step_local_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
+        if (u) for (auto& s : m->sh) {
+            if (m->kpred > 1) PHDCHK(phd_predict_ackerman_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr));
+            else PHDCHK(phd_step_local_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
+        }
         return PHD_OK;
     }
     PHDCHK(update_stage(m, u));
-    for (int k = m->world - 1; k >= 0; --k) PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->N, nullptr));
+    for (int k = m->world - 1; k >= 0; --k) PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->world * ncur(m), nullptr));
     return PHD_OK;
 }
 

@@ -33,6 +33,7 @@ MULTI_SYMBOLS = {
     "phd_multi_destroy": (_i, [_vp]),
     "phd_multi_n_shards": (_i, [_vp]),
     "phd_multi_n_particles": (_i, [_vp]),
+    "phd_multi_n_particles_now": (_i, [_vp]),
     "phd_multi_uses_rccl": (_i, [_vp]),
     "phd_multi_exchange_is_gathered": (_i, [_vp]),
     "phd_multi_exchange": (_i, [_vp]),
@@ -116,6 +117,11 @@ class MultiFilter:
             pass
 
     @property
+    def n_now(self):
+        """global particle count now (grows by n_predict_particles per predict until the resample that follows)"""
+        return mlib().phd_multi_n_particles_now(self._h)
+
+    @property
     def uses_rccl(self):
         return bool(mlib().phd_multi_uses_rccl(self._h))
 
@@ -140,11 +146,11 @@ class MultiFilter:
     def set_particles(self, poses=None, log_weights=None):
         p = None if poses is None else np.ascontiguousarray(poses, POSE)
         w = None if log_weights is None else np.ascontiguousarray(log_weights, np.float32)
-        check(mlib().phd_multi_set_particles(self._h, ptr(p), ptr(w), self.n), "phd_multi_set_particles")
+        check(mlib().phd_multi_set_particles(self._h, ptr(p), ptr(w), self.n_now), "phd_multi_set_particles")
 
     def get_particles(self):
-        p = np.zeros(self.n, POSE)
-        w = np.zeros(self.n, np.float32)
+        p = np.zeros(self.n_now, POSE)
+        w = np.zeros(self.n_now, np.float32)
         check(mlib().phd_multi_get_particles(self._h, ptr(p), ptr(w)), "phd_multi_get_particles")
         return p, w
 
@@ -155,7 +161,7 @@ class MultiFilter:
         check(mlib().phd_multi_set_maps(self._h, ptr(concat), ptr(sizes)), "phd_multi_set_maps")
 
     def map_sizes(self):
-        s = np.zeros(self.n, np.int32)
+        s = np.zeros(self.n_now, np.int32)
         check(mlib().phd_multi_get_map_sizes(self._h, ptr(s)), "phd_multi_get_map_sizes")
         return s
 
@@ -164,7 +170,7 @@ class MultiFilter:
         concat = np.zeros(max(int(sizes.sum()), 1), GAUSSIAN)
         check(mlib().phd_multi_get_maps(self._h, ptr(concat), len(concat), ptr(sizes)), "phd_multi_get_maps")
         off = np.concatenate([[0], np.cumsum(sizes)])
-        return [concat[off[p]:off[p + 1]] for p in range(self.n)]
+        return [concat[off[p]:off[p + 1]] for p in range(len(sizes))]
 
     def step(self, control, noise, z, uniform, force_resample=False):
         """-> did_resample"""
@@ -215,8 +221,8 @@ class MultiFilter:
         e = np.zeros(1, POSE)
         out = np.zeros(self.cap, GAUSSIAN)
         n, who = C.c_int32(0), C.c_int32(0)
-        poses = np.zeros(self.n, POSE)
-        lw = np.zeros(self.n, np.float32)
+        poses = np.zeros(self.n_now, POSE)
+        lw = np.zeros(self.n_now, np.float32)
         rep = StepReport()
         check(mlib().phd_multi_state_snapshot(self._h, ptr(e), ptr(out), self.cap, C.byref(n), C.byref(who), ptr(poses), ptr(lw),
                                               C.byref(rep)), "phd_multi_state_snapshot")

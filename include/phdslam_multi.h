@@ -58,7 +58,9 @@ typedef struct {
 int phd_multi_create(const phd_slam_config* cfg, const phd_multi_options* opt, phd_multi** out);
 int phd_multi_destroy(phd_multi* m);
 int phd_multi_n_shards(const phd_multi* m);
-int phd_multi_n_particles(const phd_multi* m);           /* global */
+int phd_multi_n_particles(const phd_multi* m);           /* global: n_particles of the configuration */
+int phd_multi_n_particles_now(const phd_multi* m);       /* global, now: more between a shotgun predict (n_predict_particles > 1)
+                                                            and the resample that follows (every shard grows alike) */
 int phd_multi_uses_rccl(const phd_multi* m);             /* 1: RCCL collectives; 0: peer copies (shards share a device) */
 int phd_multi_exchange_is_gathered(const phd_multi* m);  /* the form a forced resample takes */
 int phd_multi_exchange(const phd_multi* m);              /* PHD_EXCHANGE_* in use (never AUTO) */
