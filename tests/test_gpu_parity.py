@@ -869,3 +869,50 @@ def test_spill_path_reads_the_parent_slab_after_a_resample():
                     assert len(far) == n_far
                     if not fused:
                         assert np.all(far["mean"][:, 0] == np.float32(30.0 + idx[p])), (p, idx[p], far["mean"][:, 0])
+
+
+def test_exact_moment_sums_corner_cases():
+    """the fixed-point moment sums (csrc/phd_fixsum.h, oracle o_exact_*) at their edges, device == oracle bit for bit (NaN
+    patterns included): a member whose weight exceeds the seed's anchor (a negative weight of larger magnitude) poisons its
+    cluster; weights spread over 30 binary orders inside one cluster (the light members are truncated on the seed's scale, the
+    same way on both sides); covariances of 1e-10 and of 1e+6 m^2; a cluster far from the origin (means ~1e5 m)"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(4, 16, 6, seed=91)
+    cfg = P.default_config(minFeatureWeight=0.0)                       # nothing is pruned: tiny and negative weights stay
+    ocfg = oracle_config_from(cfg)
+    maps = w["maps"].copy()
+    # nearly-in-range features (15 m < r <= 18 m: they skip the update and join the merge untouched), co-located pairs
+    def near(p, k, xy, wgt, cov):
+        maps[p, k]["mean"] = xy
+        maps[p, k]["weight"] = wgt
+        maps[p, k]["cov"] = (cov, 0.0, 0.0, cov)
+    near(0, 0, (16.0, 0.5), 0.5, 0.04); near(0, 1, (16.01, 0.5), -5.0, 0.04)              # poisoned cluster
+    near(1, 0, (0.3, 16.5), 0.8, 0.04); near(1, 1, (0.31, 16.5), 0.8 * 2.0 ** -30, 0.04)  # 30 binary orders lighter
+    near(1, 2, (0.29, 16.51), 0.8 * 2.0 ** -45, 0.04)                                      # below the seed's scale: truncated to zero
+    near(2, 0, (-16.2, 1.0), 0.6, 1e-10); near(2, 1, (-16.2, 1.0), 0.3, 1e-10)            # tiny covariances
+    near(2, 2, (2.0, -16.4), 0.6, 1e6); near(2, 3, (40.0, -30.0), 0.3, 1e6)                # huge ones (a wide merge)
+    w["maps"] = maps
+    w["poses"]["px"][3] = 1e5; w["poses"]["py"][3] = -2e5                                  # a particle (and its map) far away
+    maps[3]["mean"][:, 0] += 1e5; maps[3]["mean"][:, 1] -= 2e5
+    with make_filter(cfg, w, cap=64) as f:
+        f.debug(True)
+        f.update(w["z"][0])
+        f.status()
+        got = f.get_maps()
+        n_nan = 0
+        for p in range(4):
+            gmap = w["maps"][p, :w["sizes"][p]]
+            cls = O.classify(gmap, w["poses"][p], ocfg)
+            surv, _ = f.survivors(p)
+            om = O.merge(surv, ocfg)
+            want = np.concatenate([om, gmap[cls == 0]]) if (cls == 0).any() else om
+            assert len(got[p]) == len(want), (p, len(got[p]), len(want))
+            for fld in ("weight", "mean", "cov"):
+                assert np.array_equal(got[p][fld].view(np.uint32), want[fld].view(np.uint32)), (p, fld)
+            n_nan += int(np.isnan(got[p]["weight"]).sum())
+            # and the exact sums stay within rounding of float sums in weight order where nothing is poisoned
+            omf = O.merge(surv, oracle_config_from(cfg, mergeSums=1))
+            ok = ~np.isnan(om["weight"])
+            if len(omf) == len(om):
+                assert np.allclose(om["weight"][ok], omf["weight"][ok], rtol=3e-6, atol=0)
+        assert n_nan == 1, n_nan                                     # exactly the poisoned cluster
