@@ -21,3 +21,18 @@ def test_algorithmic_bytes_and_flops_match_the_survey_formulas():
     # 150 G + 45 G M + 30 M flops per particle
     assert bench.algorithmic_flops(4096, 256, 64) == 4096 * (150 * 256 + 45 * 256 * 64 + 30 * 64)
     assert abs(bench.algorithmic_flops(4096, 256, 64) - 3.185e9) < 1e7
+
+
+def test_bench_gpus_n_without_a_launcher_refuses_missing_devices():
+    """`python3 bench.py --gpus N` needs no launcher: it drives N devices from one process (libphdslam_multi.so).  On a box with
+    fewer devices — this CPU container has none — it exits non-zero and says so; the GPU side of
+    the same path is tests/test_gpu_multi.py::test_bench_gpus_2_unlaunched_runs_the_cpp_host."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PHD_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
