@@ -363,7 +363,7 @@ __device__ __forceinline__ double lane_down1_z(double v)
 // stores — one readlane, one convert, two DPP moves, one fma and one store per step.  P_M[64] (only M = 64 needs it, for
 // the full-set ESF) is xi_63 * P_63[63].  RowPtr: an LDS or a global pointer (a generic one would compile to flat stores).
 template <typename RowPtr>
-__device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowPtr rows, int rs, int M, int lane)
+__device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowPtr rows, int rs, int M, int h, int lane)
 {
 #pragma clang fp contract(off)
     double P = lane == 0 ? 1.0 : 0.0;     // P_0 = [1]
@@ -374,10 +374,11 @@ __device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowP
     __builtin_amdgcn_s_setprio(3);
 #endif
     for (int m0 = 0; m0 < M; m0 += PHD_F64_RENORM) {
-        if (lane < PHD_F64_RENORM && m0 + lane < M) Q.kp[m0 + lane] = kP;       // the block exponent of the next rows
+        // (only the rows m >= h are parked — the inner products of the measurements below h come from the suffix rows)
+        if (lane < PHD_F64_RENORM && m0 + lane < M && m0 + lane >= h) Q.kp[m0 + lane] = kP;   // the block exponent of the next rows
         const int m1 = (m0 + PHD_F64_RENORM < M) ? m0 + PHD_F64_RENORM : M;
         for (int m = m0; m < m1; ++m) {
-            if (lane < rs) rows[(size_t)m * rs + lane] = P;                       // row m: P_m[0..m] (zeros beyond; rs >= M > m)
+            if (m >= h && lane < rs) rows[(size_t)(m - h) * rs + lane] = P;       // row m: P_m[0..m] (zeros beyond; rs >= M > m)
             const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
             if (m == 63) top = x * P;                                             // (lane 63 holds P_63[63])
             P = __builtin_fma(x, lane_up1_z(P), P);                               // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
@@ -397,14 +398,58 @@ __device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowP
     __threadfence();
 }
 
-template <typename RowPtr>
-__device__ __forceinline__ void cphd_esf_backward_dot_f64(const CphdLds& Q, RowPtr rows, int rs, int M, int lane,
-                                                          int wave, float llam, float lam, LDS_T(double)* dsum, LDS_T(int)* dexp_)
+// wave 0, after its forward sweep: the SUFFIX polynomial S_h = prod_{i >= h} (1 + xi_i x) (degree M - h) by the same step with
+// the roots M-1 .. h in reverse order — M - h steps — left in an LDS row with its block exponent.  It lets the second half of
+// the backward recursion start from T_h = S_h (correlated with) c without waiting for the first half.
+__device__ __forceinline__ void cphd_esf_suffix_f64(const CphdLds& Q, LDS_T(double)* sh_row, LDS_T(int)* sh_exp, int M, int h, int lane,
+                                                    LDS_T(int)* sctr, int conv_done)
 {
 #pragma clang fp contract(off)
-    if (wave >= PHD_FW64) return;
-    // T_M[a] = c_a = exp(I1[a]) lambda^(M-1-a) e^-lambda on a common block exponent kT
-    double T = 0.0;
+    double S = lane == 0 ? 1.0 : 0.0;
+    int kS = 0, since = 0;
+    const float xv = lane < M ? Q.lxi[lane] : 0.f;
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    for (int j = M - 1; j >= h; --j) {
+        const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), j));
+        S = __builtin_fma(x, lane_up1_z(S), S);                                     // S_j = S_{j+1} (1 + xi_j x)
+        if (++since == PHD_F64_RENORM) {
+            const int r = wave_max_i(dexp_field(S)) - 1023;
+            S = __builtin_ldexp(S, -r);
+            kS += r;
+            since = 0;
+        }
+    }
+#ifndef PHD_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // the row goes into the zpart array, which the cardinality waves read (the scaled prior) until their convolution is done:
+    // wait for their arrival counter (long since reached: the convolution takes 4 us, the two sweeps 9)
+    while (__hip_atomic_load((int*)sctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < conv_done) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < M) sh_row[lane] = S;                                                 // S_h[0 .. M - h] (zeros beyond)
+    if (lane == 0) sh_exp[0] = kS;
+}
+
+// The inner products D_m = <Y1[Z \ m], p> = <P_m, T_{m+1}>, T_{m+1}[a] = sum_b S_{m+1}[b] c_{a+b}, from TWO chains of half the
+// length that run side by side (waves 0-1 and 2-3, one wave per SIMD; within a pair the waves run the cheap recursion
+// redundantly and take alternate inner products, the row of the next one requested a turn ahead):
+//   upper (m >= h): T_M = c, T_m[a] = T_{m+1}[a] + xi_m T_{m+1}[a+1] backwards from M - 1 to h;
+//   lower (m <  h): the same recursion from T_h, which does not wait for the upper chain: T_h[a] = sum_b S_h[b] c[a+b] is an
+//                   (M - h + 1)-term correlation of c with the suffix polynomial the forward wave left behind — independent
+//                   fmas, not a chain.
+// (The step shifts towards lane 0 with a zero shifted in: c_k = 0 beyond k = M - 1, so every lane stays a valid entry.)
+// Round 3a ran ONE chain of M steps: 9.5 us.  The logarithms are taken after the sweeps, by one thread per m (dsum / dexp_).
+template <typename RowPtr>
+__device__ __forceinline__ void cphd_esf_chains_f64(const CphdLds& Q, RowPtr rowsP, int rs, int M, int h, int lane, int wave,
+                                                    float llam, float lam, LDS_T(double)* dsum, LDS_T(int)* dexp_,
+                                                    LDS_T(double)* c_lds, const LDS_T(double)* sh_row, const LDS_T(int)* sh_exp)
+{
+#pragma clang fp contract(off)
+    if (wave >= 4) return;
+    // c_a = exp(I1[a]) lambda^(M-1-a) e^-lambda on a common block exponent: the start of the upper chain
+    double V = 0.0;
     int kf = -(1 << 28);
     double frac = 0.0;
     if (lane < M) {
@@ -416,35 +461,50 @@ __device__ __forceinline__ void cphd_esf_backward_dot_f64(const CphdLds& Q, RowP
             kf = (int)kc;
         }
     }
-    int kT = wave_max_i(kf);
-    if (kT == -(1 << 28)) kT = 0;                                    // every c_a is zero
-    if (kf != -(1 << 28)) { const int d = kf - kT; T = d < -1100 ? 0.0 : __builtin_ldexp(frac, d); }
+    int kV = wave_max_i(kf);
+    if (kV == -(1 << 28)) kV = 0;                                    // every c_a is zero
+    if (kf != -(1 << 28)) { const int d = kf - kV; V = d < -1100 ? 0.0 : __builtin_ldexp(frac, d); }
     const float xv = lane < M ? Q.lxi[lane] : 0.f;
+    const bool lower = wave >= 2;
+    const int me = wave & 1;
+    int m_hi = M - 1, m_lo = h;                                      // this chain's measurements: m_hi .. m_lo
+    if (lower) {
+        m_hi = h - 1; m_lo = 0;
+        // T_h = S_h (*) c: both waves of the pair write the same c (zero-padded to 2 M entries) and read it back
+        if (lane < M) { c_lds[lane] = V; c_lds[M + lane] = 0.0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): this wave's own LDS writes have landed
+        double acc = 0.0;
+        const int deg = M - h;
+        if (lane < M)
+            for (int b = 0; b <= deg; ++b) acc = __builtin_fma(sh_row[b], c_lds[lane + b], acc);
+        V = acc;
+        kV += sh_exp[0];
+        const int r = wave_max_i(dexp_field(V)) - 1023;
+        if (r > -1023) { V = __builtin_ldexp(V, -r); kV += r; }
+    }
+    int since = 0;
 #ifndef PHD_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    // this wave's inner products: m = M - 1 - wave - PHD_FW64 u; the row of the next one is requested a turn ahead.
-    // The recursion T_m[a] = T_{m+1}[a] + xi_m T_{m+1}[a+1] runs unmasked: the entries a >= m it also touches are never read
-    // again (their values stay finite between two rescalings, and the rescaling clears them).
-    int mnext = M - 1 - wave;
-    double prow = (mnext >= 0 && lane <= mnext) ? rows[(size_t)mnext * rs + lane] : 0.0;
-    int krow = mnext >= 0 ? Q.kp[mnext] : 0;
-    for (int m = M - 1; m >= 0; --m) {
+    int mnext = m_hi - me;
+    double prow = (mnext >= m_lo && lane <= mnext) ? rowsP[(size_t)mnext * rs + lane] : 0.0;
+    int krow = mnext >= m_lo ? Q.kp[mnext] : 0;
+    for (int m = m_hi; m >= m_lo; --m) {
         if (m == mnext) {
-            // D_m = sum_{a=0..m} P_m[a] T_{m+1}[a]; the logarithm is taken after the sweep, by one thread per m
-            const double sm = wave_sum_d(prow * T);
-            if (lane == 0) { dsum[m] = sm; dexp_[m] = krow + kT; }
-            mnext = m - PHD_FW64;
-            prow = (mnext >= 0 && lane <= mnext) ? rows[(size_t)mnext * rs + lane] : 0.0;
-            krow = mnext >= 0 ? Q.kp[mnext] : 0;
+            const double sm = wave_sum_d(prow * V);                                     // <P_m, T_{m+1}>
+            if (lane == 0) { dsum[m] = sm; dexp_[m] = krow + kV; }
+            mnext = m - 2;
+            prow = (mnext >= m_lo && lane <= mnext) ? rowsP[(size_t)mnext * rs + lane] : 0.0;
+            krow = mnext >= m_lo ? Q.kp[mnext] : 0;
         }
-        if (m >= 1) {
+        if (m > m_lo) {
             const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
-            T = __builtin_fma(x, lane_down1_z(T), T);
-            if (((M - 1 - m) & (PHD_F64_RENORM - 1)) == PHD_F64_RENORM - 1) {
-                if (lane > m - 1) T = 0.0;                           // (entries the sweep no longer needs)
-                const int r = wave_max_i(dexp_field(T)) - 1023;
-                if (r > -1023) { T = __builtin_ldexp(T, -r); kT += r; }
+            V = __builtin_fma(x, lane_down1_z(V), V);
+            if (++since == PHD_F64_RENORM) {
+                const int r = wave_max_i(dexp_field(V)) - 1023;
+                if (r > -1023) { V = __builtin_ldexp(V, -r); kV += r; }
+                since = 0;
             }
         }
     }
@@ -657,21 +717,35 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     const bool rows_in_lds = tiles == 1 && (size_t)32 * S_cap >= (size_t)M * 64 * 8;
     LDS_T(double)* const rows_l = (LDS_T(double)*)L.w;
     double* const rows_g = (double*)T_scratch;
+    // f64 path (M <= 64): wave 0 runs the forward sweep (parks every row P_m) and then, M / 2 steps, the suffix polynomial S_h of
+    // the upper half of the roots, which lets the backward recursion run as two half-length chains side by side afterwards
+    const bool f64 = tiles == 1;
+    const int hsplit = M >> 1;                                      // (26 of 64 for the lower chain — which also pays the correlation — measured no faster)
+    LDS_T(int)* sctr = (LDS_T(int)*)&L.ctr[CTR_WSYNC];
+    const bool lin = (size_t)8 * cn_len <= (size_t)32 * MM;
+    // (zpart, 32 MM >= 32 M bytes, is idle from the roots to the cardinality update — but for the scaled prior of the predicted
+    //  cardinality, see cphd_esf_suffix_f64: [M] inner-product sums | [2 M] c, zero-padded | [M] S_h)
+    LDS_T(double)* const dsum = (LDS_T(double)*)L.zpart;
+    LDS_T(double)* const c_lds = dsum + M;
+    LDS_T(double)* const sh_row = dsum + 3 * M;
+    LDS_T(int)* const sh_exp = (LDS_T(int)*)&L.ctr[CTR_NHEAD];        // (a merge counter: free until the merge)
     if (wave == 0) {
-        if (tiles == 1 && rows_in_lds) cphd_esf_forward_park_f64(Q, rows_l, 64, M, lane);
-        else if (tiles == 1) cphd_esf_forward_park_f64(Q, rows_g, MM, M, lane);
+        if (f64 && rows_in_lds) cphd_esf_forward_park_f64(Q, rows_l, 64, M, 0, lane);
+        else if (f64) cphd_esf_forward_park_f64(Q, rows_g, MM, M, 0, lane);
         else if (tiles == 2) cphd_esf_forward_park<2>(Q, T_scratch, M, lane);
         else cphd_esf_forward_park<4>(Q, T_scratch, M, lane);
         GSTAMP(16, 0);   // forward sweep done
+        if (f64) {
+            cphd_esf_suffix_f64(Q, sh_row, sh_exp, M, hsplit, lane, sctr, (lin ? 2 : 1) * (PHD_NW - 1));
+            GSTAMP(31, 0);   // suffix half-sweep done
+        }
     } else {
-        LDS_T(int)* sctr = (LDS_T(int)*)&L.ctr[CTR_WSYNC];
         int target = 0;
         const int t7 = tid - 64, T7 = PHD_T - 64, w7 = wave - 1, W7 = PHD_NW - 1;
         // predicted cardinality (.bak:518-545): prior (*) Binomial(M, birthWeight).  The log-domain form costs two passes of
         // (two LDS reads, add, max | sub, exp, add) per term, 2 x 65 terms per n: 6 us.  In the LINEAR domain the convolution
         // is one fma per term; doubles, scaled by the prior's maximum, keep everything within e^-700 of that maximum (what
         // lies below is zero for every sum taken from these numbers) — when the idle zpart / I0 / I1 arrays can hold them.
-        const bool lin = (size_t)8 * cn_len <= (size_t)32 * MM;
         if (lin) {
             LDS_T(double)* const qd = (LDS_T(double)*)L.zpart;       // [cn_len] exp(prior - max)
             LDS_T(double)* const bd = (LDS_T(double)*)Q.I0;          // [Kb + 1] Binomial pmf (I0 and I1 are written after this phase)
@@ -696,7 +770,7 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
             for (int k = 0; k <= kmax; ++k) s += __expf(Q.cnb[k] + Q.cnq[n - k] - mx);
             Q.cnp[n] = safe_log(s) + mx;
         }
-        GSTAMP(17, 64);  // predicted cardinality done (wave 1)
+        GSTAMP(17, 64);  // predicted cardinality done (first wave of the group)
         waves_sync(sctr, W7, target, lane);
         GSTAMP(18, 64);
         // I_u[j] = log sum_n p(n) P(n,j+u) Wq^(n-j-u) / W1^n.  Since P(n,j+1) Wq^(n-j-1) is the u = 0 term of j+1,
@@ -708,9 +782,10 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
             waves_sync(sctr, W7, target, lane);
             GSTAMP(19, 64);  // B_n done
             if (cn_len <= 256) {
-                const int per = (M + 2 + W7 - 1) / W7;                // j = 0 .. M + 1 in contiguous ranges
+                // j = 0 .. M + 1 in contiguous ranges
+                const int per = (M + 2 + W7 - 1) / W7;
                 const int jl = w7 * per, jh = (jl + per < M + 2) ? jl + per : M + 2;
-                if (per <= 16) cphd_nsums_fast8(Q, M, Nmax, lane, jl, jh, lWq);
+                if (per <= 16) { if (jl < jh) cphd_nsums_fast8(Q, M, Nmax, lane, jl, jh, lWq); }
                 else cphd_nsums_fast<4>(Q, M, Nmax, lane, w7, W7, lWq);
             }
             else if (cn_len <= 512) cphd_nsums_fast<8>(Q, M, Nmax, lane, w7, W7, lWq);
@@ -720,7 +795,7 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
             else if (cn_len <= 512) cphd_nsums<8>(Q, M, Nmax, lane, w7, W7, lWq, lW1);
             else cphd_nsums<16>(Q, M, Nmax, lane, w7, W7, lWq, lW1);
         }
-        GSTAMP(20, 64);      // n-sums done (wave 1)
+        GSTAMP(20, 64);      // n-sums done (first wave of the group)
     }
     __syncthreads();
     CQSTAMP(2);
@@ -735,12 +810,11 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // integer exponent (m 2^k): align with v_ldexp, renormalise with v_frexp — exact operations around one correctly
     // rounded multiply and add (the oracle does the same).  Wave PHD_FW, idle in the sweep, takes <Y0,p> and <Y1,p>.
     // (the inner products' sums and exponents wait in the — still unused — logZ / zpart arrays for their logarithms)
-    LDS_T(double)* const dsum = (LDS_T(double)*)L.zpart;
     LDS_T(int)* const dexp_ = (LDS_T(int)*)L.logZ;
     if (tiles != 1 && wave == PHD_FW) cphd_full_set(Q, M, lane, llam, lam);
     if (tiles == 1) {
-        if (rows_in_lds) cphd_esf_backward_dot_f64(Q, (const LDS_T(double)*)rows_l, 64, M, lane, wave, llam, lam, dsum, dexp_);
-        else cphd_esf_backward_dot_f64(Q, (const double*)rows_g, MM, M, lane, wave, llam, lam, dsum, dexp_);
+        if (rows_in_lds) cphd_esf_chains_f64(Q, (const LDS_T(double)*)rows_l, 64, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
+        else cphd_esf_chains_f64(Q, (const double*)rows_g, MM, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
         GSTAMP(21, 0);       // wave 0's share of the backward sweep done
         GSTAMP(22, 192);     // wave 3's
         if (wave == PHD_NW - 1) cphd_full_set(Q, M, lane, llam, lam);   // (after its share of the sweep: every wave takes part in it)
