@@ -331,6 +331,46 @@ __device__ __forceinline__ double wave_sum_d(double v)
 #undef PHD_XD
     return v;
 }
+// eight per-lane doubles summed over the wave in one transposing pass (the double twin of reduce8_over_wave, phd_pass1.h:
+// every level halves the values a lane carries — one swap per 32-bit half and one add serve two values): lane l ends with the
+// wave total of a[l >> 3].  ~40 instructions for eight sums instead of 8 x 18.
+__device__ __forceinline__ double swap_add32(double x, double y)
+{
+    // lanes < 32 get x_own + x_partner... (v_permlane32_swap exchanges the upper half of the first operand with the lower half of the second)
+    const u64 bx = (u64)__double_as_longlong(x), by = (u64)__double_as_longlong(y);
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((u32)bx, (u32)by, false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((u32)(bx >> 32), (u32)(by >> 32), false, false);
+    return __longlong_as_double((long long)(((u64)hi.x << 32) | lo.x)) + __longlong_as_double((long long)(((u64)hi.y << 32) | lo.y));
+}
+__device__ __forceinline__ double swap_add16(double x, double y)
+{
+    const u64 bx = (u64)__double_as_longlong(x), by = (u64)__double_as_longlong(y);
+    const u32x2_t lo = __builtin_amdgcn_permlane16_swap((u32)bx, (u32)by, false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane16_swap((u32)(bx >> 32), (u32)(by >> 32), false, false);
+    return __longlong_as_double((long long)(((u64)hi.x << 32) | lo.x)) + __longlong_as_double((long long)(((u64)hi.y << 32) | lo.y));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = dpp_mov<CTRL, 0xF>((u32)b, (u32)b), hi = dpp_mov<CTRL, 0xF>((u32)(b >> 32), (u32)(b >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ double reduce8_over_wave_d(double (&a)[8], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = swap_add32(a[i], a[i + 4]);      // lanes < 32 go on with values 0..3, lanes >= 32 with 4..7
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = swap_add16(a[i], a[i + 2]);      // even rows of 16 lanes: value i, odd rows: value i + 2
+    const bool hi8 = (lane & 8) != 0;
+    const double keep = hi8 ? a[1] : a[0], send = hi8 ? a[0] : a[1];
+    double v = keep + dpp_d<0x128>(send);                                // row_ror:8
+    v += dpp_d<0x141>(v);                                                // row_half_mirror: l <-> 7 - l
+    v += dpp_d<0x1B>(v);                                                 // quad_perm [3,2,1,0]
+    v += dpp_d<0xB1>(v);                                                 // quad_perm [1,0,3,2]
+    return v;
+}
+
 // biased exponent of a non-negative double (0 for zero / denormals)
 __device__ __forceinline__ int dexp_field(double v) { return (int)(((u64)__double_as_longlong(v) >> 52) & 0x7FFull); }
 // log of m 2^k for a positive double m, as a float (the form the float sweeps use: log of the mantissa + k ln 2)
@@ -487,26 +527,45 @@ __device__ __forceinline__ void cphd_esf_chains_f64(const CphdLds& Q, RowPtr row
 #ifndef PHD_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    int mnext = m_hi - me;
-    double prow = (mnext >= m_lo && lane <= mnext) ? rowsP[(size_t)mnext * rs + lane] : 0.0;
-    int krow = mnext >= m_lo ? Q.kp[mnext] : 0;
-    for (int m = m_hi; m >= m_lo; --m) {
-        if (m == mnext) {
-            const double sm = wave_sum_d(prow * V);                                     // <P_m, T_{m+1}>
-            if (lane == 0) { dsum[m] = sm; dexp_[m] = krow + kV; }
-            mnext = m - 2;
-            prow = (mnext >= m_lo && lane <= mnext) ? rowsP[(size_t)mnext * rs + lane] : 0.0;
-            krow = mnext >= m_lo ? Q.kp[mnext] : 0;
+    // one step of the recursion with root m: V <- V + xi_m shift(V); rescaled every PHD_F64_RENORM steps
+    auto step = [&](int m) {
+        const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
+        V = __builtin_fma(x, lane_down1_z(V), V);
+        if (++since == PHD_F64_RENORM) {
+            const int r = wave_max_i(dexp_field(V)) - 1023;
+            if (r > -1023) { V = __builtin_ldexp(V, -r); kV += r; }
+            since = 0;
         }
-        if (m > m_lo) {
-            const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
-            V = __builtin_fma(x, lane_down1_z(V), V);
-            if (++since == PHD_F64_RENORM) {
-                const int r = wave_max_i(dexp_field(V)) - 1023;
-                if (r > -1023) { V = __builtin_ldexp(V, -r); kV += r; }
-                since = 0;
+    };
+    // this wave's inner products: m = m_hi - me, m_hi - me - 2, ...; the recursion runs every step.  The per-lane products of
+    // EIGHT inner products wait in registers for one transposing reduction (reduce8_over_wave_d): sixteen inner products per
+    // wave cost two of those instead of sixteen 6-step butterflies.
+    int m = m_hi;
+    if (me == 1 && m >= m_lo) { if (m > m_lo) step(m); --m; }
+    double prow = (m >= m_lo && lane <= m) ? rowsP[(size_t)m * rs + lane] : 0.0;
+    int krow = m >= m_lo ? Q.kp[m] : 0;
+    while (m >= m_lo) {
+        double pq[8];
+        int eq = 0, nq = 0;
+        const int mq0 = m;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            pq[q] = 0.0;
+            if (m >= m_lo) {                                                            // (uniform)
+                pq[q] = prow * V;                                                       // <P_m, T_{m+1}>, lane by lane
+                if ((lane >> 3) == q) eq = krow + kV;
+                nq = q + 1;
+                const int mn = m - 2;                                                   // the row of the next one, a turn ahead
+                prow = (mn >= m_lo && lane <= mn) ? rowsP[(size_t)mn * rs + lane] : 0.0;
+                krow = mn >= m_lo ? Q.kp[mn] : 0;
+                if (m > m_lo) step(m);
+                if (m - 1 > m_lo) step(m - 1);
+                m -= 2;
             }
         }
+        const double tot = reduce8_over_wave_d(pq, lane);                               // lane l: the total of entry l >> 3
+        const int q = lane >> 3;
+        if ((lane & 7) == 0 && q < nq) { dsum[mq0 - 2 * q] = tot; dexp_[mq0 - 2 * q] = eq; }
     }
 #ifndef PHD_NO_SETPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -582,47 +641,75 @@ __device__ __forceinline__ float max8_over_wave(float (&a)[8], int lane)
     return v;
 }
 
-// cphd_nsums_fast for cardinality rows of up to 256 entries with EIGHT j per trip: the two wave reductions of a log-sum-exp
-// (maximum, sum) are 2 x 18 instructions per j done one j at a time — more than the terms themselves; transposing
-// reductions do eight of each in ~22.  A wave takes the contiguous range [j_lo, j_hi) of j: the first eight this way, what
-// is left (two of the 66 values of a 64-measurement scan over seven waves) the plain way.  Same sums, another fixed tree.
+// four per-lane maxima over the wave (the max twin of reduce4_over_wave): lane l ends with the wave maximum of a[l >> 4]
+__device__ __forceinline__ float max4_over_wave(float (&a)[4], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 2]), false, false);
+        a[i] = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    }
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
+    float v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    v = fmaxf(v, __uint_as_float(dpp_mov<0x128, 0xF>(__float_as_uint(v), __float_as_uint(v))));                  // row_ror:8
+    v = fmaxf(v, __uint_as_float(dpp_mov<0x141, 0xF>(__float_as_uint(v), __float_as_uint(v))));                  // row_half_mirror
+    v = fmaxf(v, __uint_as_float(dpp_mov<0x1B, 0xF>(__float_as_uint(v), __float_as_uint(v))));                   // quad_perm [3,2,1,0]
+    v = fmaxf(v, __uint_as_float(dpp_mov<0xB1, 0xF>(__float_as_uint(v), __float_as_uint(v))));                   // quad_perm [1,0,3,2]
+    return v;
+}
+
+// cphd_nsums_fast for cardinality rows of up to 256 entries with EIGHT (or four) j per trip: the two wave reductions of a
+// log-sum-exp (maximum, sum) are 2 x 18 instructions per j done one j at a time — more than the terms themselves; transposing
+// reductions do eight of each in ~22, four in ~14.  A wave takes the contiguous range [j_lo, j_hi) of j: batches of eight, then
+// batches of four (the last one padded: a j outside the range is computed and dropped).  Same sums, another fixed tree.
+template <int NB>
+__device__ __forceinline__ void cphd_nsums_batch(const CphdLds& Q, int M, int Nmax, int lane, int j0, int j_hi, float lWq)
+{
+#pragma clang fp contract(off)
+    const float LOG0F = -FLT_MAX;
+    float tv[NB][4], mx[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int j = j0 + q;
+        mx[q] = LOG0F;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = j + lane + 64 * c;
+            tv[q][c] = LOG0F;
+            if (n <= Nmax) { tv[q][c] = Q.cnq[n] - Q.lfact[n - j]; mx[q] = fmaxf(mx[q], tv[q][c]); }
+        }
+    }
+    float mxw;                                                       // lane l: the maximum of j0 + (l >> 3) (NB = 8) / (l >> 4) (NB = 4)
+    if constexpr (NB == 8) mxw = max8_over_wave(mx, lane); else mxw = max4_over_wave(mx, lane);
+    float sacc[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const float m = lane_f(mxw, (64 / NB) * q);
+        sacc[q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (j0 + q + lane + 64 * c <= Nmax) sacc[q] += __expf(tv[q][c] - m);
+    }
+    float sw;
+    if constexpr (NB == 8) sw = reduce8_over_wave(sacc, lane); else sw = reduce4_over_wave(sacc, lane);
+    if ((lane & (64 / NB - 1)) == 0) {
+        const int j = j0 + lane / (64 / NB);
+        if (j < j_hi) {
+            const float v = (j <= Nmax) ? (safe_log(sw) + mxw) - (float)j * lWq : LOG0F;
+            if (j <= M) Q.I0[j] = v;
+            if (j >= 1) Q.I1[j - 1] = v;
+        }
+    }
+}
+
 __device__ __forceinline__ void cphd_nsums_fast8(const CphdLds& Q, int M, int Nmax, int lane, int j_lo, int j_hi, float lWq)
 {
 #pragma clang fp contract(off)
     const float LOG0F = -FLT_MAX;
     int j0 = j_lo;
-    if (j_hi - j0 >= 8) {
-        float tv[8][4], mx[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = j0 + q;
-            mx[q] = LOG0F;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int n = j + lane + 64 * c;
-                tv[q][c] = LOG0F;
-                if (n <= Nmax) { tv[q][c] = Q.cnq[n] - Q.lfact[n - j]; mx[q] = fmaxf(mx[q], tv[q][c]); }
-            }
-        }
-        const float mxw = max8_over_wave(mx, lane);                  // lane l: the maximum of j0 + (l >> 3)
-        float sacc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float m = lane_f(mxw, 8 * q);
-            sacc[q] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (j0 + q + lane + 64 * c <= Nmax) sacc[q] += __expf(tv[q][c] - m);
-        }
-        const float sw = reduce8_over_wave(sacc, lane);              // lane l: the sum of j0 + (l >> 3)
-        if ((lane & 7) == 0) {
-            const int j = j0 + (lane >> 3);
-            const float v = (j <= Nmax) ? (safe_log(sw) + mxw) - (float)j * lWq : LOG0F;
-            if (j <= M) Q.I0[j] = v;
-            if (j >= 1) Q.I1[j - 1] = v;
-        }
-        j0 += 8;
-    }
+    for (; j_hi - j0 >= 8; j0 += 8) cphd_nsums_batch<8>(Q, M, Nmax, lane, j0, j_hi, lWq);
+    // what is left (two of the 66 values of a 64-measurement scan over seven waves) one j at a time (batches of four, the last
+    // one padded, were measured slower: 1 947 vs 1 975 steps/s)
     for (int j = j0; j < j_hi; ++j) {
         float tv[4];
         float mx = LOG0F;
@@ -729,6 +816,8 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     LDS_T(double)* const c_lds = dsum + M;
     LDS_T(double)* const sh_row = dsum + 3 * M;
     LDS_T(int)* const sh_exp = (LDS_T(int)*)&L.ctr[CTR_NHEAD];        // (a merge counter: free until the merge)
+    // (giving the sweep wave, free two thirds into the phase, the last 6 of the 66 n-sums was measured: no gain — 1 967 vs 1 975 steps/s)
+    const int j_w0 = 0;
     if (wave == 0) {
         if (f64 && rows_in_lds) cphd_esf_forward_park_f64(Q, rows_l, 64, M, 0, lane);
         else if (f64) cphd_esf_forward_park_f64(Q, rows_g, MM, M, 0, lane);
@@ -783,8 +872,9 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
             GSTAMP(19, 64);  // B_n done
             if (cn_len <= 256) {
                 // j = 0 .. M + 1 in contiguous ranges
-                const int per = (M + 2 + W7 - 1) / W7;
-                const int jl = w7 * per, jh = (jl + per < M + 2) ? jl + per : M + 2;
+                const int nj = M + 2 - j_w0;
+                const int per = (nj + W7 - 1) / W7;
+                const int jl = w7 * per, jh = (jl + per < nj) ? jl + per : nj;
                 if (per <= 16) { if (jl < jh) cphd_nsums_fast8(Q, M, Nmax, lane, jl, jh, lWq); }
                 else cphd_nsums_fast<4>(Q, M, Nmax, lane, w7, W7, lWq);
             }
