@@ -22,7 +22,7 @@ normalise / resample on every rank -> migration of the particles whose parent li
 (all_to_all over xGMI).  `value` = filter steps/s (K / time, not multiplied by N).  The round-1 weak-scaling
 workload (256 x 64 x 32 per rank) is kept as a labelled secondary.
 
-Clock pre-roll: before the W counted warm-up steps the same step runs, un-counted, for >= 200 ms
+Clock pre-roll: before the W counted warm-up steps the same step runs, un-counted, for >= 400 ms
 (`preroll_steps` in the output), so that a 25-step run reads the clocks a long run reads.
 
 Prints ONE JSON line (rank 0) with
@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide: peak FP32 (vector)
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
-PREROLL_MS = 200.0
+PREROLL_MS = 400.0
 
 
 def cpu_model():
@@ -636,7 +636,7 @@ def _flush_c_stdio():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 200 timed steps of 0.4 ms after the clock pre-roll
+    # defaults: 200 timed steps of 0.35 ms after the clock pre-roll
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=0,
