@@ -234,3 +234,40 @@ def test_cphd_config5_size():
         live = ref["cn"] > -40
         assert np.allclose(cn[p][live], ref["cn"][live], atol=1e-2), np.abs(cn[p][live] - ref["cn"][live]).max()
         assert abs(len(maps[p]) - len(ref["map"])) <= 2
+
+
+def test_cphd_with_a_spill_list_fused_equals_staged():
+    """the CPHD variant on a dense scan whose survivor lists exceed the LDS capacity (M = 200 > 64: the mantissa / exponent ESF
+    sweeps; 2 310 survivors: phd_merge_spill_kernel): the single-launch step against the staged calls, bit for bit, over two
+    steps with a resample in between (the spill merge reads the parent's slab, the cardinality rows follow the particles)"""
+    import torch
+    P, S = pkg(), synthetic()
+    N, G, M = 6, 300, 200
+    w = S.make_workload(N, G, M, seed=4242, clustered=True, n_meas_sets=2)
+    cfg = P.default_config(filterType=1, maxCardinality=255, clutterRate=200.0)
+    dev = torch.device("cuda:0")
+
+    def mk():
+        f = P.PhdFilter(cfg, n_particles=N, map_capacity=768, max_measurements=200, survivor_capacity=4096)
+        f.set_particles(w["poses"], w["logw"])
+        f.set_maps(w["maps"], w["sizes"])
+        return f
+    with mk() as a, mk() as b:
+        b.debug(4)
+        for k in range(2):
+            dz = torch.from_numpy(w["z"][k].view(np.uint8).copy()).to(dev)
+            dn = torch.from_numpy(w["noise"][k].copy()).to(dev)
+            torch.cuda.synchronize()
+            a.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, w["uniform"][k], force_resample=True)
+            a.sync()
+            b.predict((2.0, 0.05), w["noise"][k])
+            b.update(w["z"][k])
+            b.resample(w["uniform"][k])
+            sa, sb = a.status(), b.status()
+            assert sa == sb and sa["status"] == 0 and sa["max_survivors"] > 2048, (sa, sb)
+            pa, la = a.get_particles()
+            pb, lb = b.get_particles()
+            assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+            for x, y in zip(a.get_maps(), b.get_maps()):
+                assert np.array_equal(x, y)
+            assert np.array_equal(a.cardinalities(), b.cardinalities())
