@@ -44,6 +44,26 @@ __device__ __forceinline__ bool is_close(float smx, float smy, float sxx, float 
     return mahal_dist(smx, smy, sxx, sxy, syy, emx, emy, exx, exy, eyy) < T;
 }
 
+// Is a seed within the merge distance of ITSELF (src/phdfilter.cu:2802-2806 evaluates d(s, s) like any other pair: a seed
+// whose distance to itself is NaN — singular or non-finite covariance — stays out of its own cluster)?
+// Mahalanobis, the common case without the four divisions: with a finite mean the offsets are exactly 0, and with
+// |P| <= 2^60, det >= 2^-60 every quotient of mahal_dist() is finite (< 2^121), so the distance is exactly 0 (+-0 + +-0).
+// Anything else evaluates the formula itself.
+template <bool HELLINGER>
+__device__ __forceinline__ bool seed_close_to_itself(float mx, float my, float xx, float xy, float yy, float T)
+{
+#pragma clang fp contract(off)
+    if (!HELLINGER) {
+        const float BIG = 1.152921504606846976e18f, SMALL = 8.67361737988403547e-19f;   // 2^60, 2^-60
+        const float det = xx * yy - xy * xy;                     // = mahal_dist's det: (P + P) / 2 is P exactly below 2^60
+        // (a NaN anywhere fails its comparison — fmaxf() would drop it)
+        const bool tame = fabsf(xx) <= BIG && fabsf(xy) <= BIG && fabsf(yy) <= BIG && fabsf(mx) <= BIG && fabsf(my) <= BIG;
+        if (tame && det >= SMALL) return 0.f < T;
+    }
+    const float dself = HELLINGER ? hellinger_dist(mx, my, xx, xy, yy, mx, my, xx, xy, yy) : mahal_dist(mx, my, xx, xy, yy, mx, my, xx, xy, yy);
+    return dself < T;
+}
+
 // ------------------------------------------------------------------------------------------
 // Moment matching by exact, order-free sums (phd_fixsum.h), shared by both LDS merges.
 // The reference adds a cluster's members with a reduction tree (src/phdfilter.cu:2795-2881); round 2 grouped the
@@ -76,9 +96,7 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         const int Fw = fx_field(ci.z);
         if (__float_as_int(ci.w) == i) {
             // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
-            const float dself = HELLINGER ? hellinger_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z)
-                                          : mahal_dist(a.x, a.y, b.x, b.y, b.z, a.x, a.y, b.x, b.y, b.z);
-            if (!(dself < T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+            if (!seed_close_to_itself<HELLINGER>(a.x, a.y, b.x, b.y, b.z, T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
         }
         FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
         fx_add_first(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);

@@ -268,7 +268,6 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
                                                       float Tpre, bool hellinger, const BucketMap& bm)
 {
     lds_u32 cntc = (lds_u32)L.tr;     // per bucket: count -> (placed << 16) | start
-    lds_u32 members = L.pay;          // bucket segments in arrival order
     const int NB = S_cap;             // buckets: a power of two >= 512
     // exclusive scan over the buckets (thread t owns buckets [t per, (t + 1) per)), and the largest bucket
     {
@@ -300,42 +299,45 @@ __device__ __forceinline__ bool bucket_sort_survivors(const Lds& L, int S, int S
             if (e < per) { cntc[lo + e] = run; run += v[e]; }
     }
     __syncthreads();
-    // keys (weight | ~slab index) and the bucket segments
-    u32 mh[4], ml[4];
+    // keys (weight | ~slab index), stored IN BUCKET ORDER (arrival order inside a bucket): the rank loop then reads its
+    // bucket's keys straight from consecutive slots — one LDS round trip per step instead of index -> key
+    LDS_T(u64)* const bkeys = (LDS_T(u64)*)L.khi;              // [S]: the khi and klo planes are adjacent
+    u64 mine[4];
     int bk[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = tid + e * PHD_T;
-        mh[e] = 0u; ml[e] = 0u; bk[e] = 0;
+        mine[e] = 0ull; bk[e] = 0;
         if (i < S) {
             const int u0 = L.u[i];
             const float w = L.w[i];
-            mh[e] = orderable(w);
-            ml[e] = 0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0);
-            L.khi[i] = mh[e]; L.klo[i] = ml[e];
+            mine[e] = ((u64)orderable(w) << 32) | (0xFFFFFFFFu - (u32)(u0 >= NEAR_U_BASE ? u0 - NEAR_U_BASE + n_update : u0));
             bk[e] = bucket_of(bm, w);
             const u32 old = atomicAdd((u32*)&cntc[bk[e]], 0x10000u);
-            members[(old & 0xFFFFu) + (old >> 16)] = (u32)i;
+            bkeys[(old & 0xFFFFu) + (old >> 16)] = mine[e];
         }
     }
     __syncthreads();
+    // rank inside the bucket = keys above mine (keys are unique: (weight, slab index)).  A thread's entries e, e + 1 walk
+    // their buckets together, two keys each per trip: four independent reads in flight (the walk is LDS latency)
     int rank[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = tid + e * PHD_T;
-        rank[e] = 0;
-        if (i < S) {
-            const u32 c = cntc[bk[e]];
-            const int base = (int)(c & 0xFFFFu), k = (int)(c >> 16);
-            const u64 mine = ((u64)mh[e] << 32) | ml[e];
-            int r = 0;
-            for (int t = 0; t < k; ++t) {
-                const int m = (int)members[base + t];
-                const u64 o = ((u64)L.khi[m] << 32) | L.klo[m];
-                r += (o > mine) ? 1 : 0;                           // keys are unique: (weight, slab index)
-            }
-            rank[e] = base + r;
+    for (int ep = 0; ep < 4; ep += 2) {
+        rank[ep] = rank[ep + 1] = 0;
+        if (ep * PHD_T >= S) continue;                            // uniform
+        const bool v0 = tid + ep * PHD_T < S, v1 = tid + (ep + 1) * PHD_T < S;
+        const u32 c0 = v0 ? cntc[bk[ep]] : 0u, c1 = v1 ? cntc[bk[ep + 1]] : 0u;
+        const int b0 = (int)(c0 & 0xFFFFu), k0 = (int)(c0 >> 16), b1 = (int)(c1 & 0xFFFFu), k1 = (int)(c1 >> 16);
+        const int kk = k0 > k1 ? k0 : k1;
+        int r0 = 0, r1 = 0;
+        for (int t = 0; t < kk; t += 2) {
+            // (reads past a bucket's end fall into the next buckets or the slack behind the list: masked, never used)
+            const u64 a0 = bkeys[b0 + t], a1 = bkeys[b0 + t + 1], d0 = bkeys[b1 + t], d1 = bkeys[b1 + t + 1];
+            r0 += ((t < k0 && a0 > mine[ep]) ? 1 : 0) + ((t + 1 < k0 && a1 > mine[ep]) ? 1 : 0);
+            r1 += ((t < k1 && d0 > mine[ep + 1]) ? 1 : 0) + ((t + 1 < k1 && d1 > mine[ep + 1]) ? 1 : 0);
         }
+        rank[ep] = b0 + r0;
+        rank[ep + 1] = b1 + r1;
     }
     // the planes are staged through registers only now (short live ranges: the kernel sits at its register budget)
     float rw[4], rmx[4], rmy[4], rxx[4], rxy[4], ryy[4];

@@ -260,9 +260,7 @@ __device__ __forceinline__ void merge_spill_body(const UpdateArgs& A, int p, int
         const int Fw = fx_field(ci[2]);
         unsigned* fl = (unsigned*)(acc + (size_t)c * 8 + 5);            // word 10: largest exponent, word 11: flags
         if (__float_as_int(ci[3]) == i) {
-            const float dself = HELLINGER ? hellinger_dist(r[1], r[2], r[3], r[4], r[5], r[1], r[2], r[3], r[4], r[5])
-                                          : mahal_dist(r[1], r[2], r[3], r[4], r[5], r[1], r[2], r[3], r[4], r[5]);
-            if (!(dself < T)) { atomicOr(fl + 1, 2u); continue; }
+            if (!seed_close_to_itself<HELLINGER>(r[1], r[2], r[3], r[4], r[5], T)) { atomicOr(fl + 1, 2u); continue; }
         }
         FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
         fx_add_first(fs, Fw, ci[0], ci[1], r[0], r[1], r[2], r[3], r[4], r[5]);
