@@ -871,6 +871,49 @@ def test_spill_path_reads_the_parent_slab_after_a_resample():
                         assert np.all(far["mean"][:, 0] == np.float32(30.0 + idx[p])), (p, idx[p], far["mean"][:, 0])
 
 
+def test_seed_self_distance_corner_cases():
+    """the reference evaluates d(seed, seed) like any other pair (src/phdfilter.cu:2802-2806): a seed whose distance to itself
+    is NaN stays out of its own cluster, is picked again and ends the loop with W == 0 (:2821).  The device takes that
+    decision without the four divisions when the covariance is tame (csrc/phd_merge.h, seed_close_to_itself) and with the
+    formula otherwise: singular and zero covariances, a determinant below 2^-60, entries above 2^60, a cancelling
+    determinant — device == oracle bit for bit, map lengths included."""
+    P, S = pkg(), synthetic()
+    cfg = P.default_config(minFeatureWeight=0.0)
+    ocfg = oracle_config_from(cfg)
+    cases = [
+        ((0.04, 0.04, 0.04, 0.04), "singular: det == 0"),
+        ((0.0, 0.0, 0.0, 0.0), "zero covariance"),
+        ((1e-10, 0.0, 0.0, 1e-10), "det 1e-20 < 2^-60: the formula, finite"),
+        ((1e-25, 0.0, 0.0, 1e-25), "det underflows to 0"),
+        ((2e18, 0.0, 0.0, 0.5), "an entry above 2^60"),
+        ((3e19, 0.0, 0.0, 3e19), "det overflows to inf"),
+        ((1.0, 1.0 - 2.0 ** -23, 1.0 - 2.0 ** -23, 1.0), "cancelling determinant (2^-22)"),
+        ((0.04, 0.0, 0.0, 0.04), "tame"),
+    ]
+    for ci, (cov, what) in enumerate(cases):
+        w = S.make_workload(2, 12, 5, seed=140 + ci)
+        maps = w["maps"].copy()
+        # nearly-in-range features (15 m < r <= 18 m) join the merge untouched: the heaviest of them seeds the first cluster
+        for p in range(2):
+            maps[p, 0]["mean"] = (16.0, 0.5); maps[p, 0]["weight"] = 5.0; maps[p, 0]["cov"] = cov
+            maps[p, 1]["mean"] = (16.02, 0.5); maps[p, 1]["weight"] = 0.7; maps[p, 1]["cov"] = (0.04, 0.0, 0.0, 0.04)
+        w["maps"] = maps
+        with make_filter(cfg, w, cap=64) as f:
+            f.debug(True)
+            f.update(w["z"][0])
+            f.status()
+            got = f.get_maps()
+            for p in range(2):
+                gmap = w["maps"][p, :w["sizes"][p]]
+                cls = O.classify(gmap, w["poses"][p], ocfg)
+                surv, _ = f.survivors(p)
+                om = O.merge(surv, ocfg)
+                want = np.concatenate([om, gmap[cls == 0]]) if (cls == 0).any() else om
+                assert len(got[p]) == len(want), (what, p, len(got[p]), len(want))
+                for fld in ("weight", "mean", "cov"):
+                    assert np.array_equal(got[p][fld].view(np.uint32), want[fld].view(np.uint32)), (what, p, fld)
+
+
 def test_exact_moment_sums_corner_cases():
     """the fixed-point moment sums (csrc/phd_fixsum.h, oracle o_exact_*) at their edges, device == oracle bit for bit (NaN
     patterns included): a member whose weight exceeds the seed's anchor (a negative weight of larger magnitude) poisons its
