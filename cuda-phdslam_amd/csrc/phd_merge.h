@@ -483,8 +483,13 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     lds_i32 wpos = (lds_i32)L.rwin;
     LDS_T(v4f)* const wA = (LDS_T(v4f)*)(L.rwin + 64);         // the window's copy of gA / gB
     LDS_T(v4f)* const wB = (LDS_T(v4f)*)(L.rwin + 64 + 256);
-    LDS_T(v4f)* const sF = (LDS_T(v4f)*)(L.rwin + 64 + 512);          // the round's seeds in order: (-2 mx, -2 my, E, survivor index)
-    LDS_T(v4f)* const sG = sF + 72;                                  //                             (cov xx, xy, yy, -)
+    // the round's seeds in order, laid out for the packed filter — a register PAIR per operand, no moves to assemble it:
+    //   sP[k] = (E_2k, E_2k+1, -2 mx_2k, -2 mx_2k+1)   sQ[k] = (-2 my_2k, -2 my_2k+1)   sG[r] = (cov xx, xy, yy, cluster index)
+    LDS_T(v4f)* const sP = (LDS_T(v4f)*)(L.rwin + 64 + 512);         // 36 entries (64 seeds + padding to a multiple of 8)
+    LDS_T(v2f)* const sQ = (LDS_T(v2f)*)(sP + 36);                   // 36 entries
+    LDS_T(v4f)* const sG = sP + 72;
+    LDS_T(float)* const sPf = (LDS_T(float)*)sP;
+    LDS_T(float)* const sQf = (LDS_T(float)*)sQ;
     for (int i = tid; i < S; i += PHD_T) ul_a[i] = (u16)i;
     int n_u = S;
     int kbase = 0;                                             // seeds of the rounds so far = clusters opened
@@ -588,12 +593,18 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         {
             const int rank = __popcll(seeds & lanemask_lt());
             if ((seeds >> lane) & 1ull) {
-                sF[rank] = (v4f){m2x, m2y, kE, __int_as_float(kbase + rank)};
-                sG[rank] = wB[lane];
+                const int pr = 4 * (rank >> 1) + (rank & 1);
+                sPf[pr] = kE; sPf[pr + 2] = m2x; sQf[rank] = m2y;
+                v4f g = wB[lane];
+                g.w = __int_as_float(kbase + rank);
+                sG[rank] = g;
                 // the seed's record for the moment sums after the rounds (one wave writes it)
                 if (wave == 0 && kbase + rank < cap) L.cinfo[kbase + rank] = (v4f){kx, ky, ka.w, __int_as_float(wpos[lane])};
             }
-            if (lane < 8) sF[nseeds + lane] = (v4f){0.f, 0.f, INFINITY, 0.f};   // pad to a multiple of 8: never a candidate
+            if (lane < 8) {                                       // pad to a multiple of 8: never a candidate
+                const int rp = nseeds + lane, pr = 4 * (rp >> 1) + (rp & 1);
+                sPf[pr] = INFINITY; sPf[pr + 2] = 0.f; sQf[rp] = 0.f;
+            }
         }
         const int per = (nrest + PHD_T - 1) / PHD_T;           // entries per thread
         RSTAMP(2);
@@ -616,16 +627,17 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             u32 mlo = 0, mhi = 0;
             // eight seeds per trip, their records requested together (LDS broadcast reads), descending: v_alignbit
             // shifts the mask left
-#define PHD_SEED_PAIR(M, f0, f1) do {                                                                  \
-                v2f t_ = (v2f){(f0).z, (f1).z} + eE2;                                                    \
-                t_ = __builtin_elementwise_fma((v2f){(f0).x, (f1).x}, ex2, t_);                          \
-                t_ = __builtin_elementwise_fma((v2f){(f0).y, (f1).y}, ey2, t_);                          \
+#define PHD_SEED_PAIR(M, p_, q_) do {                                                                  \
+                v2f t_ = (p_).xy + eE2;                                                                  \
+                t_ = __builtin_elementwise_fma((p_).zw, ex2, t_);                                        \
+                t_ = __builtin_elementwise_fma((q_), ey2, t_);                                           \
                 M = __builtin_amdgcn_alignbit(M, __float_as_uint(t_.y), 31);                             \
                 M = __builtin_amdgcn_alignbit(M, __float_as_uint(t_.x), 31); } while (0)
 #define PHD_SEED_OCTET(M, r) do {                                                                      \
-                const v4f f0 = sF[(r) + 0], f1 = sF[(r) + 1], f2 = sF[(r) + 2], f3 = sF[(r) + 3],        \
-                          f4 = sF[(r) + 4], f5 = sF[(r) + 5], f6 = sF[(r) + 6], f7 = sF[(r) + 7];        \
-                PHD_SEED_PAIR(M, f6, f7); PHD_SEED_PAIR(M, f4, f5); PHD_SEED_PAIR(M, f2, f3); PHD_SEED_PAIR(M, f0, f1); } while (0)
+                const int k_ = (r) >> 1;                                                                 \
+                const v4f p0 = sP[k_ + 0], p1 = sP[k_ + 1], p2 = sP[k_ + 2], p3 = sP[k_ + 3];            \
+                const v2f q0 = sQ[k_ + 0], q1 = sQ[k_ + 1], q2 = sQ[k_ + 2], q3 = sQ[k_ + 3];            \
+                PHD_SEED_PAIR(M, p3, q3); PHD_SEED_PAIR(M, p2, q2); PHD_SEED_PAIR(M, p1, q1); PHD_SEED_PAIR(M, p0, q0); } while (0)
             const int ntop = (nseeds + 7) & ~7;
             for (int r = ntop - 8; r >= 32; r -= 8) PHD_SEED_OCTET(mhi, r);
             for (int r = (ntop < 32 ? ntop : 32) - 8; r >= 0; r -= 8) PHD_SEED_OCTET(mlo, r);
@@ -645,9 +657,10 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 #ifdef PHD_ASSIGN_STATS
                     if (STAMPS) atomicAdd((unsigned long long*)&st[26], 1ull);
 #endif
-                    const v4f f = sF[r], g = sG[r];             // the seed's mean is -(−2 m)/2, exactly
-                    if (is_close<HELLINGER>(-0.5f * f.x, -0.5f * f.y, g.x, g.y, g.z, ea.x, ea.y, fb.x, fb.y, fb.z, T)) {
-                        asg[4 * i + 3] = __float_as_int(f.w);
+                    const float f2x = sPf[4 * (r >> 1) + 2 + (r & 1)], f2y = sQf[r];   // the seed's mean is -(−2 m)/2, exactly
+                    const v4f g = sG[r];
+                    if (is_close<HELLINGER>(-0.5f * f2x, -0.5f * f2y, g.x, g.y, g.z, ea.x, ea.y, fb.x, fb.y, fb.z, T)) {
+                        asg[4 * i + 3] = __float_as_int(g.w);
                         merged = true;
 #ifdef PHD_ASSIGN_STATS
                         if (STAMPS) atomicAdd((unsigned long long*)&st[27], 1ull);
