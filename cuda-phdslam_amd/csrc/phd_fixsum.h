@@ -141,4 +141,67 @@ __device__ __forceinline__ float fx_cov(i64 c, i64 Wq, int Fc, int Fw)
     return (float)__builtin_ldexp((double)c / (double)Wq, (Fc - FX_C_TOP) - (Fw - FX_W_TOP));
 }
 
+// ---- the same integers carried in doubles (the LDS merges) ----------------------------------------------------------------
+// A term has 24 significant bits and, when it is `ok`, fewer than 2^53 of magnitude; sums of up to 2048 of them stay below
+// 2^53 (see above), so adding them as DOUBLES is exact — still integer arithmetic, still order-free, bit for bit the sums of
+// the 64-bit integer path — and the conversion is three instructions (v_cvt_f64_f32, v_ldexp_f64, v_trunc_f64) instead of
+// the mantissa surgery of fx_q(); LDS adds doubles atomically (ds_add_f64).  The spill merge (HBM accumulators) keeps integers.
+__device__ __forceinline__ double fx_qd(float x, int F, int top, bool& ok)
+{
+    const u32 ef = (__float_as_uint(x) >> 23) & 0xFFu;
+    ok = ok && ef != 255u && (int)(ef ? ef : 1u) <= F;
+    return __builtin_trunc(__builtin_ldexp((double)x, top + 150 - F));   // = fx_q(x, F, top): trunc(|x| 2^(top + 150 - F)), signed
+}
+// the two 31-bit digits (both carrying the sign, like fx_digits): exact, q has 24 significant bits
+__device__ __forceinline__ void fx_digits_d(double q, double& hi, double& lo)
+{
+    hi = __builtin_trunc(q * 4.656612873077392578125e-10);               // 2^-31
+    lo = __builtin_fma(hi, -2147483648.0, q);
+}
+struct FxSumsD {
+    double W, xh, xl, yh, yl;
+    int ec;
+    bool ok;
+};
+// pass 1 term (fx_add_first)
+__device__ __forceinline__ void fx_first_d(FxSumsD& s, int Fw, float smx, float smy, float w, float mx, float my, float xx, float xy,
+                                           float yy)
+{
+#pragma clang fp contract(off)
+    bool ok = true;
+    s.W = fx_qd(w, Fw, FX_W_TOP, ok);
+    fx_digits_d(fx_qd(w * mx, Fw + FX_M_HEAD, FX_M_TOP, ok), s.xh, s.xl);         // src/phdfilter.cu:2813
+    fx_digits_d(fx_qd(w * my, Fw + FX_M_HEAD, FX_M_TOP, ok), s.yh, s.yl);
+    const float dx = mx - smx, dy = my - smy;
+    int e = fx_field(xx);
+    const int e2 = fx_field(xy), e3 = fx_field(yy), e4 = fx_field(dx * dx), e5 = fx_field(dy * dy);
+    e = e2 > e ? e2 : e; e = e3 > e ? e3 : e; e = e4 > e ? e4 : e; e = e5 > e ? e5 : e;
+    s.ec = e;
+    s.ok = ok;
+}
+// (:2828) fx_mean on double sums
+__device__ __forceinline__ void fx_mean_d(const FxSumsD& s, int Fw, float& W, float& mx, float& my)
+{
+    W = (float)__builtin_ldexp(s.W, Fw - 150 - FX_W_TOP);
+    const double sx = __builtin_fma(s.xh, 2147483648.0, s.xl);
+    const double sy = __builtin_fma(s.yh, 2147483648.0, s.yl);
+    mx = (float)(sx / s.W * 64.0);
+    my = (float)(sy / s.W * 64.0);
+}
+// pass 2 term (fx_cov_terms)
+__device__ __forceinline__ void fx_cov_terms_d(int Fc, float mean_x, float mean_y, float w, float mx, float my, float xx, float xy,
+                                               float yy, double& qxx, double& qxy, double& qyy, bool& ok)
+{
+#pragma clang fp contract(off)
+    const float d0 = mean_x - mx, d1 = mean_y - my;
+    qxx = fx_qd(w * (xx + d0 * d0), Fc, FX_C_TOP, ok);
+    qxy = fx_qd(w * (xy + d0 * d1), Fc, FX_C_TOP, ok);
+    qyy = fx_qd(w * (yy + d1 * d1), Fc, FX_C_TOP, ok);
+}
+// (:2879) fx_cov on double sums
+__device__ __forceinline__ float fx_cov_d(double c, double Wq, int Fc, int Fw)
+{
+    return (float)__builtin_ldexp(c / Wq, (Fc - FX_C_TOP) - (Fw - FX_W_TOP));
+}
+
 } // namespace phd

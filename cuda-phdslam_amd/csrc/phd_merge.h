@@ -82,6 +82,7 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
 {
     const int K = n_clusters < cap ? n_clusters : cap;         // clusters past the map capacity are reported, not stored
     LDS_T(u32)* const acc32 = (LDS_T(u32)*)acc;
+    LDS_T(double)* const accd = (LDS_T(double)*)acc;            // the sums: integers carried in doubles (phd_fixsum.h), 6 per cluster
     if (tid == 0) { ctr[CTR_NHEAD] = n_clusters; ctr[CTR_KOUT] = n_clusters; }
     for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -98,9 +99,9 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
             // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
             if (!seed_close_to_itself<HELLINGER>(a.x, a.y, b.x, b.y, b.z, T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
         }
-        FxSums fs = {0, 0, 0, 0, 0, 0, 0, 0, 0, true};
-        fx_add_first(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
-        LDS_T(i64)* const q = acc + 6 * c;
+        FxSumsD fs;
+        fx_first_d(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
+        LDS_T(double)* const q = accd + 6 * c;
         __hip_atomic_fetch_add(q + 0, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 1, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 2, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -113,21 +114,21 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
     STAMP(8);
     // per cluster: W, mean (:2828), the stop rule (:2821); the slot becomes (cxx, cxy, cyy, W | mean x, mean y, scales, flags)
     for (int c = tid; c < K; c += PHD_T) {
-        FxSums fs;
-        fs.W = acc[6 * c + 0]; fs.xh = acc[6 * c + 1]; fs.xl = acc[6 * c + 2]; fs.yh = acc[6 * c + 3]; fs.yl = acc[6 * c + 4];
+        FxSumsD fs;
+        fs.W = accd[6 * c + 0]; fs.xh = accd[6 * c + 1]; fs.xl = accd[6 * c + 2]; fs.yh = accd[6 * c + 3]; fs.yl = accd[6 * c + 4];
         const u32 ec = acc32[12 * c + 10], fl = acc32[12 * c + 11];
         const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
         const int Fw = fx_field(cinfo[c].z);
         // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then yields W == 0
         int stop_at = 0x7FFFFFFF;
-        if (fs.W == 0 && ok) stop_at = c;
+        if (fs.W == 0.0 && ok) stop_at = c;
         else if (!selfok) stop_at = c + 1;
         if (stop_at != 0x7FFFFFFF) atomicMin((int*)&ctr[CTR_KOUT], stop_at);
         float W, mx, my;
-        fx_mean(fs, Fw, W, mx, my);
+        fx_mean_d(fs, Fw, W, mx, my);
         const int Fc = fx_cov_anchor(Fw, (int)ec);
-        acc[6 * c + 0] = 0; acc[6 * c + 1] = 0; acc[6 * c + 2] = 0;
-        acc[6 * c + 3] = fs.W;
+        accd[6 * c + 0] = 0.0; accd[6 * c + 1] = 0.0; accd[6 * c + 2] = 0.0;
+        accd[6 * c + 3] = fs.W;
         acc32[12 * c + 8] = __float_as_uint(mx); acc32[12 * c + 9] = __float_as_uint(my);
         acc32[12 * c + 10] = (u32)Fc | ((u32)Fw << 16);
         acc32[12 * c + 11] = (ok ? 0u : 1u) | (fl & 2u);
@@ -147,9 +148,9 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         // (flag 2: the seed is not in its own cluster, decided in pass A)
         if ((__float_as_uint(h.w) & 2u) && __float_as_int(cinfo[c].w) == i) continue;
         bool ok = true;
-        i64 qxx, qxy, qyy;
-        fx_cov_terms((int)(sc & 0xFFFFu), h.x, h.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
-        LDS_T(i64)* const q = acc + 6 * c;
+        double qxx, qxy, qyy;
+        fx_cov_terms_d((int)(sc & 0xFFFFu), h.x, h.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
+        LDS_T(double)* const q = accd + 6 * c;
         __hip_atomic_fetch_add(q + 0, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 1, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 2, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -158,7 +159,7 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
     __syncthreads();
     // per cluster: covariance = sum / W (:2879; the symmetric form needs no force_symmetric_covariance)
     for (int c = tid; c < K; c += PHD_T) {
-        const i64 cxx = acc[6 * c + 0], cxy = acc[6 * c + 1], cyy = acc[6 * c + 2], Wq = acc[6 * c + 3];
+        const double cxx = accd[6 * c + 0], cxy = accd[6 * c + 1], cyy = accd[6 * c + 2], Wq = accd[6 * c + 3];
         const u32 sc = acc32[12 * c + 10];
         const int Fc = (int)(sc & 0xFFFFu), Fw = (int)(sc >> 16);
         if (acc32[12 * c + 11] & 1u) {
@@ -166,9 +167,9 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
 #pragma unroll
             for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + c] = bad;
         } else {
-            out_slab[3 * cap + c] = fx_cov(cxx, Wq, Fc, Fw);
-            out_slab[4 * cap + c] = fx_cov(cxy, Wq, Fc, Fw);
-            out_slab[5 * cap + c] = fx_cov(cyy, Wq, Fc, Fw);
+            out_slab[3 * cap + c] = fx_cov_d(cxx, Wq, Fc, Fw);
+            out_slab[4 * cap + c] = fx_cov_d(cxy, Wq, Fc, Fw);
+            out_slab[5 * cap + c] = fx_cov_d(cyy, Wq, Fc, Fw);
         }
     }
 }
