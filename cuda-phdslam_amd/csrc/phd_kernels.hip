@@ -54,7 +54,12 @@
 namespace phd {
 
 // host-visible sizes (declared in phd_device.h)
-size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total; }
+// (PHD_LDS_PAD: occupancy experiments — extra bytes per workgroup; -DPHD_LDS_PAD=16384 leaves ONE workgroup per CU at the
+// headline size: 578 us per launch against 348 with two, per-workgroup time 36.6 against 43.2 us — DESIGN.md §9)
+#ifndef PHD_LDS_PAD
+#define PHD_LDS_PAD 0
+#endif
+size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total + PHD_LDS_PAD; }
 int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
 size_t cphd_lds_bytes(int cn_len, int MM)
 {

@@ -8,6 +8,16 @@ python -m pytest tests -m gpu -q --timeout 900 --durations=8 -s > gpurun_out/gpu
 echo "pytest rc=$?" >> gpurun_out/gpu_tests_$tag.log
 grep -E "structurally compared|passed|failed|error" gpurun_out/gpu_tests_$tag.log | tail -12
 python __graft_entry__.py smoke 2>&1 | tail -1
+# the PMC passes first: bench.py prints `roofline.traffic` / `roofline_valu` only from counters recorded with THIS build
+# (tools/collect_profiles.sh copies the same files into profiles/ afterwards)
+if [ -z "$quick" ]; then
+  bash tools/pmc_traffic.sh 3 $tag
+  bash tools/pmc_traffic.sh 2 $tag
+  bash tools/pmc_sq.sh 3 $tag > gpurun_out/sq_counters_$tag.txt 2>&1
+  bash tools/pmc_sq.sh 2 $tag >> gpurun_out/sq_counters_$tag.txt 2>&1
+  tail -3 gpurun_out/sq_counters_$tag.txt | cut -c1-600
+  cp gpurun_out/pmc_traffic_cfg2.json gpurun_out/pmc_traffic_cfg3.json gpurun_out/pmc_sq_cfg2.json gpurun_out/pmc_sq_cfg3.json profiles/
+fi
 # exactly what the driver runs
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_$tag.json 2> gpurun_out/bench_driver_$tag.err
 python - <<PY
@@ -52,8 +62,3 @@ for cfg in 3 2 5; do
   [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_cfg${cfg}_$tag.csv && head -4 $f
 done
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_traffic.sh 3 $tag
-bash tools/pmc_traffic.sh 2 $tag
-bash tools/pmc_sq.sh 3 $tag > gpurun_out/sq_counters_$tag.txt 2>&1
-bash tools/pmc_sq.sh 2 $tag >> gpurun_out/sq_counters_$tag.txt 2>&1
-tail -3 gpurun_out/sq_counters_$tag.txt | cut -c1-600
