@@ -52,8 +52,9 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
     the configuration), more than the 102 SGPRs of a wave: the compiler parks the excess in lanes of a spare VGPR
     (v_writelane / v_readlane with a constant lane — VALU instructions in a VALU-bound kernel).  VERDICT r1 asked to
     bring `SGPRs Spill` to 0 or to show from the ISA that the spills sit outside the loops: this test does the latter
-    on every build — no spill reload or store at loop depth >= 2 of the production instantiations, and at most a few
-    dozen at depth 1 (the bodies of the phase loops: once per merge round / measurement chunk, not per pair)."""
+    on every build — no spill reload or store at loop depth >= 2 of the production instantiations, and at depth 1 (the
+    bodies of the phase loops: once per merge round / measurement chunk, not per pair) at most 8 % of the instructions of
+    the loop body they sit in."""
     text = compiled[1]
     checked = 0
     for tag in TAGS:
@@ -62,7 +63,8 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
         body = m.group(0).split("\n")
         # spill slots: VGPR lanes written with v_writelane from an SGPR at a CONSTANT lane index
         holders = set(re.findall(r"v_writelane_b32 (v\d+), s\d+, \d+", m.group(0)))
-        depth, by_depth = 0, {}
+        depth, by_depth, loop = 0, {}, None
+        per_loop = {}                                 # depth-1 loop header -> [spill moves, instructions]
         for i, line in enumerate(body):
             if re.match(r"^\.LBB\d+_\d+:|^; %bb\.", line):
                 ctx = line
@@ -74,14 +76,29 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
                 # header describe the loops inside it, not this block)
                 d = re.findall(r"(?:in Loop: Header=\S+|This (?:Inner )?Loop Header:) Depth=(\d+)", ctx)
                 depth = max(int(x) for x in d) if d else 0
-            sp = re.search(r"v_(?:readlane_b32 s\d+, (v\d+), \d+|writelane_b32 (v\d+), s\d+, \d+)\s*$", line.strip())
+                h = re.findall(r"in Loop: Header=(\S+) Depth=1", ctx)
+                loop = h[0] if h else (line.split(":")[0].lstrip(".L") if "Loop Header: Depth=1" in ctx else None)
+                if loop:
+                    loop = loop.lstrip(".L")
+            t = line.strip()
+            is_instr = bool(t) and not t.startswith(";") and not t.startswith(".") and not t.endswith(":")
+            if is_instr and depth >= 1 and loop:
+                per_loop.setdefault(loop, [0, 0])[1] += 1
+            sp = re.search(r"v_(?:readlane_b32 s\d+, (v\d+), \d+|writelane_b32 (v\d+), s\d+, \d+)\s*$", t)
             if sp and (sp.group(1) or sp.group(2)) in holders:
                 by_depth[depth] = by_depth.get(depth, 0) + 1
+                if depth == 1 and loop:
+                    per_loop.setdefault(loop, [0, 0])[0] += 1
         deep = sum(v for d, v in by_depth.items() if d >= 2)
         # (the spill-list instantiations — filters created with survivor_capacity > 2048, a correctness path, DESIGN.md §7 —
         # carry two more pointers and reload them in the survivor emit loop: per emitted component, not per pair)
         with_spill_list = tag.endswith("ELb1E")
         assert deep <= (8 if with_spill_list else 0), (tag, by_depth)
-        assert by_depth.get(1, 0) <= (160 if with_spill_list else 80), (tag, by_depth)
+        # depth 1 = the bodies of the phase loops (once per merge round / measurement chunk / CPHD chain step, hundreds to
+        # thousands of instructions each): the moves there must stay a small share of the body they sit in
+        assert by_depth.get(1, 0) <= 240, (tag, by_depth)
+        if not with_spill_list:
+            for name, (moves, instrs) in per_loop.items():
+                assert moves <= max(6, 0.08 * instrs), (tag, name, moves, instrs)
         checked += 1
     assert checked == len(TAGS)
