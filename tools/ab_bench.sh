@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B throughput runs on the GPU box: every cuda-phdslam_amd/libphdslam_<name>.so given (built here with
-# `make -C cuda-phdslam_amd/csrc variant NAME=<name> EXTRA="-D..."`) against the product library, same bench command.
+# `make -C cuda-phdslam_amd/csrc variant NAME=<name> VEXTRA="-D..."`) against the product library, same bench command.
 # usage: bash tools/ab_bench.sh <config> <steps> name1 name2 ...
 cfg=${1:-3}; steps=${2:-200}; shift 2
 mkdir -p gpurun_out
