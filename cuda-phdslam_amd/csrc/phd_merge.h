@@ -81,8 +81,16 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
                                             float* __restrict__ out_slab, int tid, u64* st)
 {
     const int K = n_clusters < cap ? n_clusters : cap;         // clusters past the map capacity are reported, not stored
+    // The accumulators: 48 B per cluster as SIX PLANES of K 8-byte words (sums: integers carried in doubles, phd_fixsum.h),
+    //   pass A: W | x hi | x lo | y hi | y lo | (largest exponent, flags)      pass B: cxx | cxy | cyy | W | (mean x, mean y) | (scales, flags)
+    // The lanes of a wave add to the clusters of their survivors — arbitrary indices c: in a plane those fall on bank pair
+    // c mod 32, all 32 in use; the record-per-cluster layout (48 B apart) left 16 of them, every atomic at least four-deep in
+    // its banks — and LDS atomics are what this routine costs (two workgroups share the pipeline).
+    LDS_T(double)* const accd = (LDS_T(double)*)acc;
     LDS_T(u32)* const acc32 = (LDS_T(u32)*)acc;
-    LDS_T(double)* const accd = (LDS_T(double)*)acc;            // the sums: integers carried in doubles (phd_fixsum.h), 6 per cluster
+    LDS_T(double)* const p0 = accd, * const p1 = accd + K, * const p2 = accd + 2 * K, * const p3 = accd + 3 * K, * const p4 = accd + 4 * K;
+    LDS_T(u32)* const w4 = acc32 + 8 * K;                       // plane 4 as words: (mean x, mean y) in pass B
+    LDS_T(u32)* const w5 = acc32 + 10 * K;                      // plane 5 as words: (largest exponent | scales, flags)
     if (tid == 0) { ctr[CTR_NHEAD] = n_clusters; ctr[CTR_KOUT] = n_clusters; }
     for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -97,26 +105,25 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         const int Fw = fx_field(ci.z);
         if (__float_as_int(ci.w) == i) {
             // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
-            if (!seed_close_to_itself<HELLINGER>(a.x, a.y, b.x, b.y, b.z, T)) { __hip_atomic_fetch_or(&acc32[12 * c + 11], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+            if (!seed_close_to_itself<HELLINGER>(a.x, a.y, b.x, b.y, b.z, T)) { __hip_atomic_fetch_or(&w5[2 * c + 1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
         }
         FxSumsD fs;
         fx_first_d(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
-        LDS_T(double)* const q = accd + 6 * c;
-        __hip_atomic_fetch_add(q + 0, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 1, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 2, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 3, fs.yh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 4, fs.yl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&acc32[12 * c + 10], (u32)fs.ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!fs.ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p0 + c, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p1 + c, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p2 + c, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p3 + c, fs.yh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p4 + c, fs.yl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&w5[2 * c], (u32)fs.ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!fs.ok) __hip_atomic_fetch_or(&w5[2 * c + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     STAMP(8);
-    // per cluster: W, mean (:2828), the stop rule (:2821); the slot becomes (cxx, cxy, cyy, W | mean x, mean y, scales, flags)
+    // per cluster: W, mean (:2828), the stop rule (:2821); the planes are re-armed for pass B
     for (int c = tid; c < K; c += PHD_T) {
         FxSumsD fs;
-        fs.W = accd[6 * c + 0]; fs.xh = accd[6 * c + 1]; fs.xl = accd[6 * c + 2]; fs.yh = accd[6 * c + 3]; fs.yl = accd[6 * c + 4];
-        const u32 ec = acc32[12 * c + 10], fl = acc32[12 * c + 11];
+        fs.W = p0[c]; fs.xh = p1[c]; fs.xl = p2[c]; fs.yh = p3[c]; fs.yl = p4[c];
+        const u32 ec = w5[2 * c], fl = w5[2 * c + 1];
         const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
         const int Fw = fx_field(cinfo[c].z);
         // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then yields W == 0
@@ -127,11 +134,11 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         float W, mx, my;
         fx_mean_d(fs, Fw, W, mx, my);
         const int Fc = fx_cov_anchor(Fw, (int)ec);
-        accd[6 * c + 0] = 0.0; accd[6 * c + 1] = 0.0; accd[6 * c + 2] = 0.0;
-        accd[6 * c + 3] = fs.W;
-        acc32[12 * c + 8] = __float_as_uint(mx); acc32[12 * c + 9] = __float_as_uint(my);
-        acc32[12 * c + 10] = (u32)Fc | ((u32)Fw << 16);
-        acc32[12 * c + 11] = (ok ? 0u : 1u) | (fl & 2u);
+        p0[c] = 0.0; p1[c] = 0.0; p2[c] = 0.0;
+        p3[c] = fs.W;
+        w4[2 * c] = __float_as_uint(mx); w4[2 * c + 1] = __float_as_uint(my);
+        w5[2 * c] = (u32)Fc | ((u32)Fw << 16);
+        w5[2 * c + 1] = (ok ? 0u : 1u) | (fl & 2u);
         if (ok) { out_slab[0 * cap + c] = W; out_slab[1 * cap + c] = mx; out_slab[2 * cap + c] = my; }
     }
     __syncthreads();
@@ -143,26 +150,25 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         const v4f a = recA[i], b = recB[i];
         const int c = __float_as_int(b.w);
         if (c >= K) continue;
-        const v4f h = ((LDS_T(v4f)*)acc)[3 * c + 2];           // (mean x, mean y, scales, flags)
-        const u32 sc = __float_as_uint(h.z);
+        const v2f hm = ((LDS_T(v2f)*)w4)[c];                    // (mean x, mean y)
+        const u32 sc = w5[2 * c], hfl = w5[2 * c + 1];          // (scales, flags)
         // (flag 2: the seed is not in its own cluster, decided in pass A)
-        if ((__float_as_uint(h.w) & 2u) && __float_as_int(cinfo[c].w) == i) continue;
+        if ((hfl & 2u) && __float_as_int(cinfo[c].w) == i) continue;
         bool ok = true;
         double qxx, qxy, qyy;
-        fx_cov_terms_d((int)(sc & 0xFFFFu), h.x, h.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
-        LDS_T(double)* const q = accd + 6 * c;
-        __hip_atomic_fetch_add(q + 0, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 1, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 2, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!ok) __hip_atomic_fetch_or(&acc32[12 * c + 11], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        fx_cov_terms_d((int)(sc & 0xFFFFu), hm.x, hm.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
+        __hip_atomic_fetch_add(p0 + c, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p1 + c, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p2 + c, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!ok) __hip_atomic_fetch_or(&w5[2 * c + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     // per cluster: covariance = sum / W (:2879; the symmetric form needs no force_symmetric_covariance)
     for (int c = tid; c < K; c += PHD_T) {
-        const double cxx = accd[6 * c + 0], cxy = accd[6 * c + 1], cyy = accd[6 * c + 2], Wq = accd[6 * c + 3];
-        const u32 sc = acc32[12 * c + 10];
+        const double cxx = p0[c], cxy = p1[c], cyy = p2[c], Wq = p3[c];
+        const u32 sc = w5[2 * c];
         const int Fc = (int)(sc & 0xFFFFu), Fw = (int)(sc >> 16);
-        if (acc32[12 * c + 11] & 1u) {
+        if (w5[2 * c + 1] & 1u) {
             const float bad = __builtin_nanf("");
 #pragma unroll
             for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + c] = bad;
