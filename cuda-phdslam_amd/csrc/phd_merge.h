@@ -550,18 +550,47 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
             const int nlt = k - wave * PHD_COLS;
             cand &= (k >= nwin || nlt <= 0) ? 0u : (nlt >= PHD_COLS ? ((1u << PHD_COLS) - 1u) : ((1u << nlt) - 1u));
             RSTAMP(1);
-            u32 bits = 0;
-            if (cand) {
-                const v4f kb = wB[k];
+            // The marked pairs are few (a wave's 64 rows x 8 columns hold ~20) and unevenly spread over the rows: a loop per row
+            // runs as long as the fullest row with a handful of lanes active.  So the wave lists its pairs (wave-private LDS,
+            // in-order — no barrier) and takes the exact decisions ONE PAIR PER LANE; the results are OR-ed into the rows.
+            const u64 anyc = __ballot(cand != 0u);
+            LDS_T(u32)* const myrow = &L.part[wave * 64 + k];
+            int tot = 0, incl = 0;
+            const int np = __popc(cand);
+            if (anyc) {                                             // uniform
+                incl = (int)wave_incl_scan((u32)np);
+                tot = __builtin_amdgcn_readlane(incl, 63);
+            }
+            if (anyc && tot <= 64) {                                // uniform: the usual case
+                LDS_T(u16)* const plist = (LDS_T(u16)*)L.win + wave * 64;     // (`win` is idle during the merge)
+                int pos = incl - np;
                 while (cand) {
                     const int c = __builtin_ctz(cand);
                     cand &= cand - 1;
-                    const int l = wave * PHD_COLS + c;
-                    const v4f la = wA[l], lb = wB[l];
-                    if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, kx, ky, kb.x, kb.y, kb.z, T)) bits |= (1u << c);
+                    plist[pos++] = (u16)((k << 3) | c);
                 }
+                *myrow = 0u;
+                if (lane < tot) {
+                    const u32 pr = plist[lane];
+                    const int kk = (int)(pr >> 3), c = (int)(pr & 7u), l = wave * PHD_COLS + c;
+                    const v4f pa = wA[kk], pb = wB[kk], la = wA[l], lb = wB[l];
+                    if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, pa.x, pa.y, pb.x, pb.y, pb.z, T))
+                        __hip_atomic_fetch_or(&L.part[wave * 64 + kk], 1u << c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                u32 bits = 0;
+                if (cand) {
+                    const v4f kb = wB[k];
+                    while (cand) {
+                        const int c = __builtin_ctz(cand);
+                        cand &= cand - 1;
+                        const int l = wave * PHD_COLS + c;
+                        const v4f la = wA[l], lb = wB[l];
+                        if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, kx, ky, kb.x, kb.y, kb.z, T)) bits |= (1u << c);
+                    }
+                }
+                *myrow = bits;
             }
-            L.part[wave * 64 + k] = bits;
         }
         __syncthreads();
         if (STAMPS && tid == 0) tq1 = __builtin_amdgcn_s_memrealtime();
