@@ -434,7 +434,13 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
                 if (slot < S_cap) {
+                    // the complete survivor at once (two thirds of the listed terms survive: a separate finalise pass would
+                    // fetch the same feature terms again, behind one more barrier)
+                    const v4f K = L.f_k[j], Pn = L.f_p[j];
                     L.w[slot] = w; L.u[slot] = n_in + m * n_in + j;
+                    L.mx[slot] = Pn.w + K.x * i0 + K.z * i1;                                          // :1903-1904
+                    L.my[slot] = L.f_my[j] + K.y * i0 + K.w * i1;
+                    L.xx[slot] = Pn.x; L.xy[slot] = Pn.y; L.yy[slot] = Pn.z;
                     __hip_atomic_fetch_add((LDS_T(u32)*)L.tr + bucket_of(bm, w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 else {   // past the LDS capacity: the complete record goes to the spill list (no finalise pass there)
@@ -478,8 +484,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         }
     }
     STAMP(4);
-    __syncthreads();
-    {
+    const bool finalised = sparse2 && n_cand <= PHD_CAND_CAP;     // (uniform) the listed pass stored complete survivors
+    if (!finalised) __syncthreads();
+    if (!finalised) {
         // dense finalise of the detection terms: rebuild gain, updated mean and Joseph covariance
         // from the prior feature (src/phdfilter.cu:1884-1906)
         const int n_now = min(L.ctr[CTR_NSURV], S_cap);
