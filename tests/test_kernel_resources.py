@@ -21,7 +21,8 @@ def compiled(tmp_path_factory):
         pytest.skip("hipcc not available")
     asm = tmp_path_factory.mktemp("isa") / "k.s"
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-           "--offload-arch=gfx950", "-ffp-contract=on", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-S",
+           "--offload-arch=gfx950", "-ffp-contract=on", "-Os", "-fno-slp-vectorize", "-mllvm", "-disable-lsr",   # = the Makefile's KFLAGS
+           "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-S",
            os.path.join(SRC, "phd_kernels.hip"), "-o", str(asm)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=SRC)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -35,16 +36,25 @@ TAGS = ("ILb0ELb0ELb0ELb0E", "ILb0ELb1ELb0ELb0E", "ILb0ELb0ELb1ELb0E", "ILb0ELb1
 
 
 def test_production_kernels_do_not_spill(compiled):
-    text = compiled[0]
+    text, asm = compiled
     found = {}
-    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", text, re.S):
-        found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?VGPRs Spill: (\d+)", text, re.S):
+        found[m.group(1)] = (int(m.group(2)), int(m.group(4)), int(m.group(3)))
     for tag in TAGS:
         names = [n for n in found if "phd_update_merge_kernel" + tag in n]
         assert len(names) == 1, (tag, sorted(found))
-        vgprs, scratch = found[names[0]]
+        vgprs, vgpr_spill, scratch = found[names[0]]
         assert vgprs <= 128, (names[0], vgprs)
-        assert scratch == 0, (names[0], scratch)
+        assert vgpr_spill == 0, (names[0], vgpr_spill)
+        # No scratch TRAFFIC: with the Makefile's flags the fused instantiations reserve a 36-byte frame per lane (a stack
+        # object the frame lowering keeps although nothing addresses it) — what matters is that no instruction of the
+        # kernel touches scratch memory.
+        m = re.search(r"^(_ZN3phd23phd_update_merge_kernel" + tag + r"\w*):.*?\.end_amdhsa_kernel", asm, re.S | re.M)
+        assert m, tag
+        touching = [l for l in m.group(0).split("\n")
+                    if re.match(r"\s+(scratch_|buffer_(load|store)\w* .*\boff(en)?\b.*s\[0:3\])", l)]
+        assert not touching, (names[0], scratch, touching[:3])
+        assert scratch <= 64, (names[0], scratch)
 
 
 def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
