@@ -22,6 +22,7 @@ def compiled(tmp_path_factory):
     asm = tmp_path_factory.mktemp("isa") / "k.s"
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
            "--offload-arch=gfx950", "-ffp-contract=on", "-Os", "-fno-slp-vectorize", "-mllvm", "-disable-lsr",   # = the Makefile's KFLAGS
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-unroll-threshold=400",
            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-S",
            os.path.join(SRC, "phd_kernels.hip"), "-o", str(asm)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=SRC)
