@@ -370,6 +370,19 @@ int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map,
                            o_gaussian* map_out, float* dlogw, float* cn_out,
                            o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out)
 {
+    return o_cphd_update_particle_ex(pose, map, n_map, z, M, cfg, clutter_rate, cn_prior, cn_len, map_out, dlogw, cn_out,
+                                     survivors_out, surv_slab_idx, n_survivors_out, r1_out, NULL, NULL);
+}
+
+/* the same, and (test diagnostics) margin_out[3] = o_merge's two decision margins + the smallest relative distance of an
+ * update component's weight to min_feature_weight; slab_all_out = the whole UNPRUNED slab followed by the nearly-in-range
+ * features (what surv_slab_idx indexes) */
+int o_cphd_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                              const o_config* cfg, float clutter_rate, const float* cn_prior, int cn_len,
+                              o_gaussian* map_out, float* dlogw, float* cn_out,
+                              o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out,
+                              float* margin_out, o_gaussian* slab_all_out)
+{
     int8_t* cls = (int8_t*)malloc(n_map > 0 ? n_map : 1);
     o_classify(map, n_map, pose, cfg, cls);
     int n_in = 0, n_near = 0, n_out0 = 0;
@@ -397,6 +410,16 @@ int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map,
     o_births(pose, z, M, cfg, births);
     o_preupdate(pose, f_in, n_in, z, M, cfg, pd, pre);
     o_cphd_update(f_in, pd, pre, births, n_in, M, cfg, clutter_rate, w_all, cn_prior, cn_len, slab, flag, dlogw, cn_out, &r1);
+    if (slab_all_out) memcpy(slab_all_out, slab, sizeof(o_gaussian) * n_update);
+    if (margin_out) {
+        float pm = FLT_MAX;
+        if (cfg->minFeatureWeight > 0)
+            for (size_t i = 0; i < n_update; i++) {
+                const float m = fabsf(slab[i].weight - cfg->minFeatureWeight) / cfg->minFeatureWeight;
+                if (m < pm) pm = m;
+            }
+        margin_out[2] = pm;
+    }
     int ns = 0;
     for (size_t i = 0; i < n_update; i++) {
         if (!flag[i]) {
@@ -408,11 +431,12 @@ int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map,
         o_gaussian g = f_near[i];
         g.weight = g.weight * r1;                                    /* joins the merge unpruned, like HEAD (:3242-3257) */
         if (surv_slab_idx) surv_slab_idx[ns] = (int32_t)(n_update + i);
+        if (slab_all_out) slab_all_out[n_update + i] = g;
         slab[ns++] = g;
     }
     if (survivors_out) memcpy(survivors_out, slab, sizeof(o_gaussian) * ns);
     if (n_survivors_out) *n_survivors_out = ns;
-    int nm = o_merge(slab, ns, cfg, map_out, NULL);
+    int nm = o_merge(slab, ns, cfg, map_out, margin_out);
     for (int i = 0; i < n_out0; i++) {
         map_out[nm] = f_out[i];
         map_out[nm].weight = f_out[i].weight * r1;

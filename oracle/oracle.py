@@ -143,6 +143,11 @@ def lib():
         L.o_gm_reduce.restype = i32; L.o_gm_reduce.argtypes = [vp, i32, f32, vp]
         L.o_update_particle.restype = i32
         L.o_update_particle.argtypes = [vp, vp, i32, vp, i32, cp, vp, vp, vp, vp, vp, vp]
+        L.o_update_particle_ex.restype = i32
+        L.o_update_particle_ex.argtypes = [vp, vp, i32, vp, i32, cp, vp, vp, vp, vp, vp, vp, vp]
+        L.o_merge_follow.restype = i32; L.o_merge_follow.argtypes = [vp, vp, i32, cp, vp, vp]
+        L.o_cphd_update_particle_ex.restype = i32
+        L.o_cphd_update_particle_ex.argtypes = [vp, vp, i32, vp, i32, cp, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.o_normalize_weights.restype = None; L.o_normalize_weights.argtypes = [vp, vp, i32]
         L.o_neff.restype = f32; L.o_neff.argtypes = [vp, i32]
         L.o_resample.restype = None; L.o_resample.argtypes = [vp, i32, vp, i32, i32, vp]
@@ -249,6 +254,22 @@ def merge(comps, cfg, with_margin=False):
     return (out[:n], margin) if with_margin else out[:n]
 
 
+FOLLOW_STATS = ("dist_flips", "dist_unexplained", "dist_worst_ratio", "order_flips", "order_unexplained", "order_worst_ratio",
+                "max_dist_move", "n_decisions", "nan_decisions")
+
+
+def merge_follow(ref, comps, cfg):
+    """TEST DIAGNOSTIC: the merge of `comps` (the oracle's survivors) taking every decision from the merge of `ref` (the
+    device's survivors, same length and order), with a first-order proof for every decision `comps` alone would have
+    taken differently (o_merge_follow).  -> (merged map in ref's output order, dict of FOLLOW_STATS)"""
+    ref = _c(ref, GAUSSIAN); comps = _c(comps, GAUSSIAN)
+    assert len(ref) == len(comps)
+    out = np.zeros(max(len(comps), 1), GAUSSIAN)
+    stats = np.zeros(9, np.float64)
+    n = lib().o_merge_follow(_p(ref), _p(comps), len(comps), C.byref(cfg), _p(out), _p(stats))
+    return out[:n], dict(zip(FOLLOW_STATS, stats.tolist()))
+
+
 def gm_reduce(comps, min_distance):
     comps = _c(comps, GAUSSIAN)
     out = np.zeros(max(len(comps), 1), GAUSSIAN)
@@ -256,8 +277,9 @@ def gm_reduce(comps, min_distance):
     return out[:n]
 
 
-def update_particle(pose, gmap, z, cfg):
-    """-> dict(map, dlogw, survivors, slab_idx, margin)"""
+def update_particle(pose, gmap, z, cfg, with_slab=False):
+    """-> dict(map, dlogw, survivors, slab_idx, margin[, slab_all: the unpruned slab + the nearly-in-range features,
+    the array slab_idx indexes])"""
     pose = _c(pose, POSE).reshape(1)
     gmap = _c(gmap, GAUSSIAN)
     z = _c(z, MEAS)
@@ -266,13 +288,17 @@ def update_particle(pose, gmap, z, cfg):
     out = np.zeros(cap, GAUSSIAN)
     surv = np.zeros(cap, GAUSSIAN)
     sidx = np.zeros(cap, np.int32)
+    slab_all = np.zeros(cap, GAUSSIAN) if with_slab else None
     ns = C.c_int(0)
     dlw = np.zeros(1, np.float32)
     margin = np.zeros(2, np.float32)
-    nm = lib().o_update_particle(_p(pose), _p(gmap), n, _p(z), M, C.byref(cfg), _p(out), _p(dlw),
-                                 _p(surv), _p(sidx), C.byref(ns), _p(margin))
-    return dict(map=out[:nm].copy(), dlogw=float(dlw[0]), survivors=surv[:ns.value].copy(),
-                slab_idx=sidx[:ns.value].copy(), margin=margin)
+    nm = lib().o_update_particle_ex(_p(pose), _p(gmap), n, _p(z), M, C.byref(cfg), _p(out), _p(dlw),
+                                    _p(surv), _p(sidx), C.byref(ns), _p(margin), _p(slab_all))
+    r = dict(map=out[:nm].copy(), dlogw=float(dlw[0]), survivors=surv[:ns.value].copy(),
+             slab_idx=sidx[:ns.value].copy(), margin=margin)
+    if with_slab:
+        r["slab_all"] = slab_all
+    return r
 
 
 def normalize_weights(logw, dlogw=None):
@@ -328,7 +354,7 @@ def cphd_set_reference_esf(on):
 
 
 def cphd_update_particle(pose, gmap, z, cfg, clutter_rate, cn_prior):
-    """-> dict(map, dlogw, cn, survivors, slab_idx, r1)"""
+    """-> dict(map, dlogw, cn, survivors, slab_idx, r1, margin (merge distance, seed weight gap), prune_margin, slab_all)"""
     pose = _c(pose, POSE).reshape(1)
     gmap = _c(gmap, GAUSSIAN); z = _c(z, MEAS); cn_prior = _c(cn_prior, np.float32)
     n, M = len(gmap), len(z)
@@ -336,10 +362,13 @@ def cphd_update_particle(pose, gmap, z, cfg, clutter_rate, cn_prior):
     out = np.zeros(cap, GAUSSIAN); surv = np.zeros(cap, GAUSSIAN); sidx = np.zeros(cap, np.int32)
     ns = C.c_int(0)
     dlw = np.zeros(1, np.float32); r1 = np.zeros(1, np.float32); cn = np.zeros(len(cn_prior), np.float32)
-    nm = lib().o_cphd_update_particle(_p(pose), _p(gmap), n, _p(z), M, C.byref(cfg), float(clutter_rate), _p(cn_prior),
-                                      len(cn_prior), _p(out), _p(dlw), _p(cn), _p(surv), _p(sidx), C.byref(ns), _p(r1))
+    margin = np.zeros(3, np.float32); slab_all = np.zeros(cap, GAUSSIAN)
+    nm = lib().o_cphd_update_particle_ex(_p(pose), _p(gmap), n, _p(z), M, C.byref(cfg), float(clutter_rate), _p(cn_prior),
+                                         len(cn_prior), _p(out), _p(dlw), _p(cn), _p(surv), _p(sidx), C.byref(ns), _p(r1),
+                                         _p(margin), _p(slab_all))
     return dict(map=out[:nm].copy(), dlogw=float(dlw[0]), cn=cn, survivors=surv[:ns.value].copy(),
-                slab_idx=sidx[:ns.value].copy(), r1=float(r1[0]))
+                slab_idx=sidx[:ns.value].copy(), r1=float(r1[0]), margin=margin[:2].copy(), prune_margin=float(margin[2]),
+                slab_all=slab_all)
 
 
 def argmax_weight(logw):

@@ -560,6 +560,173 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* o_merge_follow — TEST DIAGNOSTIC (no counterpart in the reference).
+ *
+ * The device's merge is bit for bit o_merge() of the device's own survivors `ref`.  Those survivors equal the oracle's
+ * `in` only within the update stage's tolerances (libm vs the device library), so a decision of the greedy loop — is this
+ * candidate within minSeparation of the seed (src/phdfilter.cu:2806), which unmerged component is the heaviest (:2750-2788) —
+ * that sits within that difference of its threshold may fall the other way, and every later cluster changes with it.
+ * This routine PROVES such a flip instead of tolerating it: it runs the merge of `in` but takes every decision from `ref`,
+ * and for every decision where `in` alone would have decided otherwise it checks that the survivor difference accounts for it:
+ *
+ *   distance:  d(ref) < T but d(in) >= T (or the reverse).  With g = the gradient of the distance in its ten arguments
+ *              (both means, both symmetric covariances; central differences in double at `ref`), the first-order change
+ *              of d under the observed difference is at most B1 = sum_k |g_k| |in_k - ref_k|.  The flip is explained iff
+ *              |d64(in) - T| <= kappa B1 + |d32(in) - d64(in)| + |d32(ref) - d64(ref)|      (kappa = 2: second-order terms;
+ *              the last two terms are the float evaluation errors of the two distances, measured, not modelled).
+ *   order:     the seed taken from ref's (weight desc, index asc) order is lighter in `in` than a still unmerged candidate j:
+ *              explained iff w_in[j] - w_in[s] <= kappa (|w_in[j] - w_ref[j]| + |w_in[s] - w_ref[s]|).
+ *
+ * Output: the merged map of `in` under ref's decisions (moment sums per cfg->mergeSums, in ref's order) — to be compared,
+ * component by component and IN ORDER, with the device's map — and
+ *   stats[0] distance flips followed      stats[1] of them unexplained      stats[2] worst |d64(in) - T| / allowance over the flips
+ *   stats[3] order inversions followed    stats[4] of them unexplained      stats[5] worst gap / allowance over the inversions
+ *   stats[6] largest |d32(in) - d32(ref)| / T over the decisions with a distance below 2 T (how far the survivor difference
+ *            moves a distance that matters)
+ *   stats[7] number of distance decisions taken
+ *   stats[8] decisions where a distance is NaN on either side (Hellinger metric on a cancelled determinant,
+ *            src/device_math.cuh:403-408: decided by rounding noise — counted, never "explained")                         */
+/* ------------------------------------------------------------------------------------ */
+static double o_dist64(int metric, const double* x)
+{
+    /* x = (a.mx, a.my, a.cxx, a.cxy, a.cyy, b.mx, b.my, b.cxx, b.cxy, b.cyy) */
+    const double d0 = x[0] - x[5], d1 = x[1] - x[6];
+    if (metric == 0) {
+        const double s0 = 0.5 * (x[2] + x[7]), s1 = 0.5 * (x[3] + x[8]), s3 = 0.5 * (x[4] + x[9]);
+        const double det = s0 * s3 - s1 * s1;
+        return (d0 * d0 * s3 - 2.0 * d0 * d1 * s1 + d1 * d1 * s0) / det;
+    }
+    const double s0 = x[2] + x[7], s1 = x[3] + x[8], s3 = x[4] + x[9];
+    const double det = s0 * s3 - s1 * s1;
+    const double eps = -0.25 * (d0 * d0 * s3 - 2.0 * d0 * d1 * s1 + d1 * d1 * s0) / det;
+    const double da = x[2] * x[4] - x[3] * x[3], db = x[7] * x[9] - x[8] * x[8];
+    return 1.0 - sqrt(sqrt(da * db) / (det / 4.0)) * exp(eps);
+}
+
+static void o_pack10(const o_gaussian* a, const o_gaussian* b, double* x)
+{
+    x[0] = a->mean[0]; x[1] = a->mean[1]; x[2] = a->cov[0]; x[3] = a->cov[1]; x[4] = a->cov[3];
+    x[5] = b->mean[0]; x[6] = b->mean[1]; x[7] = b->cov[0]; x[8] = b->cov[1]; x[9] = b->cov[3];
+}
+
+int o_merge_follow(const o_gaussian* ref, const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, double* stats)
+{
+    const double kappa = 2.0;
+    const float T = cfg->minSeparation;
+    for (int k = 0; k < 9; k++) stats[k] = 0;
+    if (n <= 0) return 0;
+    int n_out = 0;
+    o_sortkey* order = (o_sortkey*)malloc(sizeof(o_sortkey) * n);
+    uint8_t* merged = (uint8_t*)calloc(n, 1);
+    uint8_t* member = (uint8_t*)malloc(n);
+    for (int i = 0; i < n; i++) { order[i].w = ref[i].weight; order[i].idx = i; }
+    qsort(order, n, sizeof(o_sortkey), o_cmp_desc);
+    int first = 0;
+    while (1) {
+        while (first < n && merged[order[first].idx]) first++;
+        if (first >= n) break;
+        const int s = order[first].idx;
+        /* would `in` have picked another seed?  (its own order: weight desc, index asc; one inversion per seed, judged on the
+         * candidate that is hardest to explain) */
+        {
+            int inv = 0, bad = 0;
+            for (int k = first + 1; k < n; k++) {
+                const int j = order[k].idx;
+                if (merged[j]) continue;
+                const int heavier = in[j].weight > in[s].weight || (in[j].weight == in[s].weight && j < s);
+                if (!heavier) continue;
+                const double gap = (double)in[j].weight - (double)in[s].weight;
+                const double allow = kappa * (fabs((double)in[j].weight - (double)ref[j].weight) + fabs((double)in[s].weight - (double)ref[s].weight));
+                const double ratio = allow > 0 ? gap / allow : (gap > 0 ? INFINITY : 0.0);
+                inv = 1;
+                if (ratio > stats[5]) stats[5] = ratio;
+                if (gap > allow) bad = 1;
+            }
+            stats[3] += inv; stats[4] += bad;
+        }
+        float W = 0, sx = 0, sy = 0;
+        o_exact_sums es;
+        o_exact_begin(&es, &in[s]);
+        for (int k = first; k < n; k++) {
+            const int i = order[k].idx;
+            member[i] = 0;
+            if (merged[i]) continue;
+            const float dr = (cfg->distanceMetric == 0) ? o_mahal_dist(&ref[s], &ref[i]) : o_hellinger_dist(&ref[s], &ref[i]);
+            const float di = (cfg->distanceMetric == 0) ? o_mahal_dist(&in[s], &in[i]) : o_hellinger_dist(&in[s], &in[i]);
+            const int take = dr < T;                                     /* the device's decision */
+            if (k != first) {
+                stats[7] += 1;
+                const double mv = fabs((double)di - (double)dr) / (fabs((double)T) + FLT_MIN);
+                if (mv == mv && mv > stats[6] && (di < 2 * T || dr < 2 * T)) stats[6] = mv;
+            }
+            if (di != di || dr != dr) stats[8] += 1;
+            else if ((di < T) != take) {
+                double xr[10], xi[10], B1 = 0;
+                o_pack10(&ref[s], &ref[i], xr);
+                o_pack10(&in[s], &in[i], xi);
+                for (int q = 0; q < 10; q++) {
+                    const double dq = fabs(xi[q] - xr[q]);
+                    if (dq == 0) continue;
+                    double xp[10], xm[10];
+                    memcpy(xp, xr, sizeof xp); memcpy(xm, xr, sizeof xm);
+                    const double h = 1e-6 * (fabs(xr[q]) > 1e-3 ? fabs(xr[q]) : 1e-3);
+                    xp[q] += h; xm[q] -= h;
+                    const double g = (o_dist64(cfg->distanceMetric, xp) - o_dist64(cfg->distanceMetric, xm)) / (2 * h);
+                    B1 += fabs(g) * dq;
+                }
+                const double d64i = o_dist64(cfg->distanceMetric, xi), d64r = o_dist64(cfg->distanceMetric, xr);
+                const double allow = kappa * B1 + fabs((double)di - d64i) + fabs((double)dr - d64r);
+                const double off = fabs(d64i - (double)T);
+                stats[0] += 1;
+                /* a NaN anywhere (singular covariances under the Hellinger metric) explains nothing */
+                const double ratio = (allow > 0 && off == off && allow == allow) ? off / allow : INFINITY;
+                if (ratio > stats[2]) stats[2] = ratio;
+                if (!(off <= allow)) stats[1] += 1;
+            }
+            if (take) {
+                member[i] = 1;
+                W += in[i].weight;
+                sx += in[i].weight * in[i].mean[0];
+                sy += in[i].weight * in[i].mean[1];
+                o_exact_first(&es, &in[i]);
+            }
+        }
+        o_gaussian mg;
+        if (cfg->mergeSums == 1) {
+            if (W == 0) break;
+            mg.weight = W; mg.mean[0] = sx / W; mg.mean[1] = sy / W;
+        } else {
+            if (es.ok && es.ec < 255 && es.W == 0) break;
+            o_exact_mean(&es, &mg);
+        }
+        float c[4] = {0, 0, 0, 0};
+        for (int k = first; k < n; k++) {
+            const int i = order[k].idx;
+            if (merged[i] || !member[i]) continue;
+            const float d0 = mg.mean[0] - in[i].mean[0], d1 = mg.mean[1] - in[i].mean[1];
+            const float dd[2] = {d0, d1};
+            for (int j = 0; j < 2; j++)
+                for (int kk = 0; kk < 2; kk++)
+                    c[j * 2 + kk] += in[i].weight * (in[i].cov[j * 2 + kk] + dd[j] * dd[kk]);
+            if (cfg->mergeSums != 1) o_exact_second(&es, &mg, &in[i]);
+            merged[i] = 1;
+        }
+        if (cfg->mergeSums == 1) {
+            for (int j = 0; j < 4; j++) mg.cov[j] = c[j] / W;
+            mg.cov[1] = (mg.cov[1] + mg.cov[2]) / 2;
+            mg.cov[2] = mg.cov[1];
+        } else {
+            o_exact_cov(&es, &mg);
+        }
+        out[n_out++] = mg;
+        /* (a seed that is not close to itself under ref's decision stays unmerged and is picked again: the loop then ends
+         *  with W == 0 exactly as o_merge's does, because the decision is ref's) */
+    }
+    free(order); free(merged); free(member);
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* literal transcription of reduceGaussianMixture, src/gm_reduce.cpp:57-134                */
 /* (Eigen LLT distance :30-37 written out for 2x2; std::sort is not stable, a stable sort   */
 /*  with index tie-break is used here)                                                     */
@@ -637,6 +804,17 @@ int o_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, cons
                       o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
                       float* margin_out)
 {
+    return o_update_particle_ex(pose, map, n_map, z, M, cfg, map_out, dlogw, survivors_out, surv_slab_idx, n_survivors_out,
+                                margin_out, NULL);
+}
+
+/* the same, and (test diagnostic) the whole UNPRUNED slab followed by the nearly-in-range features in slab_all_out
+ * (n_in (M + 1) + M + n_near entries: what surv_slab_idx indexes) */
+int o_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                         const o_config* cfg, o_gaussian* map_out, float* dlogw,
+                         o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
+                         float* margin_out, o_gaussian* slab_all_out)
+{
     int8_t* cls = (int8_t*)malloc(n_map > 0 ? n_map : 1);
     o_classify(map, n_map, pose, cfg, cls);
     int n_in = 0, n_near = 0, n_out0 = 0;
@@ -660,6 +838,10 @@ int o_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, cons
     o_births(pose, z, M, cfg, births);
     o_preupdate(pose, f_in, n_in, z, M, cfg, pd, pre);
     o_update(f_in, pd, pre, births, n_in, M, cfg, slab, flag, dlogw);
+    if (slab_all_out) {
+        memcpy(slab_all_out, slab, sizeof(o_gaussian) * n_update);
+        memcpy(slab_all_out + n_update, f_near, sizeof(o_gaussian) * n_near);
+    }
     /* prune: stable compaction (thrust::remove_copy_if, src/phdfilter.cu:3134-3137) */
     int ns = 0;
     for (size_t i = 0; i < n_update; i++) {

@@ -115,6 +115,18 @@ int o_update_particle(const o_pose* pose, const o_gaussian* map, int n_map, cons
                       o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
                       float* margin_out);
 
+/* the same + (test diagnostic) slab_all_out: the whole unpruned slab followed by the nearly-in-range features — the array
+ * surv_slab_idx indexes, n_in (M + 1) + M + n_near entries (pass a buffer of n_map (M + 2) + M) */
+int o_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                         const o_config* cfg, o_gaussian* map_out, float* dlogw,
+                         o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
+                         float* margin_out, o_gaussian* slab_all_out);
+
+/* TEST DIAGNOSTIC (no counterpart in the reference): the merge of `in` taking every decision from the same merge of `ref`
+ * (the device's survivors), with a first-order proof for every decision `in` alone would have taken differently —
+ * see the comment at the definition.  out: n entries; stats: 9 doubles.  Returns the merged count. */
+int o_merge_follow(const o_gaussian* ref, const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, double* stats);
+
 /* ---- CPHD variant (cphd_cpu.c; parity unpinned, see its header) ---- */
 void o_cphd_log_factorials(float* lfact, int n);
 /* 1: leave-one-out ESFs by M separate recursions (src/phdfilter.cu.bak:1247-1272, O(M^3)); 0 (default): O(M^2) */
@@ -130,6 +142,13 @@ int o_cphd_update_particle(const o_pose* pose, const o_gaussian* map, int n_map,
                            const o_config* cfg, float clutter_rate, const float* cn_prior, int cn_len,
                            o_gaussian* map_out, float* dlogw, float* cn_out,
                            o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out);
+
+/* + margin_out[3] (merge distance margin, seed weight gap, prune margin) and the unpruned slab (test diagnostics) */
+int o_cphd_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, const o_meas* z, int M,
+                              const o_config* cfg, float clutter_rate, const float* cn_prior, int cn_len,
+                              o_gaussian* map_out, float* dlogw, float* cn_out,
+                              o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out,
+                              float* margin_out, o_gaussian* slab_all_out);
 
 int o_cphd_step(o_pose* poses, float* logw, o_gaussian* maps, int32_t* sizes, int n_particles, int cap,
                 float alpha, float v_encoder, const float* noise, const o_meas* z, int M,

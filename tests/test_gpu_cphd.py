@@ -3,8 +3,9 @@ C-ABI against the CPU oracle (oracle/cphd_cpu.c — parity unpinned at the refer
 header; the oracle itself is checked against an arbitrary-precision evaluation in test_cphd_oracle.py).
 
 Tolerances (fp32 log-domain recursion on both sides, expf/log1pf of glibc vs the ROCm device library):
-feature weights rtol 3e-3, particle log-weight increment 5e-3 + 1e-4 relative, log cardinality 5e-3 on the
-entries above -40.  The merge stage is, as for the PHD path, bit-exact on the GPU's own survivors."""
+the PHD path's value tolerances (tests/parity_utils.py), particle log-weight increment 2e-3 + (M + 2) ulps, log cardinality
+4e-3 on the entries above -40 — each <= 10 x the maxima observed (printed under -s).  The merge stage is, as for the PHD path,
+bit-exact on the GPU's own survivors, and every particle is compared cluster by cluster under the device's decisions."""
 import importlib
 import os
 import socket
@@ -13,9 +14,27 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from parity_utils import assert_maps_close, oracle_config_from, pkg, synthetic
+from parity_utils import (OBS, assert_maps_close, compare_particle_with_oracle, oracle_config_from, oracle_full_cphd_update, pkg,
+                          synthetic, ulp32)
 
 pytestmark = pytest.mark.gpu
+
+CN_ATOL = 4e-3                   # log cardinality rows (entries above -40); observed 4.1e-4 (profiles/r04_parity_observed.txt)
+
+
+def cphd_dlogw_tol(ref, M):
+    """CPHD log-weight increment log<Y0,p>: a log-sum-exp over max_cardinality + 1 terms on top of the M-term structure;
+    observed 8.5e-4 over tools/fuzz_cphd.py (|increment| ~ 270), 6.1e-5 at 4096 x 256 x 64"""
+    return 2e-3 + (M + 2) * ulp32(ref)
+
+
+@pytest.fixture(autouse=True)
+def _print_observed(request):
+    OBS.clear()
+    yield
+    line = OBS.report(request.node.name)
+    if line:
+        print("\n" + line)
 
 
 def log_poisson(mean, nmax):
@@ -59,28 +78,17 @@ def test_cphd_update_matches_oracle(N, G, M, nmax, seed):
         n_struct = 0
         for p in range(N):
             gmap = w["maps"][p, :w["sizes"][p]]
-            ref = O.cphd_update_particle(w["poses"][p], gmap, w["z"][0], ocfg, cfg.clutterRate, prior[p])
-            assert abs(dlw[p] - ref["dlogw"]) < 5e-3 + 1e-4 * abs(ref["dlogw"]), (p, dlw[p], ref["dlogw"])
+            ref = oracle_full_cphd_update(w["poses"][p], gmap, w["z"][0], ocfg, cfg.clutterRate, prior[p])
             live = ref["cn"] > -40
-            assert np.allclose(cn[p][live], ref["cn"][live], atol=5e-3), (p, np.abs(cn[p][live] - ref["cn"][live]).max())
+            OBS.note("cphd_cardinality_row_abs", np.abs(cn[p][live] - ref["cn"][live]).max())
+            assert np.allclose(cn[p][live], ref["cn"][live], atol=CN_ATOL), (p, np.abs(cn[p][live] - ref["cn"][live]).max())
             assert abs(np.log(np.exp(cn[p].astype(np.float64)).sum())) < 2e-3
-            # merge stage bit for bit on the GPU's own survivors
+            # log-weight increment, merge stage bit for bit on the GPU's own survivors, survivor set up to members proven
+            # marginal, the map cluster by cluster under the device's decisions with every flip proven (parity_utils)
             surv, sidx = f.survivors(p)
-            cls = O.classify(gmap, w["poses"][p], ocfg)
-            out0 = gmap[cls == 0].copy()
-            out0["weight"] = out0["weight"] * np.float32(ref["r1"])
-            om = O.merge(surv, ocfg)
-            assert len(maps[p]) == len(om) + len(out0), (p, len(maps[p]), len(om), len(out0))
-            for fld in ("weight", "mean", "cov"):
-                assert np.array_equal(maps[p][fld][:len(om)].view(np.uint32), om[fld].view(np.uint32)), (p, fld)
-            if len(out0):
-                assert np.allclose(maps[p]["weight"][len(om):], out0["weight"], rtol=3e-3)
-            # update stage: survivor sets and weights, when no prune decision is marginal
-            wr = ref["survivors"]["weight"]
-            if len(sidx) == len(ref["slab_idx"]) and np.array_equal(sidx, ref["slab_idx"]):
-                n_struct += 1
-                assert np.allclose(surv["weight"], wr, rtol=3e-3, atol=1e-7), (p, np.abs(surv["weight"] / wr - 1).max())
-                assert np.abs(surv["mean"] - ref["survivors"]["mean"]).max() < 2e-4
+            r = compare_particle_with_oracle(maps[p], surv, sidx, ref, ocfg, M, dlw=dlw[p], what="particle %d" % p,
+                                             tail_bit_exact=False, dlogw_tol=cphd_dlogw_tol(ref["dlogw"], M))
+            n_struct += bool(r["structural"])
         assert n_struct >= N // 2
 
 
@@ -232,7 +240,7 @@ def test_cphd_config5_size():
     for p in (0, 1777, 4095):
         ref = O.cphd_update_particle(ref_poses[p], w["maps"][p, :w["sizes"][p]], w["z"][0], ocfg, cfg.clutterRate, prior)
         live = ref["cn"] > -40
-        assert np.allclose(cn[p][live], ref["cn"][live], atol=1e-2), np.abs(cn[p][live] - ref["cn"][live]).max()
+        assert np.allclose(cn[p][live], ref["cn"][live], atol=CN_ATOL), np.abs(cn[p][live] - ref["cn"][live]).max()
         assert abs(len(maps[p]) - len(ref["map"])) <= 2
 
 

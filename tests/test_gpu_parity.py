@@ -4,24 +4,43 @@ Bars (BASELINE.json north_star): floating point within a stated tolerance, resam
 bit-exact; additionally the merge stage — which contains no transcendental — is checked BIT FOR
 BIT against the oracle on identical survivor inputs.
 
-Tolerances (fp32, both sides): component weights rtol 5e-4 (exp of a Mahalanobis distance up to
-~30 amplifies 1-ulp differences of atan2f/logf between glibc and the ROCm device library),
-means 2e-4 m, covariances rtol 2e-3, particle log-weight increments 2e-3 absolute.
+Tolerances (fp32, both sides; tests/parity_utils.py, each <= 10 x the largest deviation observed over the round-4 fuzz
+sweep, profiles/r04_parity_observed.txt): component weights, means, covariances, the particle log-weight increment in ulps
+of its accumulated sum.
 
-Structural decisions (prune w < minFeatureWeight, merge d < minSeparation, seed order) can flip
-under 1-ulp differences; the oracle reports how close each decision came to its threshold and a
-particle is compared structurally only when its margins are larger than the fp noise.
+Structural decisions (prune w < minFeatureWeight, merge d < minSeparation, seed order) can flip under 1-ulp differences
+of the survivors.  No particle is skipped for that: `compare_particle_with_oracle` holds the device's map, cluster by
+cluster, to the oracle's merge of its own values under the device's decisions and PROVES every decision the oracle alone
+would have taken differently from the first-order sensitivity of that decision to the observed survivor difference
+(oracle/scphd_cpu.c, o_merge_follow).  Every test prints the maxima it observed (run with -s).
 """
 import numpy as np
 import pytest
 
 from oracle import oracle as O
-from parity_utils import assert_maps_close, oracle_config_from, oracle_full_update, pkg, synthetic
+from parity_utils import (OBS, assert_maps_close, compare_particle_with_oracle, oracle_config_from, oracle_full_cphd_update,
+                          oracle_full_update, pkg, synthetic)
 
 pytestmark = pytest.mark.gpu
 
-PRUNE_MARGIN = 2e-3   # relative distance of a weight to minFeatureWeight below which the decision may flip
-MERGE_MARGIN = 2e-4   # relative distance of a merge distance to minSeparation
+CPHD_CN_ATOL = 4e-3              # log cardinality rows (entries above -40), absolute; observed 4.1e-4 at 4096 x 256 x 64
+
+
+def CPHD_DLOGW_TOL(ref, M):
+    """CPHD log-weight increment log<Y0,p>: a log-sum-exp over max_cardinality + 1 terms on top of the M-term structure;
+    observed 8.5e-4 over tools/fuzz_cphd.py (|increment| ~ 270), 6.1e-5 at 4096 x 256 x 64"""
+    from parity_utils import ulp32
+    return 2e-3 + (M + 2) * ulp32(ref)
+
+
+@pytest.fixture(autouse=True)
+def _print_observed(request):
+    """the maxima this test observed (weights, means, covariances, log-weight increments, decision flips): visible with -s"""
+    OBS.clear()
+    yield
+    line = OBS.report(request.node.name)
+    if line:
+        print("\n" + line)
 
 
 def make_filter(cfg, w, cap=None, mm=64, scap=0):
@@ -34,13 +53,16 @@ def make_filter(cfg, w, cap=None, mm=64, scap=0):
 
 
 def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, scap=0, structural_maps=True):
-    """one measurement update of every particle: survivors, merged map, Δlog-weight.
-    structural_maps=False skips the device-map vs oracle-map comparison (the merge stage is still checked bit for
+    """one measurement update of EVERY particle against the oracle (`compare_particle_with_oracle`: log-weight increment,
+    merge stage bit for bit on the device's survivors, exact vs float moment sums, survivor set up to members proven
+    marginal, the map cluster by cluster under the device's decisions with every flipped decision proven), then the
+    normalised particle weights.
+    structural_maps=False skips the map comparison under followed decisions (the merge stage is still checked bit for
     bit on the device's own survivors): the Hellinger distance of near-singular covariances cancels
-    catastrophically (src/device_math.cuh:373-413), so a 1-ulp difference between the two survivor sets can move
-    a distance by more than any fixed margin."""
+    catastrophically (src/device_math.cuh:373-413), so its first-order sensitivity says nothing."""
     ocfg = oracle_config_from(cfg)
     n_struct = 0
+    M = min(len(z), mm)
     with make_filter(cfg, w, cap, mm, scap) as f:
         f.debug(True)
         f.update(z)
@@ -50,32 +72,11 @@ def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, 
         _, logw = f.get_particles()
         for p in range(w["N"]):
             gmap = w["maps"][p, :w["sizes"][p]]
-            ref = oracle_full_update(w["poses"][p], gmap, z, ocfg)
+            ref = oracle_full_update(w["poses"][p], gmap, z[:M], ocfg)
             surv, sidx = f.survivors(p)
-            assert abs(dlw[p] - ref["dlogw"]) < 2e-3 + 2e-4 * abs(ref["dlogw"]), (p, dlw[p], ref["dlogw"])
-            # merge stage bit for bit: the oracle's merge applied to the GPU's own survivors
-            out0 = gmap[ref["cls"] == 0]
-            om, mgn = O.merge(surv, ocfg, with_margin=True)
-            want = np.concatenate([om, out0]) if len(out0) else om
-            # The Mahalanobis test is +, -, *, / only: the device and the CPU agree on every bit.  The Hellinger distance
-            # (distance_metric = 1) goes through sqrtf and expf, where the device's and glibc's results may differ in the last
-            # place: a merge decision the oracle itself reports within 1e-5 of the threshold (seen: 1.2e-7, one ulp — 1 of
-            # ~27 000 random Hellinger cases, profiles/r02_fuzz.txt) can then fall either way; such a particle is not compared.
-            if ocfg.distanceMetric == 1 and mgn[0] < 1e-5:
-                assert abs(len(maps[p]) - len(want)) <= 2, (p, len(maps[p]), len(want))
-                continue
-            assert len(maps[p]) == len(want), (p, len(maps[p]), len(want))
-            for fld in ("weight", "mean", "cov"):
-                assert np.array_equal(maps[p][fld].view(np.uint32), want[fld].view(np.uint32)), \
-                    "particle %d: merge not bit-exact in %s (max diff %g)" % (p, fld, np.abs(maps[p][fld] - want[fld]).max())
-            # update stage against the oracle, when no decision is fp-marginal
-            structural = ref["prune_margin"] > PRUNE_MARGIN
-            if structural:
-                assert np.array_equal(sidx, ref["slab_idx"]), "particle %d: survivor sets differ" % p
-                assert_maps_close(surv, ref["survivors"], ordered=True, what="survivors of particle %d" % p)
-                if structural_maps and ref["margin"][0] > MERGE_MARGIN:
-                    n_struct += 1
-                    assert_maps_close(maps[p], ref["map"], what="map of particle %d" % p)
+            r = compare_particle_with_oracle(maps[p], surv, sidx, ref, ocfg, M, dlw=dlw[p], what="particle %d" % p,
+                                             follow=structural_maps)
+            n_struct += bool(r["structural"])
         # normalised particle weights
         ref_lw = O.normalize_weights(w["logw"], dlw)
         # fp32 ulps of the values — of the UN-normalised ones too: w + dlw - logsumexp cancels at the magnitude of w + dlw
@@ -83,8 +84,9 @@ def check_update_against_oracle(cfg, w, z, cap=None, min_structural=0.6, mm=64, 
         # log-sum-exp to neighbouring floats
         raw_mag = float(np.abs(w["logw"].astype(np.float64) + dlw).max())
         tol = 1e-5 + 2e-6 * np.abs(ref_lw).max() + 2.4e-7 * raw_mag
+        OBS.note("normalised_logw_over_tolerance", np.abs(logw - ref_lw).max() / tol)
         assert np.abs(logw - ref_lw).max() < tol, (np.abs(logw - ref_lw).max(), tol)
-    assert n_struct >= min_structural * w["N"], "only %d of %d particles were structurally comparable" % (n_struct, w["N"])
+    assert n_struct >= min_structural * w["N"], "only %d of %d particles had the oracle's own structure" % (n_struct, w["N"])
     return st
 
 
@@ -143,6 +145,23 @@ def test_update_prune_threshold_paths(thr, G, M):
                                      structural_maps=thr > 1e-20)
     if thr == 0.0:
         assert st["max_survivors"] > 3 * M                  # every (in-range feature, measurement) term survived
+
+
+@pytest.mark.parametrize("seed", [6713, 7424, 8956, 9532, 10032])
+def test_fuzz_seeds_with_flipped_decisions_are_proven(seed):
+    """the five cases of tools/fuzz_parity.py that rounds 1-3 listed as "known ill-conditioned failures" (profiles/r03_fuzz_final.txt:
+    e.g. 6713 — one landmark, 128 measurements, min_separation 40: the births' nearly equal weights order differently on the two
+    sides; 10032 — map size 263 vs 264).  The oracle's fixed relative margins called them clear and the maps still differed; now
+    every differing decision is followed and proven from the survivor difference (compare_particle_with_oracle), and the maps
+    agree cluster by cluster under the device's decisions."""
+    from parity_utils import fuzz_case
+    P, S = pkg(), synthetic()
+    N, G, M, clustered, over = fuzz_case(seed)
+    w = S.make_workload(N, G, M, seed=seed, clustered=clustered and G >= 8)
+    check_update_against_oracle(P.default_config(**over), w, w["z"][0], cap=min(2 * G + 4 * M + 64, 1024), mm=max(M, 8),
+                                min_structural=0.0, structural_maps=over.get("distanceMetric", 0) == 0)
+    assert OBS.count.get("explained_distance_flips", 0) + OBS.count.get("explained_order_flips", 0) \
+        + OBS.count.get("prune_marginal_members", 0) > 0, "seed %d no longer exercises a flipped decision" % seed
 
 
 def test_update_equal_weights_fall_back_to_the_sorting_network():
@@ -507,69 +526,33 @@ def test_full_size_properties(cfg_id, sample):
     picks = np.arange(0, N, max(N // sample, 1))[:sample]
     poses, lw, maps, idx, dlw, surv = outs[0]
     n_ok, bad = compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, "cfg %d" % cfg_id, dlw=dlw, survivors=lambda p: surv[p])
-    print("config %d: %d of %d sampled particles structurally compared with the oracle (the rest: log-weight increment, survivor "
-          "set up to marginal members, mass / transport bound)" % (cfg_id, n_ok, len(picks)))
+    print("config %d: %d of %d sampled particles have the oracle's own structure (the rest: every differing decision proven marginal, "
+          "maps compared under the device's decisions)" % (cfg_id, n_ok, len(picks)))
     assert not bad, bad
-    # floors: the counts observed on hardware (profiles/r03*_gpu_tests.log: 126/128, 100/128, 56/64) minus a small slack
-    floor = {2: 0.9, 3: 0.7, 4: 0.78}[cfg_id]
-    assert n_ok >= floor * len(picks), "only %d of %d sampled particles were structurally comparable" % (n_ok, len(picks))
+    # floor: on hardware EVERY sampled particle has the oracle's own clusters (profiles/r04_parity_observed.txt: 128/128, 128/128,
+    # 64/64; the margin-based criterion of rounds 1-3 could compare 126/128, 100/128, 56/64); a little slack for another libm
+    assert n_ok >= 0.95 * len(picks), "only %d of %d sampled particles have the oracle's own structure" % (n_ok, len(picks))
     # the normalised weights of ALL particles from the device's own increments (the oracle's sequential log-sum-exp)
     ref_lw = O.normalize_weights(w["logw"], dlw)
     raw_mag = float(np.abs(w["logw"].astype(np.float64) + dlw).max())
     assert np.abs(lw - ref_lw).max() < 1e-5 + 2e-6 * np.abs(ref_lw).max() + 2.4e-7 * raw_mag * np.log2(N + 1)
 
 
-def map_transport_bound(a, b):
-    """a loose distance between two Gaussian mixtures that may differ by a few structural decisions (one merge more or less, a
-    component of weight ~ min_feature_weight more or less): (relative difference of the total mass, mass-weighted mean distance
-    from every component to the nearest component of the other mixture, both directions)"""
-    wa, wb = a["weight"].astype(np.float64), b["weight"].astype(np.float64)
-    ma, mb = a["mean"].astype(np.float64), b["mean"].astype(np.float64)
-    d = np.sqrt(((ma[:, None, :] - mb[None, :, :]) ** 2).sum(-1))
-    tr = max((wa * d.min(1)).sum() / wa.sum(), (wb * d.min(0)).sum() / wb.sum())
-    return abs(wa.sum() - wb.sum()) / wb.sum(), tr
-
-
 def compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, what, dlw=None, survivors=None):
-    """-> (number of particles compared structurally, list of failures).  EVERY picked particle is checked against the oracle:
-      * its log-weight increment (no structural decision in it), when `dlw` is given;
-      * its survivor set, when `survivors(p)` is given: equal where the oracle's prune margin is clear, otherwise equal up to
-        members whose weight is within PRUNE_MARGIN of min_feature_weight;
-      * its map: component by component where no prune decision and no merge distance of the ORACLE's run came within fp
-        noise of its threshold; otherwise bounded by total mass and mass-weighted nearest-component distance (a marginal
-        decision moves a few components, not the mixture)."""
+    """-> (number of particles with the oracle's own structure, list of failures).  EVERY picked particle goes through
+    `compare_particle_with_oracle` (needs the device's survivors: `survivors(p)` -> (values, slab indices))."""
     n_ok, bad = 0, []
-    minw = float(ocfg.minFeatureWeight)
+    M = len(w["z"][0])
     for p in picks:
         gmap = w["maps"][p, :w["sizes"][p]]
         ref = oracle_full_update(ref_poses[p], gmap, w["z"][0], ocfg)
         try:
-            if dlw is not None:
-                assert abs(dlw[p] - ref["dlogw"]) < 2e-3 + 2e-4 * abs(ref["dlogw"]), \
-                    "%s particle %d: log-weight increment %g vs %g" % (what, p, dlw[p], ref["dlogw"])
-            clear = ref["prune_margin"] > PRUNE_MARGIN and ref["margin"][0] > MERGE_MARGIN
-            if survivors is not None:
-                surv, sidx = survivors(p)
-                if ref["prune_margin"] > PRUNE_MARGIN:
-                    assert np.array_equal(sidx, ref["slab_idx"]), "%s particle %d: survivor sets differ" % (what, p)
-                else:
-                    common, ia, ib = np.intersect1d(sidx, ref["slab_idx"], return_indices=True)
-                    only_dev = np.setdiff1d(np.arange(len(sidx)), ia)
-                    only_ref = np.setdiff1d(np.arange(len(ref["slab_idx"])), ib)
-                    assert np.all(np.abs(surv["weight"][only_dev] - minw) <= 2 * PRUNE_MARGIN * minw), \
-                        "%s particle %d: a survivor only the device keeps is not marginal" % (what, p)
-                    assert np.all(np.abs(ref["survivors"]["weight"][only_ref] - minw) <= 2 * PRUNE_MARGIN * minw), \
-                        "%s particle %d: a survivor only the oracle keeps is not marginal" % (what, p)
-                    assert_maps_close(surv[ia], ref["survivors"][ib], ordered=True, what="%s common survivors of particle %d" % (what, p))
-            if clear:
-                assert_maps_close(maps[p], ref["map"], what="%s particle %d" % (what, p))
-                n_ok += 1
-            else:
-                dm, tr = map_transport_bound(maps[p], ref["map"])
-                assert dm < 1e-3 and tr < 0.02, "%s particle %d (marginal decisions): mass differs by %g, transport %g m" % (what, p, dm, tr)
-                assert abs(len(maps[p]) - len(ref["map"])) <= 3, (what, p, len(maps[p]), len(ref["map"]))
+            surv, sidx = survivors(p)
+            r = compare_particle_with_oracle(maps[p], surv, sidx, ref, ocfg, M, dlw=None if dlw is None else dlw[p],
+                                             what="%s particle %d" % (what, p))
+            n_ok += bool(r["structural"])
         except AssertionError as e:
-            bad.append(str(e))
+            bad.append(str(e)[:400])
     return n_ok, bad
 
 
@@ -591,7 +574,7 @@ def test_bench_path_at_bench_size(cfg_id, sample):
     import torch
     dev = torch.device("cuda:0")
     with make_filter(cfg, w, cap=2 * G, mm=M) as a, make_filter(cfg, w, cap=2 * G, mm=M) as b:
-        b.debug(4)                                           # staged launches only
+        b.debug(5)                                           # staged launches only + survivor inspection
         for k, force in enumerate((True, False)):
             dz = torch.from_numpy(w["z"][k].view(np.uint8).copy()).to(dev)
             dn = torch.from_numpy(w["noise"][k].copy()).to(dev)
@@ -604,6 +587,8 @@ def test_bench_path_at_bench_size(cfg_id, sample):
             maps_pre = b.get_maps() if k == 0 else None
             dlw_pre = b.weight_increments() if k == 0 else None
             cn_pre = b.cardinalities() if (k == 0 and cfg_id == 5) else None
+            picks = np.arange(0, N, max(N // sample, 1))[:sample] if (k == 0 and sample) else []
+            surv_pre = {int(p): b.survivors(int(p)) for p in picks}
             if force:
                 idx = b.resample(w["uniform"][k])
                 did = True
@@ -624,27 +609,31 @@ def test_bench_path_at_bench_size(cfg_id, sample):
                 for j in range(0, N, max(N // 64, 1)):
                     assert np.array_equal(ma[j], maps_pre[idx[j]])
                 ref_poses = O.predict_ackerman(w["poses"], 0.05, 2.0, w["noise"][0], ocfg)
-                picks = np.arange(0, N, max(N // sample, 1))[:sample]
                 if cfg_id == 5:
-                    # the CPHD variant against its oracle at bench size: log-weight increment, cardinality row, and the map
-                    # bounded by mass and mass-weighted nearest-component distance (the CPHD oracle reports no decision
-                    # margins; tests/test_gpu_cphd.py compares survivors and merges component by component at small sizes)
+                    # the CPHD variant against its oracle at bench size, particle by particle like the PHD: log-weight increment,
+                    # cardinality row, survivor set, merge bit for bit, the map cluster by cluster under the device's decisions
+                    # with every flip proven (oracle/cphd_cpu.c reports the same margins and the unpruned slab as scphd_cpu.c)
                     prior = np.full(256, -np.log(256.0), np.float32)
+                    n_ok = 0
                     for p in picks:
-                        ref = O.cphd_update_particle(ref_poses[p], w["maps"][p, :w["sizes"][p]], w["z"][0], ocfg, cfg.clutterRate, prior)
-                        assert abs(dlw_pre[p] - ref["dlogw"]) < 5e-3 + 2e-4 * abs(ref["dlogw"]), (p, dlw_pre[p], ref["dlogw"])
+                        ref = oracle_full_cphd_update(ref_poses[p], w["maps"][p, :w["sizes"][p]], w["z"][0], ocfg, cfg.clutterRate, prior)
+                        surv, sidx = surv_pre[int(p)]
+                        r = compare_particle_with_oracle(maps_pre[p], surv, sidx, ref, ocfg, M, dlw=dlw_pre[p], what="cfg 5 particle %d" % p,
+                                                         tail_bit_exact=False, dlogw_tol=CPHD_DLOGW_TOL(ref["dlogw"], M))
+                        n_ok += bool(r["structural"])
                         live = ref["cn"] > -40
-                        assert np.allclose(cn_pre[p][live], ref["cn"][live], atol=1e-2), (p, np.abs(cn_pre[p][live] - ref["cn"][live]).max())
-                        dm, tr = map_transport_bound(maps_pre[p], ref["map"])
-                        assert dm < 2e-3 and tr < 0.02 and abs(len(maps_pre[p]) - len(ref["map"])) <= 3, (p, dm, tr, len(maps_pre[p]), len(ref["map"]))
-                    print("config 5 bench path: %d sampled particles compared with the CPHD oracle" % len(picks))
+                        OBS.note("cphd_cardinality_row_abs", np.abs(cn_pre[p][live] - ref["cn"][live]).max())
+                        assert np.allclose(cn_pre[p][live], ref["cn"][live], atol=CPHD_CN_ATOL), (p, np.abs(cn_pre[p][live] - ref["cn"][live]).max())
+                    print("config 5 bench path: %d sampled particles compared with the CPHD oracle component by component, %d of them "
+                          "with the oracle's own structure (the rest: explained flips / marginal prune members)" % (len(picks), n_ok))
                     continue
-                n_ok, bad = compare_maps_with_oracle(maps_pre, ref_poses, w, ocfg, picks, "cfg %d (bench path)" % cfg_id, dlw=dlw_pre)
-                print("config %d bench path: %d of %d sampled particles structurally compared with the oracle (the rest: log-weight "
-                      "increment, mass / transport bound)" % (cfg_id, n_ok, len(picks)))
+                n_ok, bad = compare_maps_with_oracle(maps_pre, ref_poses, w, ocfg, picks, "cfg %d (bench path)" % cfg_id, dlw=dlw_pre,
+                                                     survivors=lambda p: surv_pre[int(p)])
+                print("config %d bench path: %d of %d sampled particles have the oracle's own structure (the rest: every differing "
+                      "decision proven marginal, maps compared under the device's decisions)" % (cfg_id, n_ok, len(picks)))
                 assert not bad, bad
-                # floors: the counts observed on hardware (255/256, 208/256) minus a small slack
-                assert n_ok >= {2: 0.9, 3: 0.7}[cfg_id] * len(picks), (n_ok, len(picks))
+                # floor: on hardware all 256 of 256 (profiles/r04_parity_observed.txt; rounds 1-3: 255/256, 208/256 comparable)
+                assert n_ok >= 0.95 * len(picks), (n_ok, len(picks))
         sa, sb = a.status(), b.status()
         assert sa["max_survivors"] == sb["max_survivors"] and sa["max_map"] == sb["max_map"]
 
@@ -763,7 +752,6 @@ def test_dense_scans_spill_instead_of_failing(G, M, clutter):
     # symmetric difference has a weight within 0.5 % of min_feature_weight, every common member agrees within the usual
     # tolerances; the merge is bit for bit the oracle's merge of the device's own survivors
     ocfg = oracle_config_from(cfg)
-    minw = cfg.minFeatureWeight
     with make_filter(cfg, w, cap=1024 if G > 256 else 768, mm=256, scap=4096) as f:
         f.debug(True)
         f.update(w["z"][0])
@@ -776,20 +764,8 @@ def test_dense_scans_spill_instead_of_failing(G, M, clutter):
             ref = oracle_full_update(w["poses"][p], gmap, w["z"][0], ocfg)
             surv, sidx = f.survivors(p)
             assert len(surv) > 2048
-            assert abs(dlw[p] - ref["dlogw"]) < 2e-3 + 2e-4 * abs(ref["dlogw"])
-            om = O.merge(surv, ocfg)
-            out0 = gmap[ref["cls"] == 0]
-            want = np.concatenate([om, out0]) if len(out0) else om
-            assert len(maps[p]) == len(want), (p, len(maps[p]), len(want))
-            for fld in ("weight", "mean", "cov"):
-                assert np.array_equal(maps[p][fld].view(np.uint32), want[fld].view(np.uint32)), (p, fld)
-            common, ia, ib = np.intersect1d(sidx, ref["slab_idx"], return_indices=True)
-            only_dev = np.setdiff1d(np.arange(len(sidx)), ia)
-            only_ref = np.setdiff1d(np.arange(len(ref["slab_idx"])), ib)
-            assert len(only_dev) + len(only_ref) <= 8, (len(only_dev), len(only_ref))
-            assert np.all(np.abs(surv["weight"][only_dev] - minw) < 5e-3 * minw)
-            assert np.all(np.abs(ref["survivors"]["weight"][only_ref] - minw) < 5e-3 * minw)
-            assert_maps_close(surv[ia], ref["survivors"][ib], ordered=True, what="common survivors of particle %d" % p)
+            r = compare_particle_with_oracle(maps[p], surv, sidx, ref, ocfg, M, dlw=dlw[p], what="particle %d" % p)
+            assert r["prune_marginal"] <= 8, r
 
 
 def test_spill_path_in_the_fused_step_and_mixed_particle_sets():

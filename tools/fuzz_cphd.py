@@ -32,6 +32,8 @@ def main():
             print("FAIL seed %d N=%d G=%d M=%d nmax=%d: %s" % (seed, N, G, M, nmax, str(e)[:240].replace("\n", " ")))
         seed += 1
     print("cphd fuzz: %d cases passed, %d failed, %.0f s" % (n_ok, n_fail, time.time() - t0))
+    from parity_utils import OBS
+    print(OBS.report("fuzz_cphd: maxima observed, counts"))
     return 1 if n_fail else 0
 
 
