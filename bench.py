@@ -540,6 +540,49 @@ def run_sharded(P, S, D, torch, dist, cfg_id, n_global, steps, warmup, dev, loca
     return res
 
 
+def verify_cpp_multi(P, S, MM, devices, exchange, cap, mm):
+    """a small filter (64 particles per shard, 32 Gaussians, 16 measurements, the bench's map capacity) through four COMMITTED
+    steps — forced, nEff-triggered, forced, forced resamples with a weight vector concentrated on the last shard, so that
+    particles migrate across every device boundary — on the sharded filter and on a single filter: particles, weights and maps
+    must agree bit for bit.  -> {"equal_to_single_filter", "exchange", ...}"""
+    k = len(devices)
+    N, G, M, steps = 64 * k, 32, min(16, mm), 4
+    w = S.make_workload(N, G, M, seed=0xC0FFEE + k, n_meas_sets=steps, clustered=True)
+    lw = np.linspace(-12.0, 0.0, N).astype(np.float32)
+    w["logw"] = (lw - np.float32(np.log(np.exp(lw.astype(np.float64)).sum()))).astype(np.float32)
+    cfg = P.default_config(n_particles=N, resampleThresh=0.6)
+    force = [True, False, True, True]
+    out = {"equal_to_single_filter": False, "particles": N, "steps": steps, "devices": list(devices)}
+    try:
+        with P.PhdFilter(cfg, n_particles=N, map_capacity=cap, max_measurements=mm, device=devices[0]) as f, \
+                MM.MultiFilter(cfg, n_shards=k, devices=list(devices), map_capacity=cap, max_measurements=mm, exchange=exchange,
+                               gathered_limit_bytes=(1 if exchange == MM.EXCHANGE_AUTO else 0)) as m:
+            out["exchange"] = m.exchange
+            out["rccl"] = m.uses_rccl
+            for x in (f, m):
+                x.set_particles(w["poses"], w["logw"])
+                x.set_maps(w["maps"], w["sizes"])
+            for s in range(steps):
+                f.predict((2.0, 0.05), w["noise"][s])
+                f.update(w["z"][s])
+                if force[s]:
+                    f.resample(w["uniform"][s])
+                else:
+                    f.resample_if_needed(w["uniform"][s], had_measurements=True)
+                m.step((2.0, 0.05), w["noise"][s], w["z"][s], w["uniform"][s], force_resample=force[s])
+                pa, la = f.get_particles()
+                pb, lb = m.get_particles()
+                same = np.array_equal(pa, pb) and np.array_equal(la, lb) and all(
+                    np.array_equal(a, b) for a, b in zip(f.get_maps(), m.get_maps()))
+                if not same:
+                    out["first_difference_at_step"] = s
+                    return out
+            out["equal_to_single_filter"] = True
+    except Exception as e:                                    # noqa: BLE001 — a failed verification is reported, the caller decides
+        out["error"] = str(e)[:300]
+    return out
+
+
 def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_phases=True):
     """ONE filter sharded over len(devices) shards, driven by the C++ multi-device host (libphdslam_multi.so,
     include/phdslam_multi.h) inside THIS process: one host thread, one HIP stream per shard, RCCL (ncclCommInitAll) when every
@@ -555,6 +598,16 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
     cfg = P.default_config(n_particles=N)
     ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "gathered": MM.EXCHANGE_GATHERED, "pull": MM.EXCHANGE_PULL}.get(
         os.environ.get("PHD_BENCH_EXCHANGE", ""), MM.EXCHANGE_AUTO)
+    # first contact: before anything is timed, the sharded filter must equal a single filter bit for bit ON THESE DEVICES, with
+    # the exchange the timed run will use (the PULL form reads peers' memory directly and had only ever run with all shards on
+    # one GPU when this was written); if it does not, the host-planned all-to-all is verified and used instead, and the line says so
+    verified = verify_cpp_multi(P, S, MM, devices, ex, 2 * G, M)
+    if not verified["equal_to_single_filter"] and verified["exchange"] != "alltoall":
+        second = verify_cpp_multi(P, S, MM, devices, MM.EXCHANGE_ALLTOALL, 2 * G, M)
+        second["fell_back_from"] = verified
+        verified = second
+        if verified["equal_to_single_filter"]:
+            ex = MM.EXCHANGE_ALLTOALL
     m = MM.MultiFilter(cfg, n_shards=n_shards, devices=list(devices), map_capacity=2 * G, max_measurements=M, exchange=ex)
     m.set_particles(w["poses"], w["logw"])
     m.set_maps(w["maps"], w["sizes"])
@@ -621,6 +674,7 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
                       "rccl": m.uses_rccl, "rccl_ranks": n_shards if m.uses_rccl else 0,
                       "value_counts": "filter steps per second (K / wall time with every shard drained)",
                       "multi_gpu_exchange": m.exchange,
+                      "multi_gpu_verified": verified,
                       "multi_gpu_phase_us_shard0": phases,
                       **({} if distinct else {"share_gpu_dry_run": True})},
            "roofline": roof, "roofline_valu": valu}

@@ -127,11 +127,13 @@ SYMBOLS = {
     "phd_step_local_dev": (_i, [_vp, Control, _vp, _vp, _i]),
     "phd_global_resample_end": (_i, [_vp, _vp]),
     "phd_global_resample_launch": (_i, [_vp, _vp, _d, _vp]),
+    "phd_global_resample_launch_normalized": (_i, [_vp, _vp, _d, _vp]),
     "phd_global_resample_plan": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "phd_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "phd_step_report_get": (_i, [_vp, _vp]),
     "phd_set_particle_count": (_i, [_vp, _i]),
     "phd_export_shard_dev": (_i, [_vp, _vp, _vp]),
+    "phd_export_shard_current_dev": (_i, [_vp, _vp, _vp]),
     "phd_step_local_rows_dev": (_i, [_vp, Control, _vp, _vp, _i, _vp, _vp]),
     "phd_set_rows_target": (_i, [_vp, _vp]),
     "phd_global_resample_gathered": (_i, [_vp, _vp, _d, _i, _i, _i, _vp]),

@@ -1400,18 +1400,17 @@ static int ensure_send_buffer(phd_filter* f, size_t need)
 // the launch; the indices — identical on every shard — are downloaded ONCE and every shard plans from the same host copy.
 //   launch: normalise the gathered raw weights (d_all_raw_logw != NULL) and draw the global indices on the device, no sync
 //   plan:   this shard's part of the migration from host indices + export of what other shards need
-extern "C" int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_logw, double uniform, int32_t** d_idx_out)
+static int global_resample_launch(phd_filter* f, const float* d_all_logw, bool normalize, double uniform, int32_t** d_idx_out)
 {
-    CHECK_F(f);
     const int ng = ng_cur(f);                     // (a grown set — particle shotgun — is resampled back to global_particles)
     WeightArgs w;
     memset(&w, 0, sizeof(w));
     w.u0 = uniform;
-    w.logw_in = d_all_raw_logw ? d_all_raw_logw : f->logw_scratch;
+    w.logw_in = d_all_logw ? d_all_logw : f->logw_scratch;
     w.logw = f->logw_scratch;
     w.n = ng;
     w.n_new = f->n_global;
-    w.mode = (d_all_raw_logw ? WM_NORMALIZE : 0) | WM_RESAMPLE_FORCE;
+    w.mode = (normalize ? WM_NORMALIZE : 0) | WM_RESAMPLE_FORCE;
     w.uniforms = f->d_uniforms;
     w.n_uniforms = 1;
     w.cdf = f->cdf;
@@ -1424,6 +1423,21 @@ extern "C" int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_
     t_end(f);
     if (d_idx_out) *d_idx_out = f->idx;
     return PHD_OK;
+}
+
+extern "C" int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_logw, double uniform, int32_t** d_idx_out)
+{
+    CHECK_F(f);
+    return global_resample_launch(f, d_all_raw_logw, d_all_raw_logw != nullptr, uniform, d_idx_out);
+}
+
+// the gathered vector is the shards' CURRENT normalised log-weights (a resample that no update precedes: nothing to
+// normalise — a second normalisation would move the last bits and with them, now and then, an index)
+extern "C" int phd_global_resample_launch_normalized(phd_filter* f, const float* d_all_logw, double uniform, int32_t** d_idx_out)
+{
+    CHECK_F(f);
+    if (!d_all_logw) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_launch_normalized: null weights");
+    return global_resample_launch(f, d_all_logw, false, uniform, d_idx_out);
 }
 
 extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int world, int rank, int32_t* send_counts,
@@ -1568,16 +1582,29 @@ extern "C" int phd_global_resample_pull(phd_filter* f, const phd_peer_view* view
 // One fixed-size collective, the indices never leave the device, nothing waits for the host.  The traffic grows with
 // world * n * pack bytes per rank, so the host side picks this form only while that is small
 // (cuda-phdslam_amd/dist.py); the all-to-all form above moves only the particles that migrate.
+static int export_shard(phd_filter* f, void** d_rows, size_t* bytes_out, const float* header_weights);
 extern "C" int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_out)
 {
     CHECK_F(f);
     if (!d_rows) return fail(PHD_ERR_INVALID_ARG, "phd_export_shard_dev: null output");
+    return export_shard(f, d_rows, bytes_out, f->logw_raw);
+}
+// the same with the CURRENT (normalised) log-weights in the row headers: a resample that no update precedes
+// (phd_global_resample_gathered with weights_in_rows = 2 uses them as they are)
+extern "C" int phd_export_shard_current_dev(phd_filter* f, void** d_rows, size_t* bytes_out)
+{
+    CHECK_F(f);
+    if (!d_rows) return fail(PHD_ERR_INVALID_ARG, "phd_export_shard_current_dev: null output");
+    return export_shard(f, d_rows, bytes_out, f->logw);
+}
+static int export_shard(phd_filter* f, void** d_rows, size_t* bytes_out, const float* header_weights)
+{
     const size_t pack = phd_particle_pack_bytes(f), need = (size_t)f->n * pack;
     int rc = ensure_send_buffer(f, need);
     if (rc) return rc;
     HIPCHK(launch_export(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur],
                          f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], nullptr, f->send_buf, f->cap, pack,
-                         f->n, f->stream, f->logw_raw));
+                         f->n, f->stream, header_weights));
     if (f->cphd)
         HIPCHK(launch_copy_rows(f->cn[f->cur], f->cn_len, nullptr, f->parent[f->pcur], (float*)f->send_buf + 8 + 6 * f->cap,
                                 pack / 4, nullptr, f->cn_len, f->n, f->stream));
@@ -1645,7 +1672,8 @@ extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_row
     if (weights_in_rows) {
         w.logw_in = (const float*)d_all_rows + 7;
         w.in_stride = (int)(pack / 4);
-        w.mode = WM_NORMALIZE | WM_RESAMPLE_FORCE;
+        // 1: un-normalised weights (an update precedes: normalise first); 2: the shards' current normalised weights, as they are
+        w.mode = (weights_in_rows == 2 ? 0 : WM_NORMALIZE) | WM_RESAMPLE_FORCE;
     } else {
         w.logw_in = f->logw_scratch;
         w.mode = WM_RESAMPLE_FORCE;
@@ -1661,7 +1689,7 @@ extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_row
     w.did_resample = f->did;
     w.n_weight_norm = ng;
     const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3;
-    if (weights_in_rows && !idx_out && ng <= 1024) {
+    if (weights_in_rows == 1 && !idx_out && ng <= 1024) {
         // one launch: every import workgroup draws its own parent from the gathered weights (no weights launch to wait for)
         t_begin(f, PHD_K_WEIGHTS);
         HIPCHK(launch_gathered_resample(w, f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], d_all_rows, f->cap, pack,

@@ -81,10 +81,15 @@ struct phd_multi {
     int n_meas = 0;                     // of the resident inputs
     bool have_noise = false;
     // per-phase timing (phd_multi_timing_*): HIP events on shard 0's stream at the phase boundaries of a step
+    bool scratch_current = false;       // every shard's logw_scratch holds the CURRENT normalised global weights (phd_global_normalize ran
+                                        // and nothing has changed a weight or the particle count since)
     bool timing = false;
-    hipEvent_t tev[PHD_MULTI_PHASES + 1] = {};
+    // the longest step records start + local + gather + weights (normalise) + weights (indices) + plan + send/recv + import = 8
+    // marks; sized with slack, and t_mark refuses (instead of dropping a span silently) beyond it
+    static constexpr int MARKS = 12;
+    hipEvent_t tev[MARKS] = {};
     int tmark = 0;                      // events recorded in the step in flight
-    int tphase[PHD_MULTI_PHASES + 1] = {};
+    int tphase[MARKS] = {};
     double t_us[PHD_MULTI_PHASES] = {};
     int64_t t_steps = 0;
 };
@@ -97,7 +102,8 @@ int ncur(const phd_multi* m) { return phd_n_particles(m->sh[0].f); }
 // phase marks (timing pass only): an event on shard 0's stream; phase = what the span ENDING at this mark was
 int t_mark(phd_multi* m, int phase)
 {
-    if (!m->timing || m->tmark > PHD_MULTI_PHASES) return PHD_OK;
+    if (!m->timing) return PHD_OK;
+    if (m->tmark >= phd_multi::MARKS) return fail(PHD_ERR_INVALID_ARG, "phd_multi: more phase marks in one step than the timing pass holds");
     Shard& s = m->sh[0];
     HIPCHK(hipSetDevice(s.device));
     HIPCHK(hipEventRecord(m->tev[m->tmark], s.stream));
@@ -246,27 +252,50 @@ int resample_stage(phd_multi* m, double uniform, bool from_raw)
         // small shards: whole shards travel, nothing waits for the host
         PHDCHK(ensure_allrows(m));
         PHDCHK(peer_wait_consumed(m));
+        // (no fresh global normalisation — resampleParticles without an update before it: the rows carry every shard's CURRENT
+        //  normalised weights and the routine uses them as they are)
+        const bool stale = !m->scratch_current;
         for (int k = 0; k < W; ++k) {
             void* rows = nullptr;
-            PHDCHK(phd_export_shard_dev(m->sh[k].f, &rows, nullptr));
+            if (stale) PHDCHK(phd_export_shard_current_dev(m->sh[k].f, &rows, nullptr));
+            else PHDCHK(phd_export_shard_dev(m->sh[k].f, &rows, nullptr));
             src[k] = rows;
             dst[k] = m->sh[k].allrows;
         }
-        PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_PLAN_EXPORT));     // (the export of the whole shard into its rows)
         PHDCHK(all_gather(m, src, dst, (size_t)m->n * m->pack));
         PHDCHK(t_mark(m, PHD_MULTI_PHASE_ALL_GATHER));
         for (int k = 0; k < W; ++k)
-            PHDCHK(phd_global_resample_gathered(m->sh[k].f, m->sh[k].allrows, uniform, W, k, 0, nullptr));
+            PHDCHK(phd_global_resample_gathered(m->sh[k].f, m->sh[k].allrows, uniform, W, k, stale ? 2 : 0, nullptr));
         PHDCHK(t_mark(m, PHD_MULTI_PHASE_IMPORT));
+        m->scratch_current = false;
         return PHD_OK;
+    }
+    // A resample that no update + global normalisation precedes (a control-only step of the particle shotgun crossing
+    // 5 n_particles, src/main.cpp:1286; resampleParticles called twice): the shards' scratch copies of the global weights are
+    // stale — shorter than the grown set, or from before the last resample.  Every shard's CURRENT normalised weights are
+    // gathered instead (also the cross-device ordering point the PULL exchange needs) and used as they are.
+    const bool regather = !from_raw && !m->scratch_current;
+    if (regather) {
+        PHDCHK(peer_wait_consumed(m));
+        for (int k = 0; k < W; ++k) {
+            float* lw = nullptr;
+            PHDCHK(phd_logweights_dev(m->sh[k].f, &lw));
+            src[k] = lw;
+            dst[k] = m->sh[k].allw;
+        }
+        PHDCHK(all_gather(m, src, dst, (size_t)ncur(m) * sizeof(float)));
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_ALL_GATHER));
     }
     // indices on every shard (identical), downloaded ONCE; every shard plans from the same host copy
     int32_t* d_idx0 = nullptr;
     for (int k = 0; k < W; ++k) {
         int32_t* d_idx = nullptr;
-        PHDCHK(phd_global_resample_launch(m->sh[k].f, from_raw ? m->sh[k].allw : nullptr, uniform, &d_idx));
+        if (regather) PHDCHK(phd_global_resample_launch_normalized(m->sh[k].f, m->sh[k].allw, uniform, &d_idx));
+        else PHDCHK(phd_global_resample_launch(m->sh[k].f, from_raw ? m->sh[k].allw : nullptr, uniform, &d_idx));
         if (k == 0) d_idx0 = d_idx;
     }
+    m->scratch_current = false;                         // (the resample below changes every weight)
     PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
     if (m->pull) {
         // no host round trip: every shard copies its slots' parents straight out of the owners' slabs.  Every owner's update
@@ -374,10 +403,22 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
         m->cap = phd_map_capacity(m->sh[0].f);
         m->MM = o.max_measurements > 0 ? std::min(o.max_measurements, PHD_MAX_MEASUREMENTS) : PHD_MAX_MEASUREMENTS;
         m->pack = phd_particle_pack_bytes(m->sh[0].f);
-        m->gathered = o.exchange == PHD_EXCHANGE_GATHERED ||
-                      (o.exchange == PHD_EXCHANGE_AUTO && (size_t)m->N * m->pack <= m->gathered_limit);
+        // PHD_MULTI_EXCHANGE = gathered | pull | alltoall picks the form an AUTO create takes (an explicit option wins): a way to
+        // fall back to the host-planned exchange on a machine whose peer reads misbehave, without rebuilding the caller
+        int exchange = o.exchange;
+        if (exchange == PHD_EXCHANGE_AUTO) {
+            const char* ex = getenv("PHD_MULTI_EXCHANGE");
+            if (ex && !strcmp(ex, "gathered")) exchange = PHD_EXCHANGE_GATHERED;
+            else if (ex && !strcmp(ex, "pull")) exchange = PHD_EXCHANGE_PULL;
+            else if (ex && !strcmp(ex, "alltoall")) exchange = PHD_EXCHANGE_ALLTOALL;
+            else if (ex && *ex && strcmp(ex, "auto")) rc = fail(PHD_ERR_INVALID_ARG, std::string("PHD_MULTI_EXCHANGE=") + ex + ": expected gathered, pull, alltoall or auto");
+        }
+        m->gathered = exchange == PHD_EXCHANGE_GATHERED ||
+                      (exchange == PHD_EXCHANGE_AUTO && (size_t)m->N * m->pack <= m->gathered_limit);
         // direct reads of the other shards' slabs: peer access between every pair of distinct devices
-        bool peers = world <= 16;
+        // (PHD_MULTI_FLAG_NO_PEER_ACCESS: behave as if no pair of DISTINCT devices had it — the decision below under test;
+        //  with every shard on one device it declares that one device "without peers" too, so that a one-GPU box can run it)
+        bool peers = world <= 16 && !(o.flags & PHD_MULTI_FLAG_NO_PEER_ACCESS);
         for (int a = 0; a < world && peers; ++a)
             for (int b = 0; b < world && peers; ++b) {
                 const int da = m->sh[a].device, db = m->sh[b].device;
@@ -389,11 +430,13 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
                 (void)hipGetLastError();
             }
-        if (o.exchange == PHD_EXCHANGE_PULL && !peers) rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: PHD_EXCHANGE_PULL needs peer access between every pair of devices (at most 16 shards)");
-        m->pull = peers && (o.exchange == PHD_EXCHANGE_PULL || o.exchange == PHD_EXCHANGE_AUTO);
+        if (rc == PHD_OK && exchange == PHD_EXCHANGE_PULL && !peers)
+            rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: PHD_EXCHANGE_PULL needs peer access between every pair of devices (at most 16 shards)");
+        // AUTO without peer access: the host-planned exchange (index download + ncclSend/ncclRecv pairs) — never an error
+        m->pull = peers && (exchange == PHD_EXCHANGE_PULL || exchange == PHD_EXCHANGE_AUTO);
         if (m->kpred > 1) {
             // the particle shotgun on shards: the grown set is resampled back by the PULL exchange (the other forms pack n particles)
-            if (!m->pull) rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: n_predict_particles > 1 on shards needs the PULL exchange (peer access between the devices)");
+            if (rc == PHD_OK && !m->pull) rc = fail(PHD_ERR_UNSUPPORTED, "phd_multi_create: n_predict_particles > 1 on shards needs the PULL exchange (peer access between the devices)");
             m->gathered = false;
         }
         for (auto& s : m->sh) {
@@ -449,12 +492,18 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
             else job->cv.wait(lk, [&] { return job->done; });
             if (!timed_out) { r = job->r; comms = job->comms; }
         }
+        if (timed_out) {
+            // The init thread is still inside ncclCommInitAll, on these devices, reading the environment: nothing it may touch is
+            // torn down — the shards, their streams and the handle are LEAKED on purpose, NCCL_SOCKET_IFNAME stays as it is — and
+            // the caller is told that this process cannot create another multi-device filter: it must exit (include/phdslam_multi.h)
+            return fail(PHD_ERR_HIP, "ncclCommInitAll did not return within " + std::to_string(timeout_s) +
+                                     " s (PHD_RCCL_INIT_TIMEOUT): run with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,BOOTSTRAP to see where "
+                                     "the bootstrap waits; --shards on one device (device-copy transport) needs no communicator.  The "
+                                     "bootstrap thread is still running: this process must exit (no further phd_multi_create)");
+        }
         if (!had_if) unsetenv("NCCL_SOCKET_IFNAME");
         (void)hipSetDevice(m->sh[0].device);
-        if (timed_out)
-            rc = fail(PHD_ERR_HIP, "ncclCommInitAll did not return within " + std::to_string(timeout_s) +
-                                   " s (PHD_RCCL_INIT_TIMEOUT): run with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,BOOTSTRAP to see where "
-                                   "the bootstrap waits; --shards on one device (device-copy transport) needs no communicator");
+        if (false) {}
         else if (r != ncclSuccess) rc = fail(PHD_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
         else for (int k = 0; k < world; ++k) m->sh[k].comm = comms[k];
     }
@@ -522,6 +571,7 @@ extern "C" int phd_multi_set_frozen(phd_multi* m, int freeze)
     CHECK_M(m);
     for (auto& s : m->sh) PHDCHK(phd_set_frozen(s.f, freeze));
     m->frozen = freeze != 0;
+    m->scratch_current = false;
     return PHD_OK;
 }
 
@@ -537,6 +587,7 @@ extern "C" int phd_multi_set_particles(phd_multi* m, const phd_pose* poses, cons
     CHECK_M(m);
     const int nc = ncur(m);
     if (n != m->world * nc) return fail(PHD_ERR_INVALID_ARG, "phd_multi_set_particles: n != the current particle count");
+    m->scratch_current = false;
     for (int k = 0; k < m->world; ++k)
         PHDCHK(phd_set_particles(m->sh[k].f, poses ? poses + (size_t)k * nc : nullptr,
                                  log_weights ? log_weights + (size_t)k * nc : nullptr, nc));
@@ -619,12 +670,21 @@ static int step_resident_body(phd_multi* m, phd_ackerman_control u, double unifo
     if (did_resample_out) *did_resample_out = 0;
     PHDCHK(peer_wait_consumed(m));
     PHDCHK(t_mark(m, 0));                               // start of the step
-    if (M <= 0) {                                       // no scan: predict only (src/main.cpp:1244-1260); no resample (:1286)
+    m->scratch_current = false;
+    if (M <= 0) {
+        // no scan: predict only (src/main.cpp:1244-1260).  The nEff trigger needs measurements (:1286); a grown particle set
+        // (n_predict_particles > 1) beyond 5 n_particles is resampled back all the same, and so is a forced step — what
+        // phd_step_dev does on a single filter
         for (auto& s : m->sh) {
             if (m->kpred > 1) PHDCHK(phd_predict_ackerman_dev(s.f, u, m->have_noise ? s.d_noise : nullptr));
             else PHDCHK(phd_step_local_dev(s.f, u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
         }
-        return t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP);
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
+        if (force_resample || W * ncur(m) > 5 * m->N) {
+            if (did_resample_out) *did_resample_out = 1;
+            return resample_stage(m, uniform, false);
+        }
+        return PHD_OK;
     }
     if (m->gathered && force_resample) {
         // small shards, forced resample: nothing waits for the host
@@ -655,6 +715,7 @@ static int step_resident_body(phd_multi* m, phd_ackerman_control u, double unifo
         const int n_now = W * ncur(m);
         for (int k = W - 1; k >= 0; --k)
             PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, n_now, k == 0 ? &neff : nullptr));
+        m->scratch_current = true;
         PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
         resample = neff <= m->cfg.resampleThresh || n_now > 5 * m->N;                // src/main.cpp:1286
         if (!resample) return PHD_OK;
@@ -678,7 +739,7 @@ extern "C" int phd_multi_timing_enable(phd_multi* m, int enable)
     CHECK_M(m);
     if (enable && !m->tev[0]) {
         HIPCHK(hipSetDevice(m->sh[0].device));
-        for (int k = 0; k <= PHD_MULTI_PHASES; ++k) HIPCHK(hipEventCreate(&m->tev[k]));
+        for (int k = 0; k < phd_multi::MARKS; ++k) HIPCHK(hipEventCreate(&m->tev[k]));
     }
     m->timing = enable != 0;
     m->tmark = 0;
@@ -805,6 +866,7 @@ extern "C" int phd_multi_update(phd_multi* m, const phd_ackerman_control* u, con
     CHECK_M(m);
     PHDCHK(phd_multi_upload_inputs(m, noise, z, n_meas));
     PHDCHK(peer_wait_consumed(m));
+    m->scratch_current = false;
     if (m->n_meas <= 0) {
         if (u) for (auto& s : m->sh) {
             if (m->kpred > 1) PHDCHK(phd_predict_ackerman_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr));
@@ -814,6 +876,7 @@ extern "C" int phd_multi_update(phd_multi* m, const phd_ackerman_control* u, con
     }
     PHDCHK(update_stage(m, u));
     for (int k = m->world - 1; k >= 0; --k) PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->world * ncur(m), nullptr));
+    m->scratch_current = true;
     return PHD_OK;
 }
 

@@ -23,7 +23,10 @@ EXCHANGE_NAMES = {1: "gathered", 2: "alltoall", 3: "pull"}
 class MultiOptions(C.Structure):
     _fields_ = [("n_shards", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("map_capacity", C.c_int32),
                 ("max_measurements", C.c_int32), ("survivor_capacity", C.c_int32), ("transport", C.c_int32),
-                ("exchange", C.c_int32), ("gathered_limit_bytes", C.c_size_t)]
+                ("exchange", C.c_int32), ("gathered_limit_bytes", C.c_size_t), ("flags", C.c_uint32)]
+
+
+FLAG_NO_PEER_ACCESS = 1
 
 
 _vp, _i, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint64
@@ -83,7 +86,7 @@ class MultiFilter:
     shards that share a device exchange by device copies instead of RCCL)."""
 
     def __init__(self, cfg, n_shards=0, devices=None, map_capacity=256, max_measurements=256, survivor_capacity=0,
-                 transport=TRANSPORT_AUTO, exchange=EXCHANGE_AUTO, gathered_limit_bytes=0):
+                 transport=TRANSPORT_AUTO, exchange=EXCHANGE_AUTO, gathered_limit_bytes=0, flags=0):
         self.cfg = cfg
         dv = None
         if devices is not None:
@@ -91,7 +94,8 @@ class MultiFilter:
             n_shards = n_shards or len(devices)
         opt = MultiOptions(n_shards=int(n_shards), devices=dv, map_capacity=int(map_capacity),
                            max_measurements=int(max_measurements), survivor_capacity=int(survivor_capacity),
-                           transport=int(transport), exchange=int(exchange), gathered_limit_bytes=int(gathered_limit_bytes))
+                           transport=int(transport), exchange=int(exchange), gathered_limit_bytes=int(gathered_limit_bytes),
+                           flags=int(flags))
         h = C.c_void_p()
         check(mlib().phd_multi_create(C.byref(cfg), C.byref(opt), C.byref(h)), "phd_multi_create")
         self._h = h

@@ -309,16 +309,22 @@ int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer);
  * synchronisation; *d_idx_out = the device copy of the indices); the host downloads the indices ONCE (they are identical on
  * every shard) and every shard plans its part of the migration and exports from that host copy with _plan. */
 int phd_global_resample_launch(phd_filter* f, const float* d_all_raw_logw, double uniform, int32_t** d_idx_out);
+/* the same from the gathered CURRENT (already normalised) log-weights of all shards — a resample no update precedes
+ * (resampleParticles after a control-only step: the particle shotgun's N > 5 n_particles trigger, src/main.cpp:1286; a second
+ * call of resampleParticles): the vector is used as it is, exactly as phd_resample uses a single filter's weights */
+int phd_global_resample_launch_normalized(phd_filter* f, const float* d_all_logw, double uniform, int32_t** d_idx_out);
 int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int world, int rank, int32_t* send_counts,
                              int32_t* recv_counts, void** d_send_buffer);
 /* The same exchange for small shards with no host round trip ("gathered" exchange): phd_export_shard_dev packs the
  * whole shard (n rows of phd_particle_pack_bytes; header word 7 = the particle's un-normalised log-weight) into the
  * library's send buffer; the caller all-gathers the shards in rank order (one fixed-size RCCL all-gather);
- * phd_global_resample_gathered normalises (weights_in_rows != 0: from the rows; 0: the vector phd_global_normalize
- * left), draws the identical global indices on every rank and fills this shard's slots straight from the gathered
- * rows.  Everything is stream-ordered; idx_out (optional, host) forces a synchronisation.  Traffic is
+ * phd_global_resample_gathered takes the weights (weights_in_rows = 1: un-normalised, from the rows — normalised first;
+ * 0: the vector phd_global_normalize left; 2: the shards' CURRENT normalised weights from the rows of
+ * phd_export_shard_current_dev, used as they are — a resample no update precedes), draws the identical global indices on
+ * every rank and fills this shard's slots straight from the gathered rows.  Everything is stream-ordered; idx_out (optional, host) forces a synchronisation.  Traffic is
  * world * n * pack bytes per rank: for small shards only — phd_global_resample_begin/_end move just the migrants. */
 int phd_export_shard_dev(phd_filter* f, void** d_rows, size_t* bytes_out);
+int phd_export_shard_current_dev(phd_filter* f, void** d_rows, size_t* bytes_out);   /* header word 7 = the current log-weight */
 /* phd_step_local_dev + phd_export_shard_dev in ONE launch: the update kernel writes every particle's merged map, predicted
  * pose, count and raw log-weight straight into its export row.  The updated maps then exist only in the rows, so the step
  * MUST be completed by phd_global_resample_gathered; until then a live (not frozen) filter refuses every other call

@@ -38,7 +38,13 @@ enum { PHD_TRANSPORT_AUTO = 0, PHD_TRANSPORT_RCCL = 1, PHD_TRANSPORT_PEER_COPY =
  *             trip, no staging buffer, a remote parent crosses the link once per destination shard)
  *   ALLTOALL  index download + host plan + export + ncclSend/ncclRecv pairs + import (one host round trip)
  *   AUTO      GATHERED while n_particles * pack bytes <= gathered_limit_bytes, else PULL when every device pair has peer
- *             access (always true for shards on one device), else ALLTOALL */
+ *             access (always true for shards on one device), else ALLTOALL — never an error.  The environment variable
+ *             PHD_MULTI_EXCHANGE = gathered | pull | alltoall | auto picks the form an AUTO create takes (an explicit option
+ *             wins): the way back to the host-planned exchange on a machine whose peer reads misbehave.
+ * The PULL form on DISTINCT devices is unmeasured on hardware (this build has only ever seen one-GPU boxes): its cross-device
+ * ordering is the RCCL all-gather of the log-weights (every owner's update precedes it on the owner's stream; every reader's
+ * pull follows it on the reader's stream) plus the `done` events the owners' next update waits for.  tests/test_gpu_multi_devices.py
+ * runs it against a single filter bit for bit wherever two devices exist, and bench.py verifies it on first contact. */
 enum { PHD_EXCHANGE_AUTO = 0, PHD_EXCHANGE_GATHERED = 1, PHD_EXCHANGE_ALLTOALL = 2, PHD_EXCHANGE_PULL = 3 };
 
 /* zero-initialise and set what you need (0 = default) */
@@ -51,10 +57,20 @@ typedef struct {
     int32_t transport;            /* PHD_TRANSPORT_*: AUTO = RCCL when every shard has a device of its own, else peer copies */
     int32_t exchange;             /* PHD_EXCHANGE_*: AUTO = gathered while n_particles * pack bytes <= gathered_limit_bytes  */
     size_t gathered_limit_bytes;  /* 0 = 32 MiB                                                                              */
+    uint32_t flags;               /* PHD_MULTI_FLAG_*                                                                        */
 } phd_multi_options;
+/* behave as if no pair of devices had peer access (tests the AUTO decision: it must fall back to ALLTOALL without an error) */
+enum { PHD_MULTI_FLAG_NO_PEER_ACCESS = 1u };
 
 /* cfg->n_particles = the GLOBAL particle count (divisible by n_shards).
- * replaces: the device setup of main() (src/main.cpp:1449-1466) + the per-step allocations of phdUpdateSynth */
+ * replaces: the device setup of main() (src/main.cpp:1449-1466) + the per-step allocations of phdUpdateSynth
+ * RCCL communicator creation runs under a watchdog (PHD_RCCL_INIT_TIMEOUT seconds, default 120, 0 = no limit).  On a time-out
+ * the call returns PHD_ERR_HIP with the diagnostics to run, and THE PROCESS MUST EXIT: the bootstrap thread is still inside
+ * ncclCommInitAll on these devices, so everything it may touch (the shards, their streams, NCCL_SOCKET_IFNAME) is deliberately
+ * left alive, and a further phd_multi_create in the same process would race it.
+ * NCCL_SOCKET_IFNAME: when unset, it is set to "lo" around ncclCommInitAll and removed afterwards (one process, one node: no
+ * routable interface is needed) — setenv/unsetenv are not thread-safe against getenv in other threads, so either call this
+ * before the process starts threads that read the environment, or export NCCL_SOCKET_IFNAME yourself (then nothing is touched). */
 int phd_multi_create(const phd_slam_config* cfg, const phd_multi_options* opt, phd_multi** out);
 int phd_multi_destroy(phd_multi* m);
 int phd_multi_n_shards(const phd_multi* m);

@@ -141,6 +141,8 @@ def test_bench_gpus_2_unlaunched_runs_the_cpp_host():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "steps/s"
     c = d["config"]
     assert c["cpp_multi_host"] and c["n_shards"] == 2 and c["particles_total"] == 16384 and c["share_gpu_dry_run"]
+    # the first-contact check: before timing, the sharded filter equalled a single filter bit for bit on these devices
+    assert c["multi_gpu_verified"]["equal_to_single_filter"] is True and c["multi_gpu_verified"]["exchange"] == c["multi_gpu_exchange"], c["multi_gpu_verified"]
     ph = c["multi_gpu_phase_us_shard0"]
     for k in ("local_step", "all_gather", "weights", "plan_export", "send_recv", "import", "resample_with_migration"):
         assert ph[k] >= 0.0
@@ -196,3 +198,145 @@ def test_particle_shotgun_on_shards_equals_one_filter(shards):
         # 48 -> 96 -> (forced) 48 -> 96 -> 192 -> 384 (> 240: back to 48)
         assert [c[0] for c in counts] == [96, 48, 96, 192, 48], counts
         f.status()
+
+
+@pytest.mark.parametrize("shards", [1, 2, 4])
+@pytest.mark.parametrize("style", ["step", "update_resample"])
+def test_shotgun_crossing_5n_on_a_step_without_a_scan(shards, style):
+    """control-only steps (timestamped data, subdivide_predict) grow a shotgun particle set too, and the
+    step that crosses 5 n_particles may carry no scan (src/main.cpp:1286: `... || N > 5 n_particles`).  No update precedes that
+    resample, so no log-weight all-gather and no global normalisation has run: the shards' scratch copy of the global weights
+    is stale (shorter than the grown set).  The host gathers every shard's CURRENT normalised weights instead and uses them as
+    they are — particles, weights and maps bit for bit those of a single filter, through phd_multi_step and through the
+    driver's order phd_multi_update + phd_multi_resample."""
+    P, S, MM = pkg(), synthetic(), mod()
+    n, k, steps = 32, 2, 6
+    w = S.make_workload(n, 10, 8, seed=640 + shards, n_meas_sets=steps)
+    cfg = P.default_config(nPredictParticles=k, n_particles=n, resampleThresh=0.0)      # only N > 5 n triggers
+    rng = np.random.default_rng(6)
+    empty = np.zeros(0, P.MEAS)
+    scans = [w["z"][0], empty, empty, w["z"][3], empty, empty]                            # 64, 128, 256 (> 160: on an EMPTY scan) ...
+    with P.PhdFilter(cfg, n_particles=n, map_capacity=96, max_measurements=16) as f, \
+            MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=96, max_measurements=16) as m:
+        for x in (f, m):
+            x.set_particles(w["poses"], w["logw"])
+            x.set_maps(w["maps"], w["sizes"])
+        counts = []
+        for step in range(steps):
+            na = f.n
+            z = scans[step]
+            noise = np.stack([rng.normal(0, 0.03, na * k), rng.normal(0, 1.0, na * k)], 1).astype(np.float32)
+            f.predict((2.0, 0.05), noise)
+            if len(z):
+                f.update(z)
+            did_f, _ = f.resample_if_needed(w["uniform"][step], had_measurements=len(z) > 0)
+            if style == "step":
+                did = m.step((2.0, 0.05), noise, z, w["uniform"][step], force_resample=False)
+            else:
+                m.update((2.0, 0.05), noise, z)
+                did = m.n_now > 5 * n                                                      # the driver's trigger (compat/phdslam_main.cpp)
+                if did:
+                    m.resample(w["uniform"][step])
+            counts.append((f.n, m.n_now, did_f, did))
+            assert did == did_f and f.n == m.n_now, counts
+            pa, la = f.get_particles()
+            pb, lb = m.get_particles()
+            assert np.array_equal(pa, pb) and np.array_equal(la, lb), (step, counts)
+            for x, y in zip(f.get_maps(), m.get_maps()):
+                assert np.array_equal(x, y), step
+        assert [c[0] for c in counts] == [64, 128, 32, 64, 128, 32], counts
+        assert counts[2][2] and counts[5][2]                                               # both resamples fell on empty scans
+        f.status()
+
+
+@pytest.mark.parametrize("shards,exchange", [(2, "pull"), (3, "alltoall"), (2, "gathered")])
+def test_resample_without_a_preceding_update_equals_one_filter(shards, exchange):
+    """resampleParticles twice in a row, and after a control-only step, on a sharded filter: the second call finds no fresh
+    global normalisation and must gather the current weights (phd_global_resample_launch_normalized) — a single filter's
+    phd_resample uses its weights as they are, and so must this (a re-normalisation would move last bits)"""
+    P, S, MM = pkg(), synthetic(), mod()
+    N = 48
+    w = S.make_workload(N, 10, 6, seed=77, n_meas_sets=2)
+    w["logw"] = (w["logw"] + np.linspace(0, 4.0, N).astype(np.float32)).astype(np.float32)
+    cfg = P.default_config(n_particles=N)
+    ex = {"gathered": MM.EXCHANGE_GATHERED, "alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=64, max_measurements=16) as f, \
+            MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=64, max_measurements=16, exchange=ex) as m:
+        for x in (f, m):
+            x.set_particles(w["poses"], w["logw"])
+            x.set_maps(w["maps"], w["sizes"])
+
+        def same(tag):
+            pa, la = f.get_particles()
+            pb, lb = m.get_particles()
+            assert np.array_equal(pa, pb) and np.array_equal(la, lb), tag
+            for x, y in zip(f.get_maps(), m.get_maps()):
+                assert np.array_equal(x, y), tag
+        f.resample(0.31); m.resample(0.31); same("resample of the initial weights (no update at all)")
+        f.predict((2.0, 0.05), w["noise"][0]); f.update(w["z"][0])
+        m.update((2.0, 0.05), w["noise"][0], w["z"][0]); same("update")
+        f.resample(0.62); m.resample(0.62); same("resample after the update")
+        f.resample(0.17); m.resample(0.17); same("a second resample, no update in between")
+        f.predict((2.0, 0.02), w["noise"][1])
+        m.update((2.0, 0.02), w["noise"][1], np.zeros(0, P.MEAS)); same("control-only step")
+        f.resample(0.88); m.resample(0.88); same("resample after a control-only step")
+
+
+def test_auto_exchange_without_peer_access_falls_back_to_alltoall(monkeypatch):
+    """a PHD_EXCHANGE_AUTO create on devices WITHOUT peer access must take the host-planned exchange
+    (index download + send/recv pairs) without an error.  No such machine is at hand, so the decision is tested with the
+    injected PHD_MULTI_FLAG_NO_PEER_ACCESS: AUTO -> alltoall (and still bit for bit a single filter), an explicit PULL -> a
+    clear refusal, small shards -> gathered as before; PHD_MULTI_EXCHANGE overrides what AUTO picks, never an explicit option."""
+    P, S, MM = pkg(), synthetic(), mod()
+    N, steps = 64, 3
+    w = S.make_workload(N, 12, 8, seed=91, n_meas_sets=steps)
+    cfg = P.default_config(n_particles=N)
+    big = dict(n_shards=2, devices=[0, 0], map_capacity=96, max_measurements=16, gathered_limit_bytes=1)   # never "small shards"
+    with MM.MultiFilter(cfg, flags=MM.FLAG_NO_PEER_ACCESS, **big) as m:
+        assert m.exchange == "alltoall"
+        ref = run_single(cfg, w, steps, 96, 16, False, [True] * steps)
+        m.seed(77)
+        m.set_particles(w["poses"], w["logw"])
+        m.set_maps(w["maps"], w["sizes"])
+        for k in range(steps):
+            m.step((2.0, 0.05 - 0.01 * k), w["noise"][k], w["z"][k], w["uniform"][k], force_resample=True)
+            p, lw = m.get_particles()
+            assert np.array_equal(p, ref[k][1]) and np.array_equal(lw, ref[k][2]), k
+            for a, b in zip(m.get_maps(), ref[k][3]):
+                assert np.array_equal(a, b), k
+    with MM.MultiFilter(cfg, **big) as m:
+        assert m.exchange == "pull"                                   # with peer access (shards on one device always have it)
+    with pytest.raises(P.PhdError) as e:
+        MM.MultiFilter(cfg, flags=MM.FLAG_NO_PEER_ACCESS, exchange=MM.EXCHANGE_PULL, **big)
+    assert "peer access" in str(e.value)
+    with MM.MultiFilter(cfg, n_shards=2, devices=[0, 0], map_capacity=96, max_measurements=16, flags=MM.FLAG_NO_PEER_ACCESS) as m:
+        assert m.exchange == "gathered"                               # small shards never needed peer access
+    monkeypatch.setenv("PHD_MULTI_EXCHANGE", "alltoall")
+    with MM.MultiFilter(cfg, **big) as m:
+        assert m.exchange == "alltoall"
+    with MM.MultiFilter(cfg, exchange=MM.EXCHANGE_PULL, **big) as m:
+        assert m.exchange == "pull"                                   # an explicit option wins
+    monkeypatch.setenv("PHD_MULTI_EXCHANGE", "bogus")
+    with pytest.raises(P.PhdError):
+        MM.MultiFilter(cfg, **big)
+
+
+def test_phase_timing_holds_the_longest_step():
+    """a non-forced step that resamples through the all-to-all exchange records 8 phase marks (start, local
+    step, all-gather, weights of the normalise, weights of the index launch, plan + export, send/recv, import); the timing
+    pass used to hold 7 and dropped the last span silently"""
+    P, S, MM = pkg(), synthetic(), mod()
+    N = 64
+    w = S.make_workload(N, 12, 8, seed=92)
+    w["logw"] = (w["logw"] + np.linspace(0, 6.0, N).astype(np.float32)).astype(np.float32)     # nEff well below the threshold
+    cfg = P.default_config(n_particles=N, resampleThresh=0.9)
+    with MM.MultiFilter(cfg, n_shards=2, devices=[0, 0], map_capacity=96, max_measurements=16, exchange=MM.EXCHANGE_ALLTOALL) as m:
+        m.set_particles(w["poses"], w["logw"])
+        m.set_maps(w["maps"], w["sizes"])
+        m.set_frozen(True)
+        m.timing(True)
+        m.upload_inputs(w["noise"][0], w["z"][0])
+        for _ in range(3):
+            m.step_resident((2.0, 0.05), 0.4, force_resample=False)
+        ph, k = m.timing_read()
+        assert k == 3 and ph["import"] > 0 and ph["send_recv"] > 0 and ph["plan_export"] > 0 and ph["weights"] > 0, ph
