@@ -18,6 +18,7 @@
 #include <sys/time.h>
 
 #include <condition_variable>
+#include <algorithm>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -253,7 +254,8 @@ int main(int argc, char** argv)
     int log_err = 0, log_inflight = 0;
     std::vector<std::thread> log_threads;
     if (!sync_log)
-        for (int t = 0; t < 4; ++t)
+        // (writer threads: a 4096-particle log is ~29 000 numbers; the filter produces two of them per millisecond)
+        for (unsigned t = 0, nt = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2)); t < nt; ++t)
             log_threads.emplace_back([&]() {
                 for (;;) {
                     LogJob j;
@@ -297,7 +299,12 @@ int main(int argc, char** argv)
     double acc_t[5] = {0, 0, 0, 0, 0};
     auto now = []() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; };
     double tp = 0;
-#define PROF_MARK(k) do { if (prof) { const double t_ = now(); acc_t[k] += t_ - tp; tp = t_; } } while (0)
+    // per step: the five phases, and what the step was made of — <out>/loopProfile.log, one line per step:
+    //   step M map_size resampled | inputs+predict update state_extraction resample log_hand_off  (ms)
+    // (tools/e2e_run.py turns it into per-phase percentiles and names the phase the slow steps spend their time in)
+    double step_t[5] = {0, 0, 0, 0, 0};
+    FILE* prof_file = prof ? fopen((out_dir + "/loopProfile.log").c_str(), "w") : nullptr;
+#define PROF_MARK(k) do { if (prof) { const double t_ = now(); acc_t[k] += t_ - tp; step_t[k] = t_ - tp; tp = t_; } } while (0)
     for (int n = 0; n < nSteps; ++n) {
         timeval t0, t1;
         gettimeofday(&t0, nullptr);
@@ -453,7 +460,10 @@ int main(int argc, char** argv)
         double elapsed = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_usec - t0.tv_usec) / 1000.0;
         if (FILE* tf = fopen(timefile.c_str(), "a")) { fprintf(tf, "%g\n", elapsed); fclose(tf); } // :1300-1305
         printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", n, nSteps, M, n_cur, n_map, did, elapsed);
+        if (prof_file) fprintf(prof_file, "%d %d %d %d %.4f %.4f %.4f %.4f %.4f\n", n, M, n_map, (int)did, step_t[0], step_t[1], step_t[2],
+                               step_t[3], step_t[4]);
     }
+    if (prof_file) fclose(prof_file);
     if (prof && nSteps > 0)
         printf("loop profile (ms per step): inputs+predict %.3f, update %.3f, state extraction %.3f, resample %.3f, log writing %.3f\n",
                acc_t[0] / nSteps, acc_t[1] / nSteps, acc_t[2] / nSteps, acc_t[3] / nSteps, acc_t[4] / nSteps);

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <charconv>
 #include <fstream>
 #include <iomanip>
 #include <map>
@@ -365,6 +366,53 @@ extern "C" int phd_load_trajectory(const char* path, phd_pose* out, size_t capac
 }
 
 // ---------------------------------------------------------------------------------------------
+// Number formatting of the state logs.  The reference streams every float through operator<< (src/main.cpp:861-952): the
+// default ostream format, i.e. printf's %g with precision 6.  std::to_chars(general, 6) produces exactly those characters
+// (C++17 [charconv.to.chars]: "as if by std::printf" with the same conversion) without the locale / sentry / virtual-call
+// machinery of a stream: at 4096 particles a log is ~29 000 numbers, which cost the writer threads 3 - 6 ms through a
+// stream — more than six filter steps — and made the log queue's back-pressure the p90 of the driver's loop time.
+// ---------------------------------------------------------------------------------------------
+struct LogBuf {
+    std::string s;
+    void reserve(size_t n) { s.reserve(n); }
+    void num(float v)
+    {
+        char tmp[32];
+        const auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::general, 6);
+        s.append(tmp, (size_t)(r.ptr - tmp));
+        s.push_back(' ');
+    }
+    void integer(int v)
+    {
+        char tmp[16];
+        const auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+        s.append(tmp, (size_t)(r.ptr - tmp));
+        s.push_back(' ');
+    }
+    void endl() { s.push_back('\n'); }
+};
+
+static std::string state_log_name(const char* dir, int step)
+{
+    std::ostringstream name;
+    if (dir && dir[0]) {
+        name << dir;
+        if (name.str().back() != '/') name << '/';
+    }
+    name << "state_estimate" << std::setfill('0') << std::setw(5) << step << ".log"; // src/main.cpp:854-858
+    return name.str();
+}
+
+static int write_whole(const std::string& name, const std::string& text, bool append)
+{
+    FILE* f = fopen(name.c_str(), append ? "ab" : "wb");
+    if (!f) return host_fail(PHD_ERR_IO, "cannot write " + name);
+    const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+    const bool closed = fclose(f) == 0;
+    return (ok && closed) ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name);
+}
+
+// ---------------------------------------------------------------------------------------------
 // state_estimate%05d.log — the 5-line consumer contract (README:31-39; python/batch_analyze.py:16-24;
 // python/plot_phdslam.py:205-226): default operator<< float formatting, space separated, trailing space
 // ---------------------------------------------------------------------------------------------
@@ -372,33 +420,27 @@ static int write_log5(const char* dir, int step, const phd_pose* e, const phd_ga
                       const float* log_weights, const phd_pose* poses, int n_particles, int max_cardinality, const float* cn)
 {
     if (!e) return host_fail(PHD_ERR_INVALID_ARG, "null pose");
-    std::ostringstream name;
-    if (dir && dir[0]) {
-        name << dir;
-        if (name.str().back() != '/') name << '/';
-    }
-    name << "state_estimate" << std::setfill('0') << std::setw(5) << step << ".log"; // src/main.cpp:854-858
-    std::ofstream s(name.str().c_str(), std::ios::out | std::ios::trunc);
-    if (!s) return host_fail(PHD_ERR_IO, "cannot write " + name.str());
-    s << e->px << " " << e->py << " " << e->ptheta << " " << e->vx << " " << e->vy << " " << e->vtheta << " " << std::endl;
+    LogBuf o;
+    o.reserve(64 + (size_t)n_map * 80 + (size_t)n_particles * 64 + (size_t)(max_cardinality + 1) * 12);
+    o.num(e->px); o.num(e->py); o.num(e->ptheta); o.num(e->vx); o.num(e->vy); o.num(e->vtheta); o.endl();
     for (int n = 0; n < n_map; ++n) { // weight mx my c0 c1 c2 c3 (:866-878)
-        s << map[n].weight << " ";
-        for (int i = 0; i < 2; ++i) s << map[n].mean[i] << " ";
-        for (int i = 0; i < 4; ++i) s << map[n].cov[i] << " ";
+        o.num(map[n].weight);
+        for (int i = 0; i < 2; ++i) o.num(map[n].mean[i]);
+        for (int i = 0; i < 4; ++i) o.num(map[n].cov[i]);
     }
-    s << std::endl;
-    for (int n = 0; n < n_particles; ++n) s << log_weights[n] << " ";
-    s << std::endl;
-    for (int n = 0; n < n_particles; ++n)
-        s << poses[n].px << " " << poses[n].py << " " << poses[n].ptheta << " " << poses[n].vx << " " << poses[n].vy << " "
-          << poses[n].vtheta << " ";
-    s << std::endl;
+    o.endl();
+    for (int n = 0; n < n_particles; ++n) o.num(log_weights[n]);
+    o.endl();
+    for (int n = 0; n < n_particles; ++n) {
+        o.num(poses[n].px); o.num(poses[n].py); o.num(poses[n].ptheta); o.num(poses[n].vx); o.num(poses[n].vy); o.num(poses[n].vtheta);
+    }
+    o.endl();
     for (int n = 0; n < max_cardinality + 1; ++n) { // PHD: zeros, CPHD: cn_estimate (:942-949)
-        if (cn) s << cn[n] << " ";
-        else s << "0 ";
+        if (cn) o.num(cn[n]);
+        else o.s.append("0 ");
     }
-    s << std::endl;
-    return s.good() ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name.str());
+    o.endl();
+    return write_whole(state_log_name(dir, step), o.s, false);
 }
 
 extern "C" int phd_write_state_log(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,
@@ -424,39 +466,33 @@ static int write_log7(const char* dir, int step, const phd_pose* e, const phd_ga
                       int n_particles, int max_cardinality, int n_predict_particles, const float* cn)
 {
     if (!e) return host_fail(PHD_ERR_INVALID_ARG, "null pose");
-    std::ostringstream name;
-    if (dir && dir[0]) {
-        name << dir;
-        if (name.str().back() != '/') name << '/';
-    }
-    name << "state_estimate" << std::setfill('0') << std::setw(5) << step << ".log";
-    std::ofstream s(name.str().c_str(), std::ios::out | std::ios::app);
-    if (!s) return host_fail(PHD_ERR_IO, "cannot write " + name.str());
-    s << e->px << " " << e->py << " " << e->ptheta << " " << e->vx << " " << e->vy << " " << e->vtheta << " " << std::endl;
-    for (int n = 0; n < n_map; ++n) {
-        s << map[n].weight << " ";
-        for (int i = 0; i < 2; ++i) s << map[n].mean[i] << " ";
-        for (int i = 0; i < 4; ++i) s << map[n].cov[i] << " ";
-    }
-    s << std::endl;
-    s << std::endl; // dynamic map: none in the static feature model
+    LogBuf o;
     const int times = (step == 0 && n_predict_particles > 1) ? n_predict_particles : 1;
-    for (int k = 0; k < times; ++k)
-        for (int n = 0; n < n_particles; ++n) s << log_weights[n] << " ";
-    s << std::endl;
-    for (int k = 0; k < times; ++k)
-        for (int n = 0; n < n_particles; ++n)
-            s << poses[n].px << " " << poses[n].py << " " << poses[n].ptheta << " " << poses[n].vx << " " << poses[n].vy << " "
-              << poses[n].vtheta << " ";
-    s << std::endl;
-    for (int n = 0; n < n_particles; ++n) s << (resample_idx ? resample_idx[n] : n) << " ";
-    s << std::endl;
-    for (int n = 0; n < max_cardinality + 1; ++n) {
-        if (cn) s << cn[n] << " ";
-        else s << "0 ";
+    o.reserve(64 + (size_t)n_map * 80 + (size_t)n_particles * (64 * (size_t)times + 8) + (size_t)(max_cardinality + 1) * 12);
+    o.num(e->px); o.num(e->py); o.num(e->ptheta); o.num(e->vx); o.num(e->vy); o.num(e->vtheta); o.endl();
+    for (int n = 0; n < n_map; ++n) {
+        o.num(map[n].weight);
+        for (int i = 0; i < 2; ++i) o.num(map[n].mean[i]);
+        for (int i = 0; i < 4; ++i) o.num(map[n].cov[i]);
     }
-    s << std::endl;
-    return s.good() ? PHD_OK : host_fail(PHD_ERR_IO, "write failed: " + name.str());
+    o.endl();
+    o.endl(); // dynamic map: none in the static feature model
+    for (int k = 0; k < times; ++k)
+        for (int n = 0; n < n_particles; ++n) o.num(log_weights[n]);
+    o.endl();
+    for (int k = 0; k < times; ++k)
+        for (int n = 0; n < n_particles; ++n) {
+            o.num(poses[n].px); o.num(poses[n].py); o.num(poses[n].ptheta); o.num(poses[n].vx); o.num(poses[n].vy); o.num(poses[n].vtheta);
+        }
+    o.endl();
+    for (int n = 0; n < n_particles; ++n) o.integer(resample_idx ? resample_idx[n] : n);
+    o.endl();
+    for (int n = 0; n < max_cardinality + 1; ++n) {
+        if (cn) o.num(cn[n]);
+        else o.s.append("0 ");
+    }
+    o.endl();
+    return write_whole(state_log_name(dir, step), o.s, true);       // HEAD opens the log in append mode (:861)
 }
 
 extern "C" int phd_write_state_log7(const char* dir, int step, const phd_pose* e, const phd_gaussian2d* map, int n_map,

@@ -51,7 +51,7 @@ def main():
     for fn in os.listdir(out):
         os.remove(os.path.join(out, fn))
     r = subprocess.run([os.path.join(ROOT, "cuda-phdslam_amd", "bin", "phdslam"), cfg_path, "synth", "--out", out, "--seed", "7",
-                        "--capacity", "512"], capture_output=True, text=True)
+                        "--capacity", "512"] + sys.argv[3:], capture_output=True, text=True)
     if r.returncode:
         print(r.stdout[-2000:], r.stderr[-2000:])
         raise SystemExit(r.returncode)
@@ -59,6 +59,20 @@ def main():
         if line.startswith("loop profile"):               # PHD_DRIVER_PROFILE=1
             print(line)
     t = np.loadtxt(os.path.join(out, "loopTime.log"))
+    pf = os.path.join(out, "loopProfile.log")
+    if os.path.exists(pf):                                    # PHD_DRIVER_PROFILE=1: which phase do the slow steps spend their time in?
+        q = np.loadtxt(pf)
+        names = ["inputs+predict", "update (synchronised for the profile)", "state extraction", "resample", "log hand-off"]
+        ph = q[:, 4:9]
+        tot = ph.sum(1)
+        slow = tot >= np.percentile(tot, 90)
+        print("   per-phase ms        median     p90     max | mean over the slowest 10 %% of steps (those above %.3f ms)" % np.percentile(tot, 90))
+        for k, nm in enumerate(names):
+            print("   %-38s %7.3f %7.3f %7.3f | %7.3f" % (nm, np.median(ph[:, k]), np.percentile(ph[:, k], 90), ph[:, k].max(), ph[slow, k].mean()))
+        print("   slow steps: measurements %.1f (all steps %.1f), map size %.0f (%.0f), resampled %.0f %% (%.0f %%); corr(step time, step index) %.2f, "
+              "corr(step time, map size) %.2f, corr(step time, measurements) %.2f"
+              % (q[slow, 1].mean(), q[:, 1].mean(), q[slow, 2].mean(), q[:, 2].mean(), 100 * q[slow, 3].mean(), 100 * q[:, 3].mean(),
+                 np.corrcoef(tot, q[:, 0])[0, 1], np.corrcoef(tot, q[:, 2])[0, 1], np.corrcoef(tot, q[:, 1])[0, 1]))
     L = P._lib.lib()
     res = np.zeros(5, np.float64)
     k = len(data["scans"]) - 1
