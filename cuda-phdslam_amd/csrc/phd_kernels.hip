@@ -49,7 +49,9 @@
 #include "phd_predict.h"
 #include "phd_cphd.h"
 #include "phd_weights.h"
-#include "phd_spill.h"
+#ifndef PHD_CPHD_TU
+#include "phd_spill.h"      // (phd_merge_spill_kernel: a plain __global__ function, defined once)
+#endif
 
 namespace phd {
 
@@ -59,6 +61,7 @@ namespace phd {
 #ifndef PHD_LDS_PAD
 #define PHD_LDS_PAD 0
 #endif
+#ifndef PHD_CPHD_TU
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total + PHD_LDS_PAD; }
 int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
 size_t cphd_lds_bytes(int cn_len, int MM)
@@ -66,6 +69,8 @@ size_t cphd_lds_bytes(int cn_len, int MM)
     u32 off[11];
     return cphd_lds_layout(cn_len, MM, off);
 }
+
+#endif // !PHD_CPHD_TU
 
 // the last step of a particle's hand-off to the weights workgroup of the fused step: its hand-off stores (pose, indirection
 // reset, log-weight increment — relaxed agent-scope atomics by the same thread, i.e. sc1 write-through stores) must be
@@ -617,6 +622,21 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Two translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel are compiled on their
+// own with -DPHD_CPHD_TU — the kernel template above, this table and nothing else — so that the two halves build side by side
+// and the CPHD half can take compile flags of its own (csrc/Makefile, KFLAGS_CPHD: measured, currently the same).
+// ------------------------------------------------------------------------------------------
+#ifdef PHD_CPHD_TU
+// <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
+extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
+                                                 (const void*)phd_update_merge_kernel<true, false, true, false>,
+                                                 (const void*)phd_update_merge_kernel<false, true, true, false>,
+                                                 (const void*)phd_update_merge_kernel<false, false, true, true>,
+                                                 (const void*)phd_update_merge_kernel<false, true, true, true>};
+#else
+extern const void* const k_update_cphd_fns[5];
+
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
                                    u64 seed, u64 counter, DevConfig cfg)
@@ -955,13 +975,10 @@ __global__ void phd_iota_kernel(int* a, int n)
 static const void* const k_update_fns[10] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
-                                             (const void*)phd_update_merge_kernel<false, false, true, false>,
-                                             (const void*)phd_update_merge_kernel<true, false, true, false>,
-                                             (const void*)phd_update_merge_kernel<false, true, true, false>,
+                                             k_update_cphd_fns[0], k_update_cphd_fns[1], k_update_cphd_fns[2],
                                              (const void*)phd_update_merge_kernel<false, false, false, true>,
                                              (const void*)phd_update_merge_kernel<false, true, false, true>,
-                                             (const void*)phd_update_merge_kernel<false, false, true, true>,
-                                             (const void*)phd_update_merge_kernel<false, true, true, true>};
+                                             k_update_cphd_fns[3], k_update_cphd_fns[4]};
 #define PHD_N_UPDATE_FNS 10
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
@@ -1014,17 +1031,14 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         });
         if (e != hipSuccess) return e;
     }
-    const dim3 g1(n_particles), g2(n_particles + 1), b(PHD_T);   // g2: + the weights workgroup of the fused step
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
-#define PHD_LAUNCH(ST, FW, CP, SP, G) hipLaunchKernelGGL((phd_update_merge_kernel<ST, FW, CP, SP>), G, b, lds_bytes, st, a)
-    if (a.cphd && a.stamps) PHD_LAUNCH(true, false, true, false, g1);
-    else if (a.stamps) PHD_LAUNCH(true, false, false, false, g1);
-    else if (a.cphd && a.fuse_weights) { if (sp) PHD_LAUNCH(false, true, true, true, g2); else PHD_LAUNCH(false, true, true, false, g2); }
-    else if (a.cphd) { if (sp) PHD_LAUNCH(false, false, true, true, g1); else PHD_LAUNCH(false, false, true, false, g1); }
-    else if (a.fuse_weights) { if (sp) PHD_LAUNCH(false, true, false, true, g2); else PHD_LAUNCH(false, true, false, false, g2); }
-    else { if (sp) PHD_LAUNCH(false, false, false, true, g1); else PHD_LAUNCH(false, false, false, false, g1); }
-#undef PHD_LAUNCH
-    return hipGetLastError();
+    const bool fused = a.fuse_weights && !a.stamps;
+    // index into k_update_fns: <STAMPS, FUSEW, CPHD, SPILL>
+    const int fn = a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
+    const dim3 grid(n_particles + (fused ? 1 : 0)), b(PHD_T);      // + the weights workgroup of the fused step
+    UpdateArgs args = a;
+    void* argv[] = {(void*)&args};
+    return hipLaunchKernel(k_update_fns[fn], grid, b, argv, lds_bytes, st);
 }
 
 hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st)
@@ -1235,4 +1249,5 @@ hipError_t launch_iota(int* a, int n, hipStream_t st)
     return hipGetLastError();
 }
 
+#endif // !PHD_CPHD_TU
 } // namespace phd
