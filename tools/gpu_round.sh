@@ -6,7 +6,7 @@ tag=${1:-r02}; quick=$2
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q --timeout 900 --durations=8 -s > gpurun_out/gpu_tests_$tag.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/gpu_tests_$tag.log
-grep -E "structurally compared|passed|failed|error" gpurun_out/gpu_tests_$tag.log | tail -12
+grep -E "sampled particles|passed|failed|error" gpurun_out/gpu_tests_$tag.log | tail -12
 python __graft_entry__.py smoke 2>&1 | tail -1
 # the PMC passes first: bench.py prints `roofline.traffic` / `roofline_valu` only from counters recorded with THIS build
 # (tools/collect_profiles.sh copies the same files into profiles/ afterwards)
@@ -32,7 +32,7 @@ python bench.py --steps 400 --warmup 40 --no-secondary --cpu-seconds 0 > gpurun_
 python -c "import json;d=json.loads(open('gpurun_out/bench_cfg3_long_$tag.json').read().strip().splitlines()[-1]);print('long run: %.1f steps/s, stages %s' % (d['value'], d['stages_us_per_workgroup']))"
 python tools/phase_profile.py 2 3 5 > gpurun_out/phase_$tag.log 2>&1
 [ -n "$quick" ] && exit 0
-(python tools/e2e_run.py 256; python tools/e2e_run.py 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/e2e_$tag.log
+(python tools/e2e_run.py 256; python tools/e2e_run.py 4096; echo "-- with PHD_DRIVER_PROFILE=1 (the update is synchronised for the attribution):"; PHD_DRIVER_PROFILE=1 python tools/e2e_run.py 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/e2e_$tag.log
 cat gpurun_out/e2e_$tag.log
 # the N > 1 paths on this one GPU: `--gpus 2` with no launcher (the C++ multi-device host, both shards on device 0), two ranks
 # sharing device 0 under the launcher (gloo transport) on the configs[3] split, one-rank RCCL
