@@ -6,6 +6,9 @@ tag=${1:-r02}; quick=$2
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q --timeout 900 --durations=8 -s > gpurun_out/gpu_tests_$tag.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/gpu_tests_$tag.log
+# the multi-device tests' bodies, every shard on device 0 (a dry run of the test file on a one-GPU box, not a measurement)
+echo "== PHD_TEST_SHARE_DEVICE=1 python -m pytest tests/test_gpu_multi_devices.py -m gpu -q" >> gpurun_out/gpu_tests_$tag.log
+PHD_TEST_SHARE_DEVICE=1 python -m pytest tests/test_gpu_multi_devices.py -m gpu -q --timeout 900 2>&1 | tail -2 >> gpurun_out/gpu_tests_$tag.log
 grep -E "sampled particles|passed|failed|error" gpurun_out/gpu_tests_$tag.log | tail -12
 python __graft_entry__.py smoke 2>&1 | tail -1
 # the PMC passes first: bench.py prints `roofline.traffic` / `roofline_valu` only from counters recorded with THIS build
