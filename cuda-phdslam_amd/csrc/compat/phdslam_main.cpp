@@ -6,7 +6,7 @@
 // resident on the device, and writes state_estimate%05d.log (README:31-39 5-line format, or HEAD's
 // 7-line writeLog with --log7) and loopTime.log.
 //
-//   phdslam <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--devices N [--shards S]]
+//   phdslam <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--device-noise] [--devices N [--shards S]]
 //
 // --devices N: ONE filter sharded over N GPUs of this process (include/phdslam_multi.h: one shard and one stream per
 // device, RCCL all-gather of the log-weights, global resample, particle migration over xGMI).  --shards S > N puts several
@@ -39,17 +39,23 @@ int main(int argc, char** argv)
 {
     setvbuf(stdout, nullptr, _IOLBF, 0); // per-step progress lines reach a pipe as they are printed
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--devices N [--shards S]]\n", argv[0]);
+        fprintf(stderr, "usage: %s <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--device-noise] [--devices N [--shards S]]\n", argv[0]);
         return 2;
     }
     std::string out_dir = ".";
     uint64_t seed = 1;
     int capacity = 0, max_steps = -1, n_devices = 0, n_shards = 0;
     bool log7 = false;
+    // --device-noise: the control noise of the vehicle predict is drawn on the device (counter-based generator seeded with
+    // --seed, one draw per predicted particle by its global index) instead of 2 N randn() calls on the host per step as the
+    // reference does (src/phdfilter.cu:1147-1152) — a quarter of the loop time at 4096 particles.  Another random stream,
+    // the same distribution (the reference's own stream is seeded from the wall clock: there is nothing to reproduce).
+    bool device_noise = false;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "synth")) continue;
         if (!strcmp(argv[i], "disparity")) { fprintf(stderr, "the disparity pipeline is out of scope\n"); return 2; }
         if (!strcmp(argv[i], "--log7")) log7 = true;
+        else if (!strcmp(argv[i], "--device-noise")) device_noise = true;
         else if (i + 1 < argc && !strcmp(argv[i], "--out")) out_dir = argv[++i];
         else if (i + 1 < argc && !strcmp(argv[i], "--seed")) seed = strtoull(argv[++i], nullptr, 10);
         else if (i + 1 < argc && !strcmp(argv[i], "--capacity")) capacity = atoi(argv[++i]);
@@ -122,6 +128,7 @@ int main(int argc, char** argv)
         mo.max_measurements = max_m < PHD_MAX_MEASUREMENTS ? max_m : PHD_MAX_MEASUREMENTS;
         phd_multi* m = nullptr;
         CHK(phd_multi_create(&config, &mo, &m));
+        if (device_noise) CHK(phd_multi_seed(m, seed));
         const int N0 = config.n_particles;
         // particle shotgun (n_predict_particles = k, src/phdfilter.cu:1185-1238): the set grows k-fold per predict, up to 5 n k
         const int kshot_m = config.nPredictParticles > 1 ? config.nPredictParticles : 1;
@@ -167,12 +174,12 @@ int main(int argc, char** argv)
                 for (int s = 0; s < sub; ++s) {
                     const int n_pred = phd_multi_n_particles_now(m) * kshot_m;               // one draw per PREDICTED particle
                     if ((size_t)n_pred > N_max) { fprintf(stderr, "particle count would exceed 5 n_particles n_predict_particles\n"); return 1; }
-                    for (int i = 0; i < n_pred; ++i) {                                       // phdfilter.cu:1147-1152
+                    for (int i = 0; i < n_pred && !device_noise; ++i) {                      // phdfilter.cu:1147-1152
                         noise[i].n_alpha = (float)(config.stdAlpha * randn());
                         noise[i].n_encoder = (float)(config.stdEncoder * randn());
                     }
                     const bool last = s == sub - 1;
-                    CHK(phd_multi_update(m, &current_control, noise.data(), last ? Z : nullptr, last ? M : 0));
+                    CHK(phd_multi_update(m, &current_control, device_noise ? nullptr : noise.data(), last ? Z : nullptr, last ? M : 0));
                 }
             } else {
                 CHK(phd_multi_update(m, nullptr, nullptr, Z, M));                            // step 0: the scan alone
@@ -215,6 +222,7 @@ int main(int argc, char** argv)
     opt.max_measurements = max_m < PHD_MAX_MEASUREMENTS ? max_m : PHD_MAX_MEASUREMENTS;
     phd_filter* f = nullptr;
     CHK(phd_create(&config, &opt, &f));   // particles start at the configured pose, weights -log N (:1130-1145)
+    if (device_noise) CHK(phd_seed(f, seed));
     const int kshot = config.nPredictParticles > 1 ? config.nPredictParticles : 1;
     const int n_max = config.n_particles * (kshot > 1 ? 5 * kshot : 1);
 
@@ -346,11 +354,11 @@ int main(int argc, char** argv)
         } else if (n > 0 && do_predict) {                                                    // no motion at step 0 (:1244)
             for (int s = 0; s < (config.subdividePredict > 0 ? config.subdividePredict : 1); ++s) {
                 n_cur = phd_n_particles(f);
-                for (int i = 0; i < n_cur * kshot; ++i) {                                    // phdfilter.cu:1147-1152
+                for (int i = 0; i < n_cur * kshot && !device_noise; ++i) {                   // phdfilter.cu:1147-1152
                     noise[i].n_alpha = (float)(config.stdAlpha * randn());
                     noise[i].n_encoder = (float)(config.stdEncoder * randn());
                 }
-                CHK(phd_predict_ackerman(f, current_control, noise.data()));
+                CHK(phd_predict_ackerman(f, current_control, device_noise ? nullptr : noise.data()));
             }
         }
         if (config.savePrediction) {
