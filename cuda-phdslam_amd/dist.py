@@ -181,7 +181,9 @@ class ShardedFilter:
     def resample(self, uniform, all_raw_logw=None):
         """global systematic resample + migration.  Returns the global parent indices.
         all_raw_logw: the gathered UN-normalised weights — normalisation and indices then come from one launch
-        (forced resample; skip normalize())"""
+        (forced resample; skip normalize()).  Without it the indices come from what normalize() left on every rank:
+        call normalize() after the last change of the weights (the C++ host, csrc/phd_multi.cpp, gathers the current weights
+        itself when no normalisation precedes)"""
         if self.gathered():
             return self.resample_gathered(uniform, all_raw_logw is not None, want_idx=True)
         if self.collectives and hasattr(self.b, "resample_begin"):
