@@ -379,6 +379,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
                    "particles_total": N, "gaussians_per_particle": G, "measurements_per_step": M,
                    "one_launch_per_step": bool(one_launch_per_step),
                    "max_survivors": st["max_survivors"], "max_map": st["max_map"],
+                   "update_residency": f.residency(),
                    "steps_per_s_unforced_resample": unforced},
         "stages_us_per_workgroup": stages,
         "roofline": roof,

@@ -151,6 +151,7 @@ SYMBOLS = {
     "phd_debug_get_survivors": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "phd_debug_get_weight_increments": (_i, [_vp, _vp]),
     "phd_device_status": (_i, [_vp, _vp, _vp, _vp]),
+    "phd_update_residency": (_i, [_vp, _vp, _vp]),
     "phd_config_defaults": (_i, [_cfgp]),
     "phd_config_load": (_i, [C.c_char_p, _cfgp, C.c_char_p, _sz, _vp]),
     "phd_load_measurements": (_i, [C.c_char_p, _i, _vp, _sz, _vp, _sz, _vp, _vp]),

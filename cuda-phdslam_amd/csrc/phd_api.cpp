@@ -699,6 +699,15 @@ static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms,
 static int interpret_report(phd_filter* f, const unsigned raw[8], phd_step_report* out);
 static void commit_weights(phd_filter* f, int mode, int free_pose);
 
+#ifdef PHD_EXP_TRACE
+static unsigned long long* g_exp_trace = nullptr;
+extern "C" int phd_exp_trace_read(unsigned long long* out, int n_rows)
+{
+    if (!g_exp_trace) return -1;
+    hipDeviceSynchronize();
+    return hipMemcpy(out, g_exp_trace, sizeof(unsigned long long) * 8 * n_rows, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, const FusedPredict* fp = nullptr,
                            const FusedWeights* fw = nullptr)
 {
@@ -770,6 +779,14 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
         build_weight_args(f, fw->mode, nullptr, 1, fw->u0, a.wa, free_pose);
         a.fuse_weights = 1;
         a.ticket = f->ticket;
+#ifdef PHD_EXP_TRACE
+        {
+            static unsigned long long* g_trace = nullptr;
+            if (!g_trace) hipMalloc(&g_trace, sizeof(unsigned long long) * 8 * 70000);
+            a.trace = g_trace;
+            g_exp_trace = g_trace;
+        }
+#endif
     }
     t_begin(f, PHD_K_UPDATE_MERGE);
     HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream));
@@ -851,6 +868,20 @@ static bool can_fuse(const phd_filter* f)
 {
     return f->fuse_enabled && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
            (size_t)f->n * 8 <= f->lds_bytes;
+}
+
+extern "C" int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_out, uint64_t* lds_bytes_out)
+{
+    CHECK_F(f);
+    HIPCHK(hipSetDevice(f->device));
+    UpdateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cphd = f->cphd ? 1 : 0;
+    a.spill_rec = f->spill_rec;
+    a.fuse_weights = can_fuse(f) ? 1 : 0;
+    if (workgroups_per_cu_out) *workgroups_per_cu_out = update_workgroups_per_cu(a, f->lds_bytes, f->n);
+    if (lds_bytes_out) *lds_bytes_out = f->lds_bytes;
+    return PHD_OK;
 }
 
 extern "C" int phd_update_dev(phd_filter* f, const phd_measurement* d_z, int n_meas)

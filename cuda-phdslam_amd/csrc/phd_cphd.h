@@ -34,10 +34,12 @@ namespace phd {
 struct CphdLds {
     lds_f32 cnq, cnp, lfact, lxi, I0, I1, lD, efull, cnb, scal;
     lds_i32 kp;       // f64 sweeps: the block exponent of the parked row P_m
+    lds_f32 zscr;     // 32 MM bytes: what the block calls L.zpart (the kernel points L.zpart here: pass 1's partial sums, then the
+                      // block's rows of doubles — the common layout keeps only max(MM, 32) floats for the sums, phd_lds.h)
 };
 enum { CQ_LY0 = 0, CQ_LY1 = 1, CQ_R1 = 2 };
 
-__host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 off[11])
+__host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 off[12])
 {
     const u32 cn = align16u(4u * (u32)cn_len);
     const u32 lf = align16u(4u * (u32)((cn_len > MM + 1 ? cn_len : MM + 1) + 1));
@@ -54,13 +56,14 @@ __host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 
     off[8] = p; p += mm;  // cnb
     off[9] = p; p += 64u; // scal
     off[10] = p; p += mm; // kp
+    off[11] = p; p += align16u(32u * (u32)MM); // zscr
     return p;
 }
 
 
 __device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
 {
-    u32 off[11];
+    u32 off[12];
     cphd_lds_layout(cn_len, MM, off);
     CphdLds Q;
     Q.cnq = (lds_f32)(base + off[0]); Q.cnp = (lds_f32)(base + off[1]); Q.lfact = (lds_f32)(base + off[2]);
@@ -68,6 +71,7 @@ __device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
     Q.lD = (lds_f32)(base + off[6]); Q.efull = (lds_f32)(base + off[7]); Q.cnb = (lds_f32)(base + off[8]);
     Q.scal = (lds_f32)(base + off[9]);
     Q.kp = (lds_i32)(base + off[10]);
+    Q.zscr = (lds_f32)(base + off[11]);
     return Q;
 }
 

@@ -95,6 +95,9 @@ struct UpdateArgs {
     // fused weights / resample tail (small particle counts): run by the last workgroup to finish
     int fuse_weights;
     unsigned* ticket;
+#ifdef PHD_EXP_TRACE
+    unsigned long long* trace;  // experiment: [grid][8] (start, end, HW_ID, hand-off, pass 2 + barrier, merge, pass 2) in 100 MHz ticks
+#endif
     WeightArgs wa;
     unsigned* status;
     int* max_surv;
@@ -126,6 +129,7 @@ hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, c
 int update_fuse_max_particles();
 
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
+int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, int n_particles);   // what the runtime says a CU holds (-1: query failed)
 #define PHD_MAX_PEERS 16        // shards whose memory one pull kernel can read (phd_global_resample_pull)
 hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank, float* dst,
                                 int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,

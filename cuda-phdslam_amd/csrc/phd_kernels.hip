@@ -38,6 +38,7 @@
 
 #include <mutex>
 #include <set>
+#include <atomic>
 
 #include "phd_defs.h"
 #include "phd_lane.h"
@@ -49,7 +50,11 @@
 #include "phd_predict.h"
 #include "phd_cphd.h"
 #include "phd_weights.h"
-#ifndef PHD_CPHD_TU
+// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU compile the kernel template and one table of instantiations each)
+#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU)
+#define PHD_PART_TU 1
+#endif
+#ifndef PHD_PART_TU
 #include "phd_spill.h"      // (phd_merge_spill_kernel: a plain __global__ function, defined once)
 #endif
 
@@ -61,16 +66,16 @@ namespace phd {
 #ifndef PHD_LDS_PAD
 #define PHD_LDS_PAD 0
 #endif
-#ifndef PHD_CPHD_TU
+#ifndef PHD_PART_TU
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total + PHD_LDS_PAD; }
 int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
 size_t cphd_lds_bytes(int cn_len, int MM)
 {
-    u32 off[11];
+    u32 off[12];
     return cphd_lds_layout(cn_len, MM, off);
 }
 
-#endif // !PHD_CPHD_TU
+#endif // !PHD_PART_TU
 
 // the last step of a particle's hand-off to the weights workgroup of the fused step: its hand-off stores (pose, indirection
 // reset, log-weight increment — relaxed agent-scope atomics by the same thread, i.e. sc1 write-through stores) must be
@@ -98,16 +103,31 @@ __device__ __forceinline__ void handoff_ticket(unsigned* ticket)
 // ------------------------------------------------------------------------------------------
 // SPILL: the instantiation of filters created with a spill list (survivor_capacity > 2048); without it the spill branches
 // fold away (they cost 0.3 us of the 17.5 us step at 256 x 64 x 32 when merely present)
-template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL>
-__global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(UpdateArgs A)
+// MINW: waves per SIMD the register allocation must allow.  4 = two workgroups per CU (<= 128 VGPRs, what the code wants: 107);
+// 6 = three (<= 80 VGPRs: ~50 registers live in scratch — measured 1.7 % slower at equal residency, 22 % faster when LDS lets the
+// third workgroup in, profiles/r04_three_workgroups.txt).  launch_update_merge picks by the filter's LDS size.
+template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL, int MINW = PHD_MIN_WAVES>
+__global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const Lds L = lds_carve((lds_u8)lds_raw, A.S_cap, A.cap, A.MM);
+    Lds L = lds_carve((lds_u8)lds_raw, A.S_cap, A.cap, A.MM);
     // CPHD instantiation: its arrays follow the common layout
     const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(A.S_cap, A.cap, A.MM).total, A.cn_len, A.MM) : CphdLds();
+    if (CPHD) L.zpart = Q.zscr;   // the block parks rows of cn_len doubles where pass 1 leaves its partial sums: a scratch of its own
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: uniform, kept in an SGPR
+#ifdef PHD_EXP_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#define PHD_TRACE_END() do { if (A.trace && tid == 0) { A.trace[8 * blockIdx.x] = tr_t0; A.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); \
+        A.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } while (0)
+#define PHD_TRACE_AT(k) do { if (A.trace && tid == 0) A.trace[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PHD_TRACE_HANDOFF() do { if (A.trace) A.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PHD_TRACE_END() do {} while (0)
+#define PHD_TRACE_HANDOFF() do {} while (0)
+#define PHD_TRACE_AT(k) do {} while (0)
+#endif
     if (FUSEW && blockIdx.x == gridDim.x - 1) {
         // ---- fused step: the weights / nEff / resample routine has a workgroup of its own (the grid is N + 1).
         // It needs the particles' log-weight increments, predicted poses and map indirection — all known once a
@@ -140,6 +160,9 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         }
         __syncthreads();
         if (!s_tail_ok) return;
+        // everything the routine needs is there: from here on it is the step's critical path whenever the last particles hand over
+        // late (it shares its CU with up to three particle workgroups, which have the rest of their merge to hide behind it)
+        __builtin_amdgcn_s_setprio(3);
         // the instantiation launch_weights runs for this particle count (one table — 256 threads up to 512 particles, 512 up to 4096: the
         // reduction trees, hence the bits of the log-sum-exp and of nEff, are a function of the block size), so
         // phd_step_dev and the staged calls agree bit for bit.  Up to 512 particles that is four waves; the other
@@ -154,6 +177,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         } else {
             weights_body<PHD_T, 8, true>(A.wa, lds_raw);                 // up to 4096
         }
+        PHD_TRACE_END();
         return;
     }
     const int p = blockIdx.x;
@@ -211,24 +235,14 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         if (FUSEW && A.parent_reset) __hip_atomic_store(&A.parent_reset[p], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- birth geometry (host loop src/phdfilter.cu:3470-3506): depends only on the pose and the
-    //      measurement, so the top lanes of the workgroup — idle while the low lanes classify the map —
-    //      compute it now; the birth weights follow once the normalisers are known
-    for (int m = PHD_T - 1 - tid; m < M; m += PHD_T) {
-        const float zr = L.z_r[m];
-        const float theta = pose.ptheta + L.z_b[m];
-        float sn, cs;
-        sincosf(theta, &sn, &cs);
-        const float dx = zr * cs, dy = zr * sn;
-        const float J0 = dx / zr, J1 = dy / zr, J2 = -dy, J3 = dx;
-        const float sr = cfg.stdRange * cfg.birthNoiseFactor, sb = cfg.stdBearing * cfg.birthNoiseFactor;
-        const float vr = sr * sr, vb = sb * sb;
-        L.bgeo[0 * A.MM + m] = pose.px + dx;
-        L.bgeo[1 * A.MM + m] = pose.py + dy;
-        L.bgeo[2 * A.MM + m] = J0 * J0 * vr + J2 * J2 * vb;
-        L.bgeo[3 * A.MM + m] = J0 * J1 * vr + J2 * J3 * vb;
-        L.bgeo[4 * A.MM + m] = J1 * J1 * vr + J3 * J3 * vb;
-    }
+    // ---- birth geometry (host loop src/phdfilter.cu:3470-3506): depends only on the pose and the measurement; thread m
+    //      computes measurement m's now (M <= 256 < PHD_T: one each) and keeps the five numbers in registers until the
+    //      normalisers are known — the lanes are idle here anyway, and LDS has no room for them (phd_lds.h)
+    float bg_mx = 0.f, bg_my = 0.f, bg_xx = 0.f, bg_xy = 0.f, bg_yy = 0.f;
+    static_assert(PHD_MAX_MEASUREMENTS <= PHD_T, "one birth per thread");
+#ifndef PHD_EXP_BG_LATE
+    if (tid < M) birth_geometry(pose, L.z_r[tid], L.z_b[tid], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
+#endif
 
     // ---- classification + per-feature EKF terms -----------------------------------------------
     float pdw_local = 0.f; // sum_j pd_j w_j (cardinality_predict, :2160)
@@ -269,15 +283,8 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                 L.f_a[j] = (v4f){t.r, t.b, t.s00, t.s12};
                 L.f_c[j] = (v2f){t.s11, lw0 - safe_log(6.2831855f) - 0.5f * safe_log(t.det)};
                 L.f_idx[j] = (u16)i;
-                {
-                    // gain and Joseph covariance do not depend on the measurement (src/phdfilter.cu:1884-1901):
-                    // once per feature here, not once per surviving detection term in the finalise pass
-                    float oxx, oxy, oyy;
-                    joseph_cov(t, pxx, pxy, pyy, cfg, oxx, oxy, oyy);
-                    L.f_k[j] = (v4f){t.K0, t.K1, t.K2, t.K3};
-                    L.f_p[j] = (v4f){oxx, oxy, oyy, mx};
-                    L.f_my[j] = my;
-                }
+                // (gain and Joseph covariance, src/phdfilter.cu:1884-1901, are rebuilt for the detection terms that survive
+                //  the prune — detection_posterior() — instead of being kept for every feature: 36 B of LDS per feature)
                 pdw_local += t.pd * w;
                 nd_j = j;
             } else if (cls == 0) {
@@ -331,10 +338,11 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     __syncthreads();
     if (STAMPS && tid == 0) st[24] = __builtin_amdgcn_s_memrealtime();
     float lz_local = 0.f;
+    float dl_phd = 0.f;     // the particle's log-weight increment (PHD), every thread the same; handed over after pass 2
     if (CPHD) {
         // roots Xi_m = (lambda/kappa)(sum_j pd w_j g_jm + birthWeight) (.bak:1205-1222)
         const float rat = cfg.clutterRate / cfg.clutterDensity;
-        for (int m = tid; m < M; m += PHD_T) Q.lxi[m] = (pass1_feature_sum(L, p1g, m, A.MM) + cfg.birthWeight) * rat;
+        for (int m = tid; m < M; m += PHD_T) Q.lxi[m] = (pass1_feature_sum(L, p1g, m, M) + cfg.birthWeight) * rat;
         const float pdw = block_sum(pdw_local, L.red, tid);
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
@@ -349,8 +357,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const float wb = (mv && L.zok[mv ? m : 0]) ? expf(safe_log(cfg.birthWeight) - L.logZ[mv ? m : 0]) : 0.f;
             const bool keep = mv && !(wb < cfg.minFeatureWeight);
             const int slot = alloc_slots(keep, L.ctr);
-            if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
-                                     L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp, bm);
+#ifdef PHD_EXP_BG_LATE
+            if (keep) birth_geometry(pose, L.z_r[m], L.z_b[m], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
+#endif
+            if (keep) store_survivor(L, slot, S_cap, wb, bg_mx, bg_my, bg_xx, bg_xy, bg_yy, n_in + M * n_in + m, sp, bm);   // (m = tid)
         }
         // missed detections of the in-range features: w (1 - pd) r1 (.bak:1445-1460)
         for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
@@ -373,18 +383,10 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (kv) store_survivor(L, slot, S_cap, in[0 * cap + i] * r1, in[1 * cap + i], in[2 * cap + i], in[3 * cap + i],
                                    in[4 * cap + i], in[5 * cap + i], NEAR_U_BASE + i, sp, bm);
         }
-        if (tid == 0) {
-            if (FUSEW) { // as in the PHD branch below: the last hand-off store, then the ticket
-                __hip_atomic_store(&A.dlogw[p], Q.scal[CQ_LY0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                handoff_ticket(A.ticket);
-            } else {
-                A.dlogw[p] = Q.scal[CQ_LY0];                                                         // .bak:2661-2667
-                if (A.raw_out) A.raw_out[p] = A.logw_in[p] + Q.scal[CQ_LY0];
-            }
-        }
+        // (the particle's log-weight increment, log <Y0,p>, .bak:2661-2667, is handed over after pass 2 — see there)
     } else {
     for (int m = tid; m < M; m += PHD_T) {
-        float sum = pass1_feature_sum(L, p1g, m, A.MM);
+        float sum = pass1_feature_sum(L, p1g, m, M);
         sum += cfg.clutterDensity;                                                                    // :2213
         sum += cfg.birthWeight;                                                                       // :2214
         const float lz = safe_log(sum);                                                               // :2217
@@ -394,22 +396,16 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         const float wb = L.zok[m] ? expf(safe_log(cfg.birthWeight) - lz) : 0.f;
         const bool keep = !(wb < cfg.minFeatureWeight);
         const int slot = alloc_slots(keep, L.ctr);
-        if (keep) store_survivor(L, slot, S_cap, wb, L.bgeo[0 * A.MM + m], L.bgeo[1 * A.MM + m], L.bgeo[2 * A.MM + m],
-                                 L.bgeo[3 * A.MM + m], L.bgeo[4 * A.MM + m], n_in + M * n_in + m, sp, bm);
+#ifdef PHD_EXP_BG_LATE
+        if (keep) birth_geometry(pose, L.z_r[m], L.z_b[m], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
+#endif
+        if (keep) store_survivor(L, slot, S_cap, wb, bg_mx, bg_my, bg_xx, bg_xy, bg_yy, n_in + M * n_in + m, sp, bm);       // (m = tid)
     }
     {
         float lz_sum, pdw;
         block_sum2(lz_local, pdw_local, L.red, tid, lz_sum, pdw, /*scratch_idle=*/true); // the only reduction of the PHD path
         // particle_weighting == 0 (:2260-2263): sum_m log Z_m - (sum_j pd_j w_j + M * birthWeight)
-        if (tid == 0) {
-            const float dl = lz_sum - (pdw + (float)M * cfg.birthWeight);
-            if (FUSEW) {
-                // the last of this particle's hand-off stores (pose: at the top; indirection: after the first barrier)
-                __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                handoff_ticket(A.ticket);
-            } else A.dlogw[p] = dl;
-            if (!FUSEW && A.raw_out) A.raw_out[p] = A.logw_in[p] + dl;                                // :3741-3744
-        }
+        dl_phd = lz_sum - (pdw + (float)M * cfg.birthWeight);
     }
     } // !CPHD
     // PHD: everything pass 2 reads (log Z_m, the candidate list and its counts) was published by the barriers above
@@ -438,20 +434,18 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             const bool keep = tv && !(w < cfg.minFeatureWeight);                                      // :2314
             const int slot = alloc_slots(keep, L.ctr);
             if (keep) {
+                // the complete survivor at once (two thirds of the listed terms survive: a separate finalise pass would
+                // fetch the same feature terms again, behind one more barrier)
+                float umx, umy, uxx, uxy, uyy;
+                detection_posterior(in, cap, L.f_idx[j], pose, cfg, i0, i1, umx, umy, uxx, uxy, uyy);
                 if (slot < S_cap) {
-                    // the complete survivor at once (two thirds of the listed terms survive: a separate finalise pass would
-                    // fetch the same feature terms again, behind one more barrier)
-                    const v4f K = L.f_k[j], Pn = L.f_p[j];
                     L.w[slot] = w; L.u[slot] = n_in + m * n_in + j;
-                    L.mx[slot] = Pn.w + K.x * i0 + K.z * i1;                                          // :1903-1904
-                    L.my[slot] = L.f_my[j] + K.y * i0 + K.w * i1;
-                    L.xx[slot] = Pn.x; L.xy[slot] = Pn.y; L.yy[slot] = Pn.z;
+                    L.mx[slot] = umx; L.my[slot] = umy;
+                    L.xx[slot] = uxx; L.xy[slot] = uxy; L.yy[slot] = uyy;
                     __hip_atomic_fetch_add((LDS_T(u32)*)L.tr + bucket_of(bm, w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 else {   // past the LDS capacity: the complete record goes to the spill list (no finalise pass there)
-                    const v4f K = L.f_k[j], Pn = L.f_p[j];
-                    spill_store(sp, L, slot, w, Pn.w + K.x * i0 + K.z * i1, L.f_my[j] + K.y * i0 + K.w * i1, Pn.x, Pn.y, Pn.z,
-                                n_in + m * n_in + j);
+                    spill_store(sp, L, slot, w, umx, umy, uxx, uxy, uyy, n_in + m * n_in + j);
                 }
             }
         }
@@ -481,14 +475,32 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
                     __hip_atomic_fetch_add((LDS_T(u32)*)L.tr + bucket_of(bm, w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 else {
-                    const v4f K = L.f_k[jj], Pn = L.f_p[jj];
-                    spill_store(sp, L, slot, w, Pn.w + K.x * i0 + K.z * i1, L.f_my[jj] + K.y * i0 + K.w * i1, Pn.x, Pn.y, Pn.z,
-                                n_in + m * n_in + j);
+                    float umx, umy, uxx, uxy, uyy;
+                    detection_posterior(in, cap, L.f_idx[jj], pose, cfg, i0, i1, umx, umy, uxx, uxy, uyy);
+                    spill_store(sp, L, slot, w, umx, umy, uxx, uxy, uyy, n_in + m * n_in + j);
                 }
             }
         }
     }
+    // ---- the particle's log-weight increment, and (fused step) the hand-off to the weights workgroup.  Known since pass 1, stored
+    //      only now: vector-memory operations complete IN ORDER for a wave's counter, so a store or the ticket's atomic issued
+    //      before pass 2 makes this wave's loads of the prior features (detection_posterior) wait for the store's round trip to
+    //      memory — 1 to 2.5 us depending on the XCD, with seven waves waiting at the barrier (measured with workgroup time
+    //      stamps, profiles/r04_three_workgroups.txt).  After pass 2 nothing of this wave follows the ticket until the tail.
+    if (tid == 0) {
+        const float dl = CPHD ? Q.scal[CQ_LY0] : dl_phd;
+        if (FUSEW) {
+            // the last of this particle's hand-off stores (pose: at the top; indirection: after the first barrier)
+            __hip_atomic_store(&A.dlogw[p], dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            handoff_ticket(A.ticket);
+            PHD_TRACE_HANDOFF();
+        } else {
+            A.dlogw[p] = dl;
+            if (A.raw_out) A.raw_out[p] = A.logw_in[p] + dl;                                          // :3741-3744
+        }
+    }
     STAMP(4);
+    PHD_TRACE_AT(6);
     const bool finalised = sparse2 && n_cand <= PHD_CAND_CAP;     // (uniform) the listed pass stored complete survivors
     if (!finalised) __syncthreads();
     if (!finalised) {
@@ -501,16 +513,18 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
             if (u < u_det_lo || u >= u_det_hi) continue;
             const int m = (u - n_in) / n_in;
             const int j = (u - n_in) - m * n_in;
-            const v4f fa = L.f_a[j], K = L.f_k[j], Pn = L.f_p[j];
+            const v4f fa = L.f_a[j];
             const float i0 = L.z_r[m] - fa.x;
             const float i1 = wrap_angle(L.z_b[m] - fa.y);
-            L.mx[s] = Pn.w + K.x * i0 + K.z * i1;                                                    // :1903-1904
-            L.my[s] = L.f_my[j] + K.y * i0 + K.w * i1;
-            L.xx[s] = Pn.x; L.xy[s] = Pn.y; L.yy[s] = Pn.z;
+            float umx, umy, uxx, uxy, uyy;
+            detection_posterior(in, cap, L.f_idx[j], pose, cfg, i0, i1, umx, umy, uxx, uxy, uyy);
+            L.mx[s] = umx; L.my[s] = umy;
+            L.xx[s] = uxx; L.xy[s] = uxy; L.yy[s] = uyy;
         }
     }
     __syncthreads();
     STAMP(5);
+    PHD_TRACE_AT(4);
     int n_surv = L.ctr[CTR_NSURV];
     unsigned status = 0;
     // more survivors than LDS holds: with a spill list (and room in it) the particle's merge is handed to
@@ -585,6 +599,7 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
     const bool packed = (n_update + n_map <= 0xFFFF) && (S_cap <= 0x10000);
     if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
     else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
+    PHD_TRACE_AT(5);
     int k_out = L.ctr[CTR_KOUT];
     if (k_out > cap) { k_out = cap; status |= PHD_STATUS_MAP_OVERFLOW; }
     // append the untouched out-of-range features (src/phdfilter.cu:3311-3318)
@@ -617,17 +632,24 @@ __global__ __launch_bounds__(PHD_T, PHD_MIN_WAVES) void phd_update_merge_kernel(
         if (hm > __hip_atomic_load(A.max_map, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(A.max_map, hm);
     }
     STAMP(11);
+    PHD_TRACE_END();
     if (STAMPS && CPHD && tid == 0) { // the CPHD block's parts replace the merge-round statistics
         st[12] = cq[1] - cq[0]; st[13] = cq[2] - cq[1]; st[14] = cq[3] - cq[2]; st[15] = cq[4] - cq[3];
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Two translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel are compiled on their
-// own with -DPHD_CPHD_TU — the kernel template above, this table and nothing else — so that the two halves build side by side
-// and the CPHD half can take compile flags of its own (csrc/Makefile, KFLAGS_CPHD: measured, currently the same).
+// Three translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
+// three-workgroups-per-CU ones are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU — the kernel template above, one of
+// these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
+// (csrc/Makefile, KFLAGS_CPHD: measured, currently the same).
 // ------------------------------------------------------------------------------------------
-#ifdef PHD_CPHD_TU
+#if defined(PHD_W6_TU)
+// <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
+extern const void* const k_update_w6_fns[3] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
+                                               (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6>};
+#elif defined(PHD_CPHD_TU)
 // <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
 extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
                                                  (const void*)phd_update_merge_kernel<true, false, true, false>,
@@ -636,6 +658,7 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
                                                  (const void*)phd_update_merge_kernel<false, true, true, true>};
 #else
 extern const void* const k_update_cphd_fns[5];
+extern const void* const k_update_w6_fns[3];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
@@ -972,14 +995,15 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-static const void* const k_update_fns[10] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
+static const void* const k_update_fns[13] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
                                              k_update_cphd_fns[0], k_update_cphd_fns[1], k_update_cphd_fns[2],
                                              (const void*)phd_update_merge_kernel<false, false, false, true>,
                                              (const void*)phd_update_merge_kernel<false, true, false, true>,
-                                             k_update_cphd_fns[3], k_update_cphd_fns[4]};
-#define PHD_N_UPDATE_FNS 10
+                                             k_update_cphd_fns[3], k_update_cphd_fns[4],
+                                             k_update_w6_fns[0], k_update_w6_fns[1], k_update_w6_fns[2]};
+#define PHD_N_UPDATE_FNS 13
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1013,6 +1037,33 @@ size_t update_static_lds_bytes()
     return mx;
 }
 
+// index into k_update_fns: <STAMPS, FUSEW, CPHD, SPILL>, and the three-per-CU instantiations when three of this filter's
+// workgroups fit the CU's LDS (the update's 608 B of static arrays included)
+// compute units of the current device (cached per ordinal)
+static int device_cu_count()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+static int update_fn_index(const UpdateArgs& a, size_t lds_bytes, int n_particles)
+{
+    const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
+    const bool fused = a.fuse_weights && !a.stamps;
+    // the 80-register build pays ~2 % (and more on the critical path of a lone workgroup) for the right to a third resident
+    // workgroup: only where LDS admits three AND the launch has more than two workgroups per CU to place
+    const bool three = !a.cphd && !sp && 3 * (lds_bytes + 1024) <= 160 * 1024 && n_particles > 2 * device_cu_count();
+    if (three) return a.stamps ? 11 : fused ? 12 : 10;
+    return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
+}
+
 hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st)
 {
     // function attributes are per device: set once for every device this process launches on (thread-safe: filters on
@@ -1031,14 +1082,20 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         });
         if (e != hipSuccess) return e;
     }
-    const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
     const bool fused = a.fuse_weights && !a.stamps;
-    // index into k_update_fns: <STAMPS, FUSEW, CPHD, SPILL>
-    const int fn = a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
+    const int fn = update_fn_index(a, lds_bytes, n_particles);
     const dim3 grid(n_particles + (fused ? 1 : 0)), b(PHD_T);      // + the weights workgroup of the fused step
     UpdateArgs args = a;
     void* argv[] = {(void*)&args};
     return hipLaunchKernel(k_update_fns[fn], grid, b, argv, lds_bytes, st);
+}
+
+// workgroups of the update kernel a CU holds at a time for this filter (the runtime's own count: LDS, registers, waves)
+int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, int n_particles)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_update_fns[update_fn_index(a, lds_bytes, n_particles)], PHD_T, lds_bytes) != hipSuccess) return -1;
+    return n;
 }
 
 hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st)
@@ -1249,5 +1306,5 @@ hipError_t launch_iota(int* a, int n, hipStream_t st)
     return hipGetLastError();
 }
 
-#endif // !PHD_CPHD_TU
+#endif // !PHD_PART_TU
 } // namespace phd

@@ -4,6 +4,7 @@
 #include "phd_defs.h"
 #include "phd_lane.h"
 #include "phd_math.h"
+#include "phd_lds_layout.h"
 
 namespace phd {
 
@@ -19,55 +20,6 @@ typedef LDS_T(u32)* lds_u32;
 typedef LDS_T(u16)* lds_u16;
 typedef LDS_T(unsigned char)* lds_u8;
 
-// merge rounds: window copy (pos[64] | gA[64] | gB[64]) + the round's seed records (2 x 72 float4), behind the sort arrays
-#define PHD_RWIN_BYTES (4u * 64u + 2u * 16u * 64u + 2u * 16u * 72u)
-
-struct LdsOffsets {
-    u32 w, mx, my, xx, xy, yy, tr, u;
-    u32 alias;      // start of the aliased region
-    u32 cinfo;      // (inside it) the merge's per-cluster seed records, behind both the rounds' working set and the sums
-    u32 out_idx, z_r, z_b, logZ, zpart, zok, bgeo, part, win, red, ctr;
-    u32 total;
-};
-
-__host__ __device__ __forceinline__ u32 align16u(u32 x) { return (x + 15u) & ~15u; }
-
-__host__ __device__ __forceinline__ LdsOffsets lds_offsets(int S, int C, int MM)
-{
-    LdsOffsets o;
-    u32 p = 0;
-    const u32 sv = align16u(4u * (u32)S);
-    o.w = p; p += sv; o.mx = p; p += sv; o.my = p; p += sv; o.xx = p; p += sv;
-    o.xy = p; p += sv; o.yy = p; p += sv; o.tr = p; p += sv; o.u = p; p += sv;
-    o.alias = p;
-    const u32 feat = align16u(16u * (u32)C) + align16u(8u * (u32)C) + align16u(2u * (u32)C) + 2u * align16u(16u * (u32)C) +
-                     align16u(4u * (u32)C);
-    const u32 sort1 = 3u * sv + PHD_RWIN_BYTES;   // sort arrays / round lists + the rounds' window and seed records
-    // the exact moment sums of the round-based merge (phd_fixsum.h): 48 B of accumulators per output cluster (<= C) from the
-    // start of the region once the rounds are over, and 16 B per cluster of seed records written DURING the rounds — behind both
-    const u32 sums = 48u * (u32)C;
-    o.cinfo = o.alias + (sort1 > sums ? sort1 : sums);
-    u32 amax = feat > sort1 ? feat : sort1;
-    const u32 msum = (o.cinfo - o.alias) + 16u * (u32)C;
-    amax = amax > msum ? amax : msum;
-    const u32 small = 2u * PHD_SMALL_S * 32u + 64u + 2u * PHD_SMALL_S * 16u; // merge_small(): rows, member columns, seeds, staged planes
-    amax = amax > small ? amax : small;
-    p += amax;
-    o.out_idx = p; p += align16u(2u * (u32)C);
-    o.z_r = p; p += align16u(4u * (u32)MM);
-    o.z_b = p; p += align16u(4u * (u32)MM);
-    o.logZ = p; p += align16u(4u * (u32)MM);
-    o.zpart = p; p += align16u(4u * PHD_NW * (u32)MM);
-    o.zok = p; p += align16u(4u * (u32)MM);
-    o.bgeo = p; p += align16u(20u * (u32)MM);
-    o.part = p; p += 4u * PHD_NW * 64u;
-    o.win = p; p += 4u * 7u * 64u;
-    o.red = p; p += align16u(4u * (2 * PHD_NW + 4));
-    o.ctr = p; p += 4u * 32u;
-    o.total = p;
-    return o;
-}
-
 struct Lds {
     // survivors (SoA), S entries each
     lds_f32 w, mx, my, xx, xy, yy;
@@ -75,33 +27,33 @@ struct Lds {
     lds_i32 u; // slab index (sort tie-break); after the sort: cluster assignment
     // the same 32 S bytes as two float4 arrays, the layout of the SORTED survivors in the round-based merge (S > 256):
     //   gA[i] = (mean x, mean y, E, weight)   E = |mean|^2 (1 - 2e-6) - 0.505 T tr: the far-pair filter's per-Gaussian term
-    //   gB[i] = (cov xx, cov xy, cov yy, cluster assignment as int bits)
+    //   gB[i] = (cov xx, cov xy, cov yy, assignment word)   assignment = cluster index | the cluster's seed's index << 16, -1: none
     // one ds_read_b128 per use instead of three to six ds_read_b32 with their address arithmetic
     LDS_T(v4f)* gA;
     LDS_T(v4f)* gB;
-    // aliased region
+    // region X
     LDS_T(v4f)* f_a;                           // per in-range feature: (r, b, S00, S01+S10)
     LDS_T(v2f)* f_c;                           //                       (S11, folded log-weight base)
     lds_u16 f_idx;                                // map index of in-range feature j
-    LDS_T(v4f)* f_k;                              // Kalman gain K0..K3 of in-range feature j
-    LDS_T(v4f)* f_p;                              // Joseph-form updated covariance (the same for every measurement) and prior mean x: (xx, xy, yy, mx)
-    lds_f32 f_my;                                 // prior mean y
     lds_u32 khi, klo, pay;                        // sort 1
-    LDS_T(long long)* acc;                        // exact moment sums: [C][6] 64-bit words (after the rounds; aliases khi.. )
-    LDS_T(v4f)* cinfo;                            // per cluster: (seed mean x, y, seed weight, seed's survivor index), written in the rounds
-    lds_f32 rwin;                                 // merge rounds: window copy + seed records (PHD_RWIN_BYTES), behind khi/klo/pay
+    lds_u16 ulist;                                // merge rounds: two u16 lists of S entries (the unmerged survivors)
+    lds_f32 rwin;                                 // merge rounds: window copy + seed records (PHD_RWIN_BYTES), behind the lists
+    LDS_T(long long)* acc;                        // exact moment sums: 48 B per cluster from the start of X to wide_end
+    int acc_clusters;                             // clusters the accumulators hold at a time
     LDS_T(u64)* srow;                             // merge_small: [256][4] closeness to earlier positions
-    LDS_T(u64)* scol;                             // merge_small: [256][4] members of the cluster seeded at a position
     LDS_T(u64)* sseed;                            // merge_small: [4] seed mask
     LDS_T(v4f)* sA;                               // merge_small: [256] (mx, my, 0.505 T tr, w) in sorted order
-    LDS_T(v4f)* sB;                               // merge_small: [256] (xx, xy, yy, -)
-    // not aliased
-    lds_u16 out_idx;                  // C
-    lds_f32 z_r, z_b, logZ, zpart;    // MM, MM, MM, 4*MM
-    lds_u32 zok;                      // MM
-    lds_f32 bgeo;                     // 5*MM: birth mean and covariance per measurement
+    LDS_T(v4f)* sB;                               // merge_small: [256] (xx, xy, yy, assignment word)
+    lds_u32 splist;                               // merge_small: candidate pairs, in the dead survivor planes
+    int splist_cap;
+    // behind X (dead once the update / the rounds are over)
     lds_u32 part;                     // 4*64 row parts of the window closeness matrix
     lds_f32 win;                      // 7*64 floats: with `part` the candidate list of pass 1 / 2
+    lds_f32 z_r, z_b, logZ;           // MM each
+    lds_u32 zok;                      // MM
+    lds_f32 zpart;                    // max(MM, 32): pass 1's partial sums (CPHD: redirected to the block's own scratch)
+    // persistent
+    lds_u16 out_idx;                  // C
     lds_f32 red;                      // PHD_NW + 4
     lds_i32 ctr;                      // 32 counters
 };
@@ -117,28 +69,35 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
     u32 f = o.alias;
     L.f_a = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
     L.f_c = (LDS_T(v2f)*)(base + f); f += align16u(8u * (u32)C);
-    L.f_idx = (lds_u16)(base + f); f += align16u(2u * (u32)C);
-    L.f_k = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
-    L.f_p = (LDS_T(v4f)*)(base + f); f += align16u(16u * (u32)C);
-    L.f_my = (lds_f32)(base + f);
+    L.f_idx = (lds_u16)(base + f);
     const u32 sv = align16u(4u * (u32)S);
     L.khi = (lds_u32)(base + o.alias);
     L.klo = (lds_u32)(base + o.alias + sv);
     L.pay = (lds_u32)(base + o.alias + 2u * sv);
+    L.ulist = (lds_u16)(base + o.alias);
+    L.rwin = (lds_f32)(base + o.alias + sv);
     L.acc = (LDS_T(long long)*)(base + o.alias);
-    L.cinfo = (LDS_T(v4f)*)(base + o.cinfo);
-    L.rwin = (lds_f32)(base + o.alias + 3u * sv);
+    L.acc_clusters = (int)((o.wide_end - o.alias) / 48u);
     L.srow = (LDS_T(u64)*)(base + o.alias);
-    L.scol = (LDS_T(u64)*)(base + o.alias + PHD_SMALL_S * 32u);
-    L.sseed = (LDS_T(u64)*)(base + o.alias + 2u * PHD_SMALL_S * 32u);
-    L.sA = (LDS_T(v4f)*)(base + o.alias + 2u * PHD_SMALL_S * 32u + 64u);
-    L.sB = (LDS_T(v4f)*)(base + o.alias + 2u * PHD_SMALL_S * 32u + 64u + PHD_SMALL_S * 16u);
-    L.out_idx = (lds_u16)(base + o.out_idx);
-    L.z_r = (lds_f32)(base + o.z_r); L.z_b = (lds_f32)(base + o.z_b); L.logZ = (lds_f32)(base + o.logZ);
-    L.zpart = (lds_f32)(base + o.zpart); L.zok = (lds_u32)(base + o.zok);
-    L.bgeo = (lds_f32)(base + o.bgeo);
+    L.sseed = (LDS_T(u64)*)(base + o.alias + PHD_SMALL_S * 32u);
+    if (S >= 4 * PHD_SMALL_S) {
+        // the planes are dead once the sorted staging has read them: records in the first two, pairs in the next three
+        L.sA = (LDS_T(v4f)*)(base + o.w);
+        L.sB = (LDS_T(v4f)*)(base + o.mx);
+        L.splist = (lds_u32)(base + o.my);
+        L.splist_cap = 3 * S;
+    } else {
+        L.sA = (LDS_T(v4f)*)(base + o.alias + 48u * PHD_SMALL_S);
+        L.sB = (LDS_T(v4f)*)(base + o.alias + 48u * PHD_SMALL_S + PHD_SMALL_S * 16u);
+        L.splist = (lds_u32)(base + o.w);
+        L.splist_cap = 5 * S;
+    }
     L.part = (lds_u32)(base + o.part);
     L.win = (lds_f32)(base + o.win);
+    L.z_r = (lds_f32)(base + o.z_r); L.z_b = (lds_f32)(base + o.z_b); L.logZ = (lds_f32)(base + o.logZ);
+    L.zok = (lds_u32)(base + o.zok);
+    L.zpart = (lds_f32)(base + o.zpart);
+    L.out_idx = (lds_u16)(base + o.out_idx);
     L.red = (lds_f32)(base + o.red);
     L.ctr = (lds_i32)(base + o.ctr);
     return L;

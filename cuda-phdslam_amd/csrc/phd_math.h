@@ -68,6 +68,42 @@ __device__ __forceinline__ void joseph_cov(const EkfTerms& t, float pxx, float p
     oyy = c3;
 }
 
+// the birth Gaussian of a measurement (host loop src/phdfilter.cu:3470-3506): the inverse measurement model at the particle's
+// pose and the measurement noise (scaled by birth_noise_factor) pushed through its Jacobian
+__device__ __forceinline__ void birth_geometry(const phd_pose& pose, float zr, float zb, const DevConfig& cfg, float& mx, float& my,
+                                               float& xx, float& xy, float& yy)
+{
+    const float theta = pose.ptheta + zb;
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    const float dx = zr * cs, dy = zr * sn;
+    const float J0 = dx / zr, J1 = dy / zr, J2 = -dy, J3 = dx;
+    const float sr = cfg.stdRange * cfg.birthNoiseFactor, sb = cfg.stdBearing * cfg.birthNoiseFactor;
+    const float vr = sr * sr, vb = sb * sb;
+    mx = pose.px + dx;
+    my = pose.py + dy;
+    xx = J0 * J0 * vr + J2 * J2 * vb;
+    xy = J0 * J1 * vr + J2 * J3 * vb;
+    yy = J1 * J1 * vr + J3 * J3 * vb;
+}
+
+// The detection term of in-range feature i (map slab `in`, planes of `cap`) for the innovation (i0, i1): updated mean
+// (src/phdfilter.cu:1903-1904) and Joseph covariance (:1891-1894).  Gain and covariance do not depend on the measurement, but
+// keeping them per feature costs 36 B of LDS each; the terms that survive the prune (a few per feature at most) rebuild them
+// from the prior instead — the same two routines on the same inputs as the classification pass, hence the same bits.
+__device__ __forceinline__ void detection_posterior(const float* __restrict__ in, int cap, int i, const phd_pose& pose,
+                                                    const DevConfig& cfg, float i0, float i1, float& mx, float& my, float& xx,
+                                                    float& xy, float& yy)
+{
+    const float pmx = in[1 * cap + i], pmy = in[2 * cap + i];
+    const float pxx = in[3 * cap + i], pxy = in[4 * cap + i], pyy = in[5 * cap + i];
+    EkfTerms t;
+    ekf_terms(pmx, pmy, pxx, pxy, pyy, pose, cfg, t);
+    joseph_cov(t, pxx, pxy, pyy, cfg, xx, xy, yy);
+    mx = pmx + t.K0 * i0 + t.K2 * i1;
+    my = pmy + t.K1 * i0 + t.K3 * i1;
+}
+
 // ------------------------------------------------------------------------------------------
 // exact distances — evaluated in the reference's operation order with FMA contraction off, so
 // the merge reproduces the CPU oracle bit for bit on identical inputs.

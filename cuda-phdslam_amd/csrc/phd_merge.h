@@ -71,27 +71,33 @@ __device__ __forceinline__ bool seed_close_to_itself(float mx, float my, float x
 // adds its terms to its cluster's accumulators with LDS atomics, in whatever order the lanes arrive.
 //   A: weights, weighted means, the covariance scale (largest exponent)      -> per-cluster W, mean
 //   B: weighted covariances about the merged mean                             -> per-cluster covariance
-// recA[i] = (mean x, mean y, -, weight), recB[i] = (cov xx, xy, yy, cluster index as int bits) for the S survivors;
-// cinfo[c] = (seed mean x, y, seed weight, the seed's survivor index); acc: 48 B per cluster, free to be overwritten.
-// Leaves the cluster count (min(n_clusters, first stop)) in ctr[CTR_KOUT].  Every thread of the workgroup calls it.
+// recA[i] = (mean x, mean y, -, weight), recB[i] = (cov xx, xy, yy, assignment word) for the S survivors; the assignment word
+// is (cluster index | index of the cluster's seed << 16), -1 for none: the seed's mean and weight — the anchors of the
+// fixed-point scales — are read from the seed's own record, no per-cluster table.
+// acc: 48 B per cluster for acc_clusters clusters at a time; more clusters than that take another sweep over the survivors
+// (4096 x 256 x 64: ~320 clusters, room for 384).  Leaves the cluster count (min(n_clusters, first stop)) in ctr[CTR_KOUT].
+// Every thread of the workgroup calls it.
 // ------------------------------------------------------------------------------------------
 template <bool HELLINGER, bool STAMPS>
 __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(v4f)* recB, int S, int n_clusters, int cap,
-                                            LDS_T(long long)* acc, const LDS_T(v4f)* cinfo, lds_i32 ctr, float T,
+                                            LDS_T(long long)* acc, int acc_clusters, lds_i32 ctr, float T,
                                             float* __restrict__ out_slab, int tid, u64* st)
 {
-    const int K = n_clusters < cap ? n_clusters : cap;         // clusters past the map capacity are reported, not stored
+    const int Kall = n_clusters < cap ? n_clusters : cap;      // clusters past the map capacity are reported, not stored
+    if (tid == 0) { ctr[CTR_NHEAD] = n_clusters; ctr[CTR_KOUT] = n_clusters; }
+    for (int lo = 0; lo < Kall; lo += acc_clusters) {
+    const int K = (Kall - lo) < acc_clusters ? (Kall - lo) : acc_clusters;
     // The accumulators: 48 B per cluster as SIX PLANES of K 8-byte words (sums: integers carried in doubles, phd_fixsum.h),
-    //   pass A: W | x hi | x lo | y hi | y lo | (largest exponent, flags)      pass B: cxx | cxy | cyy | W | (mean x, mean y) | (scales, flags)
+    //   pass A: W | x hi | x lo | y hi | y lo | (largest exponent, flags | seed's weight field << 8)
+    //   pass B: cxx | cxy | cyy | W | (mean x, mean y) | (scales, flags)
     // The lanes of a wave add to the clusters of their survivors — arbitrary indices c: in a plane those fall on bank pair
     // c mod 32, all 32 in use; the record-per-cluster layout (48 B apart) left 16 of them, every atomic at least four-deep in
-    // its banks — and LDS atomics are what this routine costs (two workgroups share the pipeline).
+    // its banks — and LDS atomics are what this routine costs (the resident workgroups share the pipeline).
     LDS_T(double)* const accd = (LDS_T(double)*)acc;
     LDS_T(u32)* const acc32 = (LDS_T(u32)*)acc;
     LDS_T(double)* const p0 = accd, * const p1 = accd + K, * const p2 = accd + 2 * K, * const p3 = accd + 3 * K, * const p4 = accd + 4 * K;
     LDS_T(u32)* const w4 = acc32 + 8 * K;                       // plane 4 as words: (mean x, mean y) in pass B
     LDS_T(u32)* const w5 = acc32 + 10 * K;                      // plane 5 as words: (largest exponent | scales, flags)
-    if (tid == 0) { ctr[CTR_NHEAD] = n_clusters; ctr[CTR_KOUT] = n_clusters; }
     for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 #ifdef PHD_DUP_MOMENTS
@@ -99,16 +105,21 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
 #endif
     for (int i = tid; i < S; i += PHD_T) {
         const v4f a = recA[i], b = recB[i];
-        const int c = __float_as_int(b.w);
-        if (c >= K) continue;
-        const v4f ci = cinfo[c];
-        const int Fw = fx_field(ci.z);
-        if (__float_as_int(ci.w) == i) {
-            // the seed: in its own cluster only if it is close to itself (a NaN distance is not)
-            if (!seed_close_to_itself<HELLINGER>(a.x, a.y, b.x, b.y, b.z, T)) { __hip_atomic_fetch_or(&w5[2 * c + 1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+        const u32 aw = __float_as_uint(b.w);
+        const int c = (int)(aw & 0xFFFFu) - lo;
+        if (aw == 0xFFFFFFFFu || c < 0 || c >= K) continue;
+        const int seed = (int)(aw >> 16);
+        const v4f sa = recA[seed];                              // the seed's record: (mean x, mean y, -, weight)
+        const int Fw = fx_field(sa.w);
+        if (seed == i) {
+            // the seed: leaves its weight field for the per-cluster steps, and is in its own cluster only if it is close to
+            // itself (a NaN distance is not)
+            const bool self = seed_close_to_itself<HELLINGER>(a.x, a.y, b.x, b.y, b.z, T);
+            __hip_atomic_fetch_or(&w5[2 * c + 1], ((u32)Fw << 8) | (self ? 0u : 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!self) continue;
         }
         FxSumsD fs;
-        fx_first_d(fs, Fw, ci.x, ci.y, a.w, a.x, a.y, b.x, b.y, b.z);
+        fx_first_d(fs, Fw, sa.x, sa.y, a.w, a.x, a.y, b.x, b.y, b.z);
         __hip_atomic_fetch_add(p0 + c, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(p1 + c, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(p2 + c, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -125,11 +136,11 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         fs.W = p0[c]; fs.xh = p1[c]; fs.xl = p2[c]; fs.yh = p3[c]; fs.yl = p4[c];
         const u32 ec = w5[2 * c], fl = w5[2 * c + 1];
         const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
-        const int Fw = fx_field(cinfo[c].z);
+        const int Fw = (int)((fl >> 8) & 0xFFu);
         // reference loop: W == 0 -> break (src/phdfilter.cu:2821); a seed left unmerged is re-picked and then yields W == 0
         int stop_at = 0x7FFFFFFF;
-        if (fs.W == 0.0 && ok) stop_at = c;
-        else if (!selfok) stop_at = c + 1;
+        if (fs.W == 0.0 && ok) stop_at = lo + c;
+        else if (!selfok) stop_at = lo + c + 1;
         if (stop_at != 0x7FFFFFFF) atomicMin((int*)&ctr[CTR_KOUT], stop_at);
         float W, mx, my;
         fx_mean_d(fs, Fw, W, mx, my);
@@ -139,7 +150,7 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         w4[2 * c] = __float_as_uint(mx); w4[2 * c + 1] = __float_as_uint(my);
         w5[2 * c] = (u32)Fc | ((u32)Fw << 16);
         w5[2 * c + 1] = (ok ? 0u : 1u) | (fl & 2u);
-        if (ok) { out_slab[0 * cap + c] = W; out_slab[1 * cap + c] = mx; out_slab[2 * cap + c] = my; }
+        if (ok) { out_slab[0 * cap + lo + c] = W; out_slab[1 * cap + lo + c] = mx; out_slab[2 * cap + lo + c] = my; }
     }
     __syncthreads();
     STAMP(9);
@@ -148,12 +159,13 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
 #endif
     for (int i = tid; i < S; i += PHD_T) {
         const v4f a = recA[i], b = recB[i];
-        const int c = __float_as_int(b.w);
-        if (c >= K) continue;
+        const u32 aw = __float_as_uint(b.w);
+        const int c = (int)(aw & 0xFFFFu) - lo;
+        if (aw == 0xFFFFFFFFu || c < 0 || c >= K) continue;
         const v2f hm = ((LDS_T(v2f)*)w4)[c];                    // (mean x, mean y)
         const u32 sc = w5[2 * c], hfl = w5[2 * c + 1];          // (scales, flags)
         // (flag 2: the seed is not in its own cluster, decided in pass A)
-        if ((hfl & 2u) && __float_as_int(cinfo[c].w) == i) continue;
+        if ((hfl & 2u) && (int)(aw >> 16) == i) continue;
         bool ok = true;
         double qxx, qxy, qyy;
         fx_cov_terms_d((int)(sc & 0xFFFFu), hm.x, hm.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
@@ -171,12 +183,14 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         if (w5[2 * c + 1] & 1u) {
             const float bad = __builtin_nanf("");
 #pragma unroll
-            for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + c] = bad;
+            for (int pl = 0; pl < 6; ++pl) out_slab[pl * cap + lo + c] = bad;
         } else {
-            out_slab[3 * cap + c] = fx_cov_d(cxx, Wq, Fc, Fw);
-            out_slab[4 * cap + c] = fx_cov_d(cxy, Wq, Fc, Fw);
-            out_slab[5 * cap + c] = fx_cov_d(cyy, Wq, Fc, Fw);
+            out_slab[3 * cap + lo + c] = fx_cov_d(cxx, Wq, Fc, Fw);
+            out_slab[4 * cap + lo + c] = fx_cov_d(cxy, Wq, Fc, Fw);
+            out_slab[5 * cap + lo + c] = fx_cov_d(cyy, Wq, Fc, Fw);
         }
+    }
+    if (lo + acc_clusters < Kall) __syncthreads();             // (uniform) the next sweep re-arms the planes these loops read
     }
 }
 
@@ -248,8 +262,8 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     __syncthreads();
     STAMP(6);
     u64 tq0 = 0, tq1 = 0, tq2 = 0;
-    lds_u32 plist = (lds_u32)L.w;                // candidate pairs (k << 16 | l): the first five survivor planes
-    const int pcap = 5 * S_cap;
+    lds_u32 plist = L.splist;                    // candidate pairs (k << 16 | l): survivor planes, dead since the sorted staging
+    const int pcap = L.splist_cap;
     // ---- closeness rows.  Work units are HALF waves: 32 consecutive positions (half-block hb) x 16 columns (column unit
     //      cu, columns 16 cu .. 16 cu + 15, only units with a column below the half-block's last row), two units per
     //      wave iteration, dealt round-robin to the waves; a unit fills the 16-bit quarter cu of its rows' words.
@@ -398,10 +412,8 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     // ---- membership: every position joins the first seed of its row (a seed joins itself); its cluster index — the seeds
     //      before its owner, i.e. the output position — goes into the record, the seed leaves the cluster's record
     const u64 s0 = L.sseed[0], s1 = L.sseed[1], s2 = L.sseed[2], s3 = L.sseed[3];
-    // (the rows and the member-mask area are dead after this pass: the sums' accumulators take the first 12 KB of the
-    //  16 KB they occupy, the cluster records the last 4 KB)
+    // (the rows and the seed masks are dead after this pass: the sums' accumulators take their place, 12 KB for 256 clusters)
     LDS_T(long long)* const acc = (LDS_T(long long)*)L.srow;
-    LDS_T(v4f)* const cinfo = (LDS_T(v4f)*)((lds_u8)L.srow + 48u * PHD_SMALL_S);
     int owner = 0;
     bool is_seed = false;
     if (tid < S) {
@@ -426,11 +438,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
         if (o >= 64) c += (o >= 128) ? __popcll(s1) : __popcll(s1 & below);
         if (o >= 128) c += (o >= 192) ? __popcll(s2) : __popcll(s2 & below);
         if (o >= 192) c += __popcll(s3 & below);
-        ((LDS_T(int)*)&L.sB[k])[3] = c;
-        if (is_seed && c < cap) {
-            const v4f sa = L.sA[k];
-            cinfo[c] = (v4f){sa.x, sa.y, sa.w, __int_as_float(k)};
-        }
+        ((LDS_T(int)*)&L.sB[k])[3] = c | (o << 16);   // the assignment word: cluster | its seed's position
     }
     if (STAMPS && tid == 0) {
         const u64 tq3 = __builtin_amdgcn_s_memrealtime();
@@ -439,7 +447,7 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
     STAMP(7);
     // ---- moment matching by exact, order-free sums (moment_sums above)
     const int n_clusters = __popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3);
-    moment_sums<HELLINGER, STAMPS>(L.sA, L.sB, S, n_clusters, cap, acc, cinfo, L.ctr, T, out_slab, tid, st);
+    moment_sums<HELLINGER, STAMPS>(L.sA, L.sB, S, n_clusters, cap, acc, PHD_SMALL_S, L.ctr, T, out_slab, tid, st);
     __syncthreads();
     STAMP(10);
 }
@@ -485,8 +493,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     // packed add, two packed FMAs for TWO pairs, and one v_alignbit per pair that shifts the sign bit into the mask.
     LDS_T(v4f)* const gA = L.gA;
     LDS_T(v4f)* const gB = L.gB;
-    LDS_T(int)* const asg = (LDS_T(int)*)L.gB;           // cluster assignment of survivor i: asg[4 i + 3]
-    lds_u16 ul_a = (lds_u16)L.pay, ul_b = ul_a + S_cap;  // two u16 lists in the (free) sort-payload region
+    LDS_T(int)* const asg = (LDS_T(int)*)L.gB;           // assignment word of survivor i (cluster | seed's index << 16): asg[4 i + 3]
+    lds_u16 ul_a = L.ulist, ul_b = ul_a + S_cap;         // two u16 lists where the sort's keys were
     lds_i32 wpos = (lds_i32)L.rwin;
     LDS_T(v4f)* const wA = (LDS_T(v4f)*)(L.rwin + 64);         // the window's copy of gA / gB
     LDS_T(v4f)* const wB = (LDS_T(v4f)*)(L.rwin + 64 + 256);
@@ -614,7 +622,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 // the cluster of a window candidate: its own if it is a seed, else the first seed it is close to.  Cluster
                 // index = seeds before it, over all rounds = its position in the output (descending seed weight)
                 const int owner = ((seeds >> lane) & 1ull) ? lane : __builtin_ctzll(row & seeds);
-                asg[4 * wpos[lane] + 3] = kbase + __popcll(seeds & ((1ull << owner) - 1ull));
+                asg[4 * wpos[lane] + 3] = (kbase + __popcll(seeds & ((1ull << owner) - 1ull))) | (wpos[owner] << 16);
             }
         }
         if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
@@ -632,10 +640,8 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 const int pr = 4 * (rank >> 1) + (rank & 1);
                 sPf[pr] = kE; sPf[pr + 2] = m2x; sQf[rank] = m2y;
                 v4f g = wB[lane];
-                g.w = __int_as_float(kbase + rank);
+                g.w = __int_as_float((kbase + rank) | (wpos[lane] << 16));   // what a survivor that joins this seed stores
                 sG[rank] = g;
-                // the seed's record for the moment sums after the rounds (one wave writes it)
-                if (wave == 0 && kbase + rank < cap) L.cinfo[kbase + rank] = (v4f){kx, ky, ka.w, __int_as_float(wpos[lane])};
             }
             if (lane < 8) {                                       // pad to a multiple of 8: never a candidate
                 const int rp = nseeds + lane, pr = 4 * (rp >> 1) + (rp & 1);
@@ -749,7 +755,7 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
 
     STAMP(7);
     // ---- moment matching by exact, order-free sums (moment_sums above) ----
-    moment_sums<HELLINGER, STAMPS>(gA, gB, S, kbase, cap, L.acc, L.cinfo, L.ctr, T, out_slab, tid, st);
+    moment_sums<HELLINGER, STAMPS>(gA, gB, S, kbase, cap, L.acc, L.acc_clusters, L.ctr, T, out_slab, tid, st);
     __syncthreads();
     STAMP(10);
 }

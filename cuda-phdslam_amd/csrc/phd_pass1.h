@@ -78,11 +78,12 @@ __device__ __forceinline__ Pass1Grid pass1_grid(int M)
 }
 
 // Z_m's feature sum: the partial sums of the NF waves that own measurement m's chunk
-__device__ __forceinline__ float pass1_feature_sum(const Lds& L, const Pass1Grid& g, int m, int MM)
+__device__ __forceinline__ float pass1_feature_sum(const Lds& L, const Pass1Grid& g, int m, int M)
 {
-    const int cg = (m % g.nchunks) & (g.NC - 1);           // chunk c holds the measurements c, c + nchunks, c + 2 nchunks, ...
-    float s = L.zpart[cg * MM + m];
-    for (int fg = 1; fg < g.NF; ++fg) s += L.zpart[(fg * g.NC + cg) * MM + m];
+    // measurement m belongs to ONE chunk, chunk c to the NF waves (fg, c mod NC): NF partial sums per measurement, stored
+    // [fg][M] — NF > 1 only for scans of at most 16 measurements, so NF M <= max(M, 32) floats (phd_lds.h)
+    float s = L.zpart[m];
+    for (int fg = 1; fg < g.NF; ++fg) s += L.zpart[fg * M + m];
     return s;
 }
 
@@ -208,7 +209,7 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
         int m;
         if (CH == 8) { tot = reduce8_over_wave((float (&)[8])acc, lane); m = c + (lane >> 3) * mstep; }
         else { tot = reduce4_over_wave((float (&)[4])acc, lane); m = c + (lane >> 4) * mstep; }
-        if ((lane & (64 / CH - 1)) == 0 && m < M) L.zpart[wave * MM + m] = tot;
+        if ((lane & (64 / CH - 1)) == 0 && m < M) L.zpart[fg * M + m] = tot;
     }
 }
 

@@ -307,6 +307,13 @@ class PhdFilter:
         check(lib().phd_debug_get_weight_increments(self._h, ptr(d)), "phd_debug_get_weight_increments")
         return d
 
+    def residency(self):
+        """-> dict(workgroups_per_cu, lds_bytes): how the update kernel sits on a CU (phd_update_residency)"""
+        n = C.c_int32(0)
+        b = C.c_uint64(0)
+        check(lib().phd_update_residency(self._h, C.byref(n), C.byref(b)), "phd_update_residency")
+        return dict(workgroups_per_cu=n.value, lds_bytes=b.value)
+
     def status(self, raise_on_overflow=True):
         st = C.c_uint32(0)
         ms = C.c_int32(0)

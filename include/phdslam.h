@@ -390,6 +390,9 @@ int phd_debug_get_stamps(phd_filter* f, uint64_t* out);
 int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, int32_t* slab_index_out,
                             int capacity, int32_t* n_out);
 int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out);
+/* how the update kernel of this filter sits on a CU: dynamic LDS bytes per workgroup (one workgroup = one particle) and the
+ * workgroups the runtime says a CU holds at a time (registers, LDS and waves taken together; 3 at 4096 x 256 x 64).  Diagnostic. */
+int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_out, uint64_t* lds_bytes_out);
 /* status word accumulated on the device: bit0 map overflow, bit1 survivor overflow (-> PHD_ERR_CAPACITY), bit2 the weights
  * workgroup of a fused step gave up waiting for the particles' workgroups (-> PHD_ERR_HIP; a bounded spin of seconds, never
  * seen in practice) */
