@@ -246,7 +246,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         f->cphd = true;
         f->cn_len = cfg->maxCardinality + 1;
         f->lfact_len = std::max(f->cn_len, f->MM + 1) + 1;
-        f->lds_bytes += cphd_lds_bytes(f->cn_len, f->MM);
+        f->lds_bytes += cphd_lds_bytes(f->S_cap, f->cn_len, f->MM);
     }
     // a launch can use 160 KiB minus what the kernel's instantiations declare statically (the fused ones carry the
     // weights routine's arrays): refuse here what launch_update_merge could not launch

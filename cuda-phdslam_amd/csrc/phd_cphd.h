@@ -39,6 +39,8 @@ struct CphdLds {
 };
 enum { CQ_LY0 = 0, CQ_LY1 = 1, CQ_R1 = 2 };
 
+// The block's arrays: `scal` outlives the block (the missed-detection factor and log <Y0,p> are read at the emission, the
+// hand-off and the tail) and sits behind the common layout; everything else is dead when the block returns.  off[9] = scal.
 __host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 off[12])
 {
     const u32 cn = align16u(4u * (u32)cn_len);
@@ -54,22 +56,47 @@ __host__ __device__ __forceinline__ u32 cphd_lds_layout(int cn_len, int MM, u32 
     off[6] = p; p += mm;  // lD
     off[7] = p; p += mm;  // efull
     off[8] = p; p += mm;  // cnb
-    off[9] = p; p += 64u; // scal
     off[10] = p; p += mm; // kp
     off[11] = p; p += align16u(32u * (u32)MM); // zscr
+    off[9] = 0;           // scal: its own 64 bytes (cphd_carve)
     return p;
 }
+#define PHD_CPHD_PERSIST_BYTES 64u
 
+// The f64 sweeps (M <= 64) park the rows P_m[0..m], m < M, in the survivor planes — empty until this block has produced the
+// weights.  TRIANGULAR: row m starts at entry m (m + 1) / 2; the sweep still stores all 64 lanes of a row (zeros beyond
+// entry m), which run into the places of the rows behind it — written later, in ascending m.  (M - 1) M / 2 + 64 entries:
+// 16.3 KB at M = 64 instead of the 32 KB of the rectangular form, which leaves the planes room for the block's own arrays:
+// at 4096 x 256 x 64 the CPHD filter then needs the common layout + 64 B, and three workgroups share a CU.
+__host__ __device__ __forceinline__ u32 cphd_rows_bytes(int MM)
+{
+    const int m = MM < 64 ? MM : 64;
+    return 8u * (u32)((m - 1) * m / 2 + 64);
+}
+__host__ __device__ __forceinline__ bool cphd_block_in_planes(int S_cap, int cn_len, int MM)
+{
+    u32 off[12];
+    return 32u * (u32)S_cap >= cphd_rows_bytes(MM) + cphd_lds_layout(cn_len, MM, off);
+}
+// bytes behind the common layout
+__host__ __device__ __forceinline__ u32 cphd_extra_lds_bytes(int S_cap, int cn_len, int MM)
+{
+    u32 off[12];
+    const u32 blk = cphd_lds_layout(cn_len, MM, off);
+    return PHD_CPHD_PERSIST_BYTES + (cphd_block_in_planes(S_cap, cn_len, MM) ? 0u : blk);
+}
 
-__device__ __forceinline__ CphdLds cphd_carve(lds_u8 base, int cn_len, int MM)
+// persist: behind the common layout; planes: the survivor planes' base
+__device__ __forceinline__ CphdLds cphd_carve(lds_u8 persist, lds_u8 planes, int S_cap, int cn_len, int MM)
 {
     u32 off[12];
     cphd_lds_layout(cn_len, MM, off);
+    lds_u8 base = cphd_block_in_planes(S_cap, cn_len, MM) ? planes + cphd_rows_bytes(MM) : persist + PHD_CPHD_PERSIST_BYTES;
     CphdLds Q;
     Q.cnq = (lds_f32)(base + off[0]); Q.cnp = (lds_f32)(base + off[1]); Q.lfact = (lds_f32)(base + off[2]);
     Q.lxi = (lds_f32)(base + off[3]); Q.I0 = (lds_f32)(base + off[4]); Q.I1 = (lds_f32)(base + off[5]);
     Q.lD = (lds_f32)(base + off[6]); Q.efull = (lds_f32)(base + off[7]); Q.cnb = (lds_f32)(base + off[8]);
-    Q.scal = (lds_f32)(base + off[9]);
+    Q.scal = (lds_f32)persist;
     Q.kp = (lds_i32)(base + off[10]);
     Q.zscr = (lds_f32)(base + off[11]);
     return Q;
@@ -406,7 +433,9 @@ __device__ __forceinline__ double lane_down1_z(double v)
 // because its shifted-in neighbour is zero), no masks (entries beyond a = m are exact zeros: 0 + xi * 0), unconditional
 // stores — one readlane, one convert, two DPP moves, one fma and one store per step.  P_M[64] (only M = 64 needs it, for
 // the full-set ESF) is xi_63 * P_63[63].  RowPtr: an LDS or a global pointer (a generic one would compile to flat stores).
-template <typename RowPtr>
+// TRI: the triangular row layout of the LDS rows (cphd_rows_bytes; h = 0 there)
+template <bool TRI> __device__ __forceinline__ size_t cphd_row_off(int m, int rs) { return TRI ? (size_t)(m * (m + 1) / 2) : (size_t)m * rs; }
+template <bool TRI, typename RowPtr>
 __device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowPtr rows, int rs, int M, int h, int lane)
 {
 #pragma clang fp contract(off)
@@ -422,7 +451,7 @@ __device__ __forceinline__ void cphd_esf_forward_park_f64(const CphdLds& Q, RowP
         if (lane < PHD_F64_RENORM && m0 + lane < M && m0 + lane >= h) Q.kp[m0 + lane] = kP;   // the block exponent of the next rows
         const int m1 = (m0 + PHD_F64_RENORM < M) ? m0 + PHD_F64_RENORM : M;
         for (int m = m0; m < m1; ++m) {
-            if (m >= h && lane < rs) rows[(size_t)(m - h) * rs + lane] = P;       // row m: P_m[0..m] (zeros beyond; rs >= M > m)
+            if (m >= h && lane < rs) rows[cphd_row_off<TRI>(m - h, rs) + lane] = P;  // row m: P_m[0..m] (zeros beyond; rs >= M > m)
             const double x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
             if (m == 63) top = x * P;                                             // (lane 63 holds P_63[63])
             P = __builtin_fma(x, lane_up1_z(P), P);                               // P_{m+1}[a] = P_m[a] + xi_m P_m[a-1]
@@ -485,7 +514,7 @@ __device__ __forceinline__ void cphd_esf_suffix_f64(const CphdLds& Q, LDS_T(doub
 //                   fmas, not a chain.
 // (The step shifts towards lane 0 with a zero shifted in: c_k = 0 beyond k = M - 1, so every lane stays a valid entry.)
 // Round 3a ran ONE chain of M steps: 9.5 us.  The logarithms are taken after the sweeps, by one thread per m (dsum / dexp_).
-template <typename RowPtr>
+template <bool TRI, typename RowPtr>
 __device__ __forceinline__ void cphd_esf_chains_f64(const CphdLds& Q, RowPtr rowsP, int rs, int M, int h, int lane, int wave,
                                                     float llam, float lam, LDS_T(double)* dsum, LDS_T(int)* dexp_,
                                                     LDS_T(double)* c_lds, const LDS_T(double)* sh_row, const LDS_T(int)* sh_exp)
@@ -546,7 +575,7 @@ __device__ __forceinline__ void cphd_esf_chains_f64(const CphdLds& Q, RowPtr row
     // wave cost two of those instead of sixteen 6-step butterflies.
     int m = m_hi;
     if (me == 1 && m >= m_lo) { if (m > m_lo) step(m); --m; }
-    double prow = (m >= m_lo && lane <= m) ? rowsP[(size_t)m * rs + lane] : 0.0;
+    double prow = (m >= m_lo && lane <= m) ? rowsP[cphd_row_off<TRI>(m, rs) + lane] : 0.0;
     int krow = m >= m_lo ? Q.kp[m] : 0;
     while (m >= m_lo) {
         double pq[8];
@@ -560,7 +589,7 @@ __device__ __forceinline__ void cphd_esf_chains_f64(const CphdLds& Q, RowPtr row
                 if ((lane >> 3) == q) eq = krow + kV;
                 nq = q + 1;
                 const int mn = m - 2;                                                   // the row of the next one, a turn ahead
-                prow = (mn >= m_lo && lane <= mn) ? rowsP[(size_t)mn * rs + lane] : 0.0;
+                prow = (mn >= m_lo && lane <= mn) ? rowsP[cphd_row_off<TRI>(mn, rs) + lane] : 0.0;
                 krow = mn >= m_lo ? Q.kp[mn] : 0;
                 if (m > m_lo) step(m);
                 if (m - 1 > m_lo) step(m - 1);
@@ -805,7 +834,7 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     GSTAMP(29, 0);
     // M <= 64: the sweeps in double (cphd_esf_*_f64); their rows live in the survivor arrays — idle until this block has
     // produced the weights — when those hold M rows of 64 doubles, else in the HBM scratch (row stride MM)
-    const bool rows_in_lds = tiles == 1 && (size_t)32 * S_cap >= (size_t)M * 64 * 8;
+    const bool rows_in_lds = tiles == 1 && 32u * (u32)S_cap >= cphd_rows_bytes(MM);    // (triangular rows; the block's own arrays may follow them)
     LDS_T(double)* const rows_l = (LDS_T(double)*)L.w;
     double* const rows_g = (double*)T_scratch;
     // f64 path (M <= 64): wave 0 runs the forward sweep (parks every row P_m) and then, M / 2 steps, the suffix polynomial S_h of
@@ -823,8 +852,8 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // (giving the sweep wave, free two thirds into the phase, the last 6 of the 66 n-sums was measured: no gain — 1 967 vs 1 975 steps/s)
     const int j_w0 = 0;
     if (wave == 0) {
-        if (f64 && rows_in_lds) cphd_esf_forward_park_f64(Q, rows_l, 64, M, 0, lane);
-        else if (f64) cphd_esf_forward_park_f64(Q, rows_g, MM, M, 0, lane);
+        if (f64 && rows_in_lds) cphd_esf_forward_park_f64<true>(Q, rows_l, 64, M, 0, lane);
+        else if (f64) cphd_esf_forward_park_f64<false>(Q, rows_g, MM, M, 0, lane);
         else if (tiles == 2) cphd_esf_forward_park<2>(Q, T_scratch, M, lane);
         else cphd_esf_forward_park<4>(Q, T_scratch, M, lane);
         GSTAMP(16, 0);   // forward sweep done
@@ -916,8 +945,8 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     LDS_T(int)* const dexp_ = (LDS_T(int)*)L.logZ;
     if (tiles != 1 && wave == PHD_FW) cphd_full_set(Q, M, lane, llam, lam);
     if (tiles == 1) {
-        if (rows_in_lds) cphd_esf_chains_f64(Q, (const LDS_T(double)*)rows_l, 64, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
-        else cphd_esf_chains_f64(Q, (const double*)rows_g, MM, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
+        if (rows_in_lds) cphd_esf_chains_f64<true>(Q, (const LDS_T(double)*)rows_l, 64, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
+        else cphd_esf_chains_f64<false>(Q, (const double*)rows_g, MM, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
         GSTAMP(21, 0);       // wave 0's share of the backward sweep done
         GSTAMP(22, 192);     // wave 3's
         if (wave == PHD_NW - 1) cphd_full_set(Q, M, lane, llam, lam);   // (after its share of the sweep: every wave takes part in it)
@@ -993,7 +1022,9 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
         }
         cn_out[n] = Q.cnp[n] + (safe_log(s) + mx) - lY0;
     }
-    // the bucket counts of the merge's counting sort (phd_lds.h): the `tr` plane held sweep rows until now
+    // the bucket counts of the merge's counting sort (phd_lds.h): the `tr` plane held sweep rows until now — and, with a long
+    // cardinality distribution, may hold part of this block's own arrays, which the loops above still read
+    if (cphd_block_in_planes(S_cap, cn_len, MM)) __syncthreads();   // (uniform)
     for (int b = tid; b < S_cap; b += PHD_T) ((LDS_T(u32)*)L.tr)[b] = 0u;
     __syncthreads();
     CQSTAMP(4);

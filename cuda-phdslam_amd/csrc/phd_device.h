@@ -122,7 +122,7 @@ struct UpdateArgs {
 
 size_t update_lds_bytes(int S, int C, int MM);
 size_t update_static_lds_bytes();           // static __shared__ of the update kernel's instantiations (needs a device)
-size_t cphd_lds_bytes(int cn_len, int MM);   // extra LDS of the CPHD instantiation, carved after update_lds_bytes()
+size_t cphd_lds_bytes(int S_cap, int cn_len, int MM);   // extra LDS of the CPHD instantiation, carved after update_lds_bytes()
 // rows of `len` floats: dst[(c ? c[k] : k)] = src[b ? b[a ? a[k] : k] : (a ? a[k] : k)], k < n; skipped when a[k] < 0
 hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, const int* b, float* dst, size_t dst_stride,
                             const int* c, int len, int n, hipStream_t st);

@@ -50,8 +50,9 @@
 #include "phd_predict.h"
 #include "phd_cphd.h"
 #include "phd_weights.h"
-// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU compile the kernel template and one table of instantiations each)
-#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU)
+// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU compile the kernel template and one table of
+//  instantiations each)
+#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU) || defined(PHD_CPHD_W6_TU)
 #define PHD_PART_TU 1
 #endif
 #ifndef PHD_PART_TU
@@ -69,11 +70,7 @@ namespace phd {
 #ifndef PHD_PART_TU
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total + PHD_LDS_PAD; }
 int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
-size_t cphd_lds_bytes(int cn_len, int MM)
-{
-    u32 off[12];
-    return cphd_lds_layout(cn_len, MM, off);
-}
+size_t cphd_lds_bytes(int S_cap, int cn_len, int MM) { return cphd_extra_lds_bytes(S_cap, cn_len, MM); }
 
 #endif // !PHD_PART_TU
 
@@ -112,7 +109,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L = lds_carve((lds_u8)lds_raw, A.S_cap, A.cap, A.MM);
     // CPHD instantiation: its arrays follow the common layout
-    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(A.S_cap, A.cap, A.MM).total, A.cn_len, A.MM) : CphdLds();
+    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(A.S_cap, A.cap, A.MM).total, (lds_u8)lds_raw, A.S_cap, A.cn_len, A.MM) : CphdLds();
     if (CPHD) L.zpart = Q.zscr;   // the block parks rows of cn_len doubles where pass 1 leaves its partial sums: a scratch of its own
 
     const int tid = threadIdx.x;
@@ -639,12 +636,17 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 }
 
 // ------------------------------------------------------------------------------------------
-// Three translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
-// three-workgroups-per-CU ones are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU — the kernel template above, one of
-// these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
+// Four translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
+// three-workgroups-per-CU ones (PHD, CPHD) are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU — the
+// kernel template above, one of these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
 // (csrc/Makefile, KFLAGS_CPHD: measured, currently the same).
 // ------------------------------------------------------------------------------------------
-#if defined(PHD_W6_TU)
+#if defined(PHD_CPHD_W6_TU)
+// <STAMPS, FUSEW, CPHD, -, 6>: the same three for the CPHD filter
+extern const void* const k_update_cphd_w6_fns[3] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
+                                                    (const void*)phd_update_merge_kernel<true, false, true, false, 6>,
+                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6>};
+#elif defined(PHD_W6_TU)
 // <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
 extern const void* const k_update_w6_fns[3] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
@@ -659,6 +661,7 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
 #else
 extern const void* const k_update_cphd_fns[5];
 extern const void* const k_update_w6_fns[3];
+extern const void* const k_update_cphd_w6_fns[3];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
@@ -995,15 +998,16 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-static const void* const k_update_fns[13] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
+static const void* const k_update_fns[16] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
                                              k_update_cphd_fns[0], k_update_cphd_fns[1], k_update_cphd_fns[2],
                                              (const void*)phd_update_merge_kernel<false, false, false, true>,
                                              (const void*)phd_update_merge_kernel<false, true, false, true>,
                                              k_update_cphd_fns[3], k_update_cphd_fns[4],
-                                             k_update_w6_fns[0], k_update_w6_fns[1], k_update_w6_fns[2]};
-#define PHD_N_UPDATE_FNS 13
+                                             k_update_w6_fns[0], k_update_w6_fns[1], k_update_w6_fns[2],
+                                             k_update_cphd_w6_fns[0], k_update_cphd_w6_fns[1], k_update_cphd_w6_fns[2]};
+#define PHD_N_UPDATE_FNS 16
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1059,8 +1063,8 @@ static int update_fn_index(const UpdateArgs& a, size_t lds_bytes, int n_particle
     const bool fused = a.fuse_weights && !a.stamps;
     // the 80-register build pays ~2 % (and more on the critical path of a lone workgroup) for the right to a third resident
     // workgroup: only where LDS admits three AND the launch has more than two workgroups per CU to place
-    const bool three = !a.cphd && !sp && 3 * (lds_bytes + 1024) <= 160 * 1024 && n_particles > 2 * device_cu_count();
-    if (three) return a.stamps ? 11 : fused ? 12 : 10;
+    const bool three = !sp && 3 * (lds_bytes + 1024) <= 160 * 1024 && n_particles > 2 * device_cu_count();
+    if (three) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }
 
