@@ -434,7 +434,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
                 // the complete survivor at once (two thirds of the listed terms survive: a separate finalise pass would
                 // fetch the same feature terms again, behind one more barrier)
                 float umx, umy, uxx, uxy, uyy;
-                detection_posterior(in, cap, L.f_idx[j], pose, cfg, i0, i1, umx, umy, uxx, uxy, uyy);
+                detection_posterior(in, cap, L.f_idx[j], pose, cfg, fa.x, fa.z, fa.w, fc.x, i0, i1, umx, umy, uxx, uxy, uyy);
                 if (slot < S_cap) {
                     L.w[slot] = w; L.u[slot] = n_in + m * n_in + j;
                     L.mx[slot] = umx; L.my[slot] = umy;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
                 }
                 else {
                     float umx, umy, uxx, uxy, uyy;
-                    detection_posterior(in, cap, L.f_idx[jj], pose, cfg, i0, i1, umx, umy, uxx, uxy, uyy);
+                    detection_posterior(in, cap, L.f_idx[jj], pose, cfg, fa.x, fa.z, fa.w, fc.x, i0, i1, umx, umy, uxx, uxy, uyy);
                     spill_store(sp, L, slot, w, umx, umy, uxx, uxy, uyy, n_in + m * n_in + j);
                 }
             }
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
             const float i0 = L.z_r[m] - fa.x;
             const float i1 = wrap_angle(L.z_b[m] - fa.y);
             float umx, umy, uxx, uxy, uyy;
-            detection_posterior(in, cap, L.f_idx[j], pose, cfg, i0, i1, umx, umy, uxx, uxy, uyy);
+            detection_posterior(in, cap, L.f_idx[j], pose, cfg, fa.x, fa.z, fa.w, L.f_c[j].x, i0, i1, umx, umy, uxx, uxy, uyy);
             L.mx[s] = umx; L.my[s] = umy;
             L.xx[s] = uxx; L.xy[s] = uxy; L.yy[s] = uyy;
         }

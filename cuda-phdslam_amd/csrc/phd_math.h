@@ -91,14 +91,28 @@ __device__ __forceinline__ void birth_geometry(const phd_pose& pose, float zr, f
 // (src/phdfilter.cu:1903-1904) and Joseph covariance (:1891-1894).  Gain and covariance do not depend on the measurement, but
 // keeping them per feature costs 36 B of LDS each; the terms that survive the prune (a few per feature at most) rebuild them
 // from the prior instead — the same two routines on the same inputs as the classification pass, hence the same bits.
+// The inverse innovation covariance is NOT rebuilt: the classification pass left it in LDS for pass 1 (r, S00, S01 + S10, S11 —
+// S01 = S10, so half the sum is either, exactly), which spares the innovation covariance, its determinant and four divisions.
 __device__ __forceinline__ void detection_posterior(const float* __restrict__ in, int cap, int i, const phd_pose& pose,
-                                                    const DevConfig& cfg, float i0, float i1, float& mx, float& my, float& xx,
-                                                    float& xy, float& yy)
+                                                    const DevConfig& cfg, float r, float S0, float S12, float S3, float i0,
+                                                    float i1, float& mx, float& my, float& xx, float& xy, float& yy)
 {
     const float pmx = in[1 * cap + i], pmy = in[2 * cap + i];
     const float pxx = in[3 * cap + i], pxy = in[4 * cap + i], pyy = in[5 * cap + i];
     EkfTerms t;
-    ekf_terms(pmx, pmy, pxx, pxy, pyy, pose, cfg, t);
+    {
+        // ekf_terms()'s own expressions for the Jacobian (:1854-1858) and the gain (:1884-1888), on its own values
+        const float dx = pmx - pose.px, dy = pmy - pose.py;
+        const float r2 = dx * dx + dy * dy;
+        const float J0 = dx / r, J2 = dy / r, J1 = -dy / r2, J3 = dx / r2;
+        const float P0 = pxx, P1 = pxy, P2 = pxy, P3 = pyy;
+        const float S1 = 0.5f * S12, S2 = S1;
+        t.K0 = S0 * (P0 * J0 + P2 * J2) + S1 * (P0 * J1 + P2 * J3);
+        t.K1 = S0 * (P1 * J0 + P3 * J2) + S1 * (P1 * J1 + P3 * J3);
+        t.K2 = S2 * (P0 * J0 + P2 * J2) + S3 * (P0 * J1 + P2 * J3);
+        t.K3 = S2 * (P1 * J0 + P3 * J2) + S3 * (P1 * J1 + P3 * J3);
+        t.J0 = J0; t.J1 = J1; t.J2 = J2; t.J3 = J3;
+    }
     joseph_cov(t, pxx, pxy, pyy, cfg, xx, xy, yy);
     mx = pmx + t.K0 * i0 + t.K2 * i1;
     my = pmy + t.K1 * i0 + t.K3 * i1;
