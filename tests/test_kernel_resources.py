@@ -38,7 +38,7 @@ def compiled(tmp_path_factory):
         pytest.skip("hipcc not available")
     cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
     jobs = []
-    for target in ("print-kflags", "print-kflags-cphd", "print-kflags-w6"):
+    for target in ("print-kflags", "print-kflags-cphd", "print-kflags-w6", "print-kflags-cphd-w6"):
         d = tmp_path_factory.mktemp("isa")
         cmd = [cc] + kernel_flags(target) + ["--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj", "-c",
                                              os.path.join(SRC, "phd_kernels.hip"), "-o", str(d / "k.o")]
@@ -66,7 +66,7 @@ def compiled(tmp_path_factory):
 # (+ the launch bound: Li4 = two workgroups per CU, Li6 = three)
 TAGS = ("ILb0ELb0ELb0ELb0ELi4E", "ILb0ELb1ELb0ELb0ELi4E", "ILb0ELb0ELb1ELb0ELi4E", "ILb0ELb1ELb1ELb0ELi4E",
         "ILb0ELb0ELb0ELb1ELi4E", "ILb0ELb1ELb0ELb1ELi4E", "ILb0ELb0ELb1ELb1ELi4E", "ILb0ELb1ELb1ELb1ELi4E")
-TAGS_W6 = ("ILb0ELb0ELb0ELb0ELi6E", "ILb0ELb1ELb0ELb0ELi6E")
+TAGS_W6 = ("ILb0ELb0ELb0ELb0ELi6E", "ILb0ELb1ELb0ELb0ELi6E", "ILb0ELb0ELb1ELb0ELi6E", "ILb0ELb1ELb1ELb0ELi6E")
 
 
 def test_production_kernels_do_not_spill(compiled):
@@ -243,7 +243,7 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
 # Re-record (after a deliberate kernel change): python tests/test_kernel_resources.py
 # ---------------------------------------------------------------------------------------------------------------------
 HEADLINE = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb0ELb0ELi6EEEvNS_10UpdateArgsE"    # the fused step, three per CU
-RECORDED = {"code_bytes": 160224, "instructions": 30674, "valu": 17603}
+RECORDED = {"code_bytes": 167212, "instructions": 31797, "valu": 17810}
 
 
 def static_profile(asm, sizes):
