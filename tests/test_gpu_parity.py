@@ -183,6 +183,28 @@ def test_update_clustered_merge_stress():
     assert st["max_survivors"] > 400
 
 
+def test_more_clusters_than_one_sweep_of_the_moment_sums():
+    """The accumulators of the exact moment sums share LDS with everything that is dead after the rounds: room for 384
+    clusters at 1024 survivor slots / map capacity 512 (csrc/phd_lds_layout.h).  A map of 470 landmarks with a merge distance
+    of 3 leaves ~440 clusters: the sums take a second sweep over the survivors, and the result is still the oracle's."""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(3, 470, 24, seed=41)
+    st = check_update_against_oracle(P.default_config(minSeparation=3.0), w, w["z"][0], cap=512, min_structural=0.3)
+    assert 384 < st["max_map"] <= 512, st
+
+
+def test_headline_filters_sit_three_per_cu():
+    """4096 x 256 x 64 (map capacity 512, 1024 survivor slots): the runtime's own count of resident workgroups, PHD and CPHD —
+    what the round-4 LDS layout and the 80-register instantiations are for; a filter of 256 particles keeps the two-per-CU build"""
+    P, S = pkg(), synthetic()
+    for ft, n, want in ((0, 4096, 3), (1, 4096, 3), (0, 256, 2)):
+        cfg = P.default_config(filterType=ft, maxCardinality=255)
+        with P.PhdFilter(cfg, n_particles=n, map_capacity=512, max_measurements=64) as f:
+            r = f.residency()
+            assert r["workgroups_per_cu"] == want, (ft, n, r)
+            assert 3 * (r["lds_bytes"] + 1024) <= 160 * 1024, r
+
+
 def test_update_max_measurements_and_full_map():
     """M = 256 (the reference's cap) and a map that fills its slab"""
     P, S = pkg(), synthetic()
