@@ -93,9 +93,11 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
     // The lanes of a wave add to the clusters of their survivors — arbitrary indices c: in a plane those fall on bank pair
     // c mod 32, all 32 in use; the record-per-cluster layout (48 B apart) left 16 of them, every atomic at least four-deep in
     // its banks — and LDS atomics are what this routine costs (the resident workgroups share the pipeline).
+    // (the sums themselves are 64-bit INTEGERS — fx_i64() — added with ds_add_u64; plane 3 carries W as a double in pass B)
     LDS_T(double)* const accd = (LDS_T(double)*)acc;
     LDS_T(u32)* const acc32 = (LDS_T(u32)*)acc;
-    LDS_T(double)* const p0 = accd, * const p1 = accd + K, * const p2 = accd + 2 * K, * const p3 = accd + 3 * K, * const p4 = accd + 4 * K;
+    LDS_T(i64)* const p0 = acc, * const p1 = acc + K, * const p2 = acc + 2 * K, * const p3 = acc + 3 * K, * const p4 = acc + 4 * K;
+    LDS_T(double)* const p3d = accd + 3 * K;
     LDS_T(u32)* const w4 = acc32 + 8 * K;                       // plane 4 as words: (mean x, mean y) in pass B
     LDS_T(u32)* const w5 = acc32 + 10 * K;                      // plane 5 as words: (largest exponent | scales, flags)
     for (int t = tid; t < 3 * K; t += PHD_T) ((LDS_T(v4f)*)acc)[t] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -120,11 +122,11 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         }
         FxSumsD fs;
         fx_first_d(fs, Fw, sa.x, sa.y, a.w, a.x, a.y, b.x, b.y, b.z);
-        __hip_atomic_fetch_add(p0 + c, fs.W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p1 + c, fs.xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p2 + c, fs.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p3 + c, fs.yh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p4 + c, fs.yl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p0 + c, fx_i64(fs.W), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p1 + c, fx_i64(fs.xh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p2 + c, fx_i64(fs.xl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p3 + c, fx_i64(fs.yh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p4 + c, fx_i64(fs.yl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_max(&w5[2 * c], (u32)fs.ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!fs.ok) __hip_atomic_fetch_or(&w5[2 * c + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -133,7 +135,7 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
     // per cluster: W, mean (:2828), the stop rule (:2821); the planes are re-armed for pass B
     for (int c = tid; c < K; c += PHD_T) {
         FxSumsD fs;
-        fs.W = p0[c]; fs.xh = p1[c]; fs.xl = p2[c]; fs.yh = p3[c]; fs.yl = p4[c];
+        fs.W = (double)p0[c]; fs.xh = (double)p1[c]; fs.xl = (double)p2[c]; fs.yh = (double)p3[c]; fs.yl = (double)p4[c];   // (below 2^53: exact)
         const u32 ec = w5[2 * c], fl = w5[2 * c + 1];
         const bool ok = !(fl & 1u) && ec < 255u, selfok = !(fl & 2u);
         const int Fw = (int)((fl >> 8) & 0xFFu);
@@ -145,8 +147,8 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         float W, mx, my;
         fx_mean_d(fs, Fw, W, mx, my);
         const int Fc = fx_cov_anchor(Fw, (int)ec);
-        p0[c] = 0.0; p1[c] = 0.0; p2[c] = 0.0;
-        p3[c] = fs.W;
+        p0[c] = 0; p1[c] = 0; p2[c] = 0;
+        p3d[c] = fs.W;
         w4[2 * c] = __float_as_uint(mx); w4[2 * c + 1] = __float_as_uint(my);
         w5[2 * c] = (u32)Fc | ((u32)Fw << 16);
         w5[2 * c + 1] = (ok ? 0u : 1u) | (fl & 2u);
@@ -169,15 +171,15 @@ __device__ __forceinline__ void moment_sums(const LDS_T(v4f)* recA, const LDS_T(
         bool ok = true;
         double qxx, qxy, qyy;
         fx_cov_terms_d((int)(sc & 0xFFFFu), hm.x, hm.y, a.w, a.x, a.y, b.x, b.y, b.z, qxx, qxy, qyy, ok);
-        __hip_atomic_fetch_add(p0 + c, qxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p1 + c, qxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p2 + c, qyy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p0 + c, fx_i64(qxx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p1 + c, fx_i64(qxy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p2 + c, fx_i64(qyy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!ok) __hip_atomic_fetch_or(&w5[2 * c + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     // per cluster: covariance = sum / W (:2879; the symmetric form needs no force_symmetric_covariance)
     for (int c = tid; c < K; c += PHD_T) {
-        const double cxx = p0[c], cxy = p1[c], cyy = p2[c], Wq = p3[c];
+        const double cxx = (double)p0[c], cxy = (double)p1[c], cyy = (double)p2[c], Wq = p3d[c];
         const u32 sc = w5[2 * c];
         const int Fc = (int)(sc & 0xFFFFu), Fw = (int)(sc >> 16);
         if (w5[2 * c + 1] & 1u) {
