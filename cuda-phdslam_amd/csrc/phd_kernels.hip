@@ -189,13 +189,16 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     const SpillRef sp = {SPILL ? A.spill_rec + (size_t)p * 2 * A.spill_cap * 8 : nullptr, SPILL ? A.spill_cap : 0};
     if (SPILL && tid == 0) A.spill_meta[(size_t)p * 8] = 0;
     phd_pose pose = A.pose[p];
-    if (A.do_predict) {
-        // fused vehicle predict: every lane computes the same pose (no broadcast needed); lane 0 stores it after the
-        // first barrier — a live filter predicts in place, and every lane must have read the prior pose by then
+    if (A.do_predict && wave == 0) {
+        // fused vehicle predict: ONE wave computes the pose (a tangent, a sine / cosine pair, the generator: ~200 vector
+        // instructions — seven more copies of them were 5 % of the workgroup's instructions when every lane computed its own)
+        // and leaves it in LDS for the others, who pick it up behind the first barrier; lane 0 stores it to HBM there — a live
+        // filter predicts in place, and every lane must have read the prior pose by then
         float n_alpha, n_encoder;
         if (A.noise) { n_alpha = A.noise[p].n_alpha; n_encoder = A.noise[p].n_encoder; }
         else draw_noise(A.seed, A.counter, p, cfg, n_alpha, n_encoder);
         pose = predict_pose(pose, A.control, n_alpha, n_encoder, cfg);
+        if (lane == 0) { L.red[0] = pose.px; L.red[1] = pose.py; L.red[2] = pose.ptheta; }
     }
     u64* st = STAMPS ? (A.stamps + (size_t)p * PHD_STAMP_ROW) : nullptr;
     u64 cq[5] = {0, 0, 0, 0, 0};
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     }
     __syncthreads();
     // every thread holds the prior pose and src by now
+    if (A.do_predict) { pose.px = L.red[0]; pose.py = L.red[1]; pose.ptheta = L.red[2]; pose.vx = 0.f; pose.vy = 0.f; pose.vtheta = 0.f; }
     if (tid == 0) {
         if (A.do_predict) {
             if (FUSEW) { // handed to the weights workgroup: agent-scope (sc1) stores

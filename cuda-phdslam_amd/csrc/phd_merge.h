@@ -606,9 +606,12 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         if (STAMPS && tid == 0) tq1 = __builtin_amdgcn_s_memrealtime();
         // (2) seeds: s_k = not exists l < k : close(k,l) and s_l.  The recursion is well founded, so the
         //     parallel iteration s <- F(s) reaches its unique fixed point (position k is final after k+1
-        //     sweeps; in practice a handful).  Every wave computes the same mask.
-        u64 seeds;
-        {
+        //     sweeps; in practice a handful).  ONE wave resolves it and writes the round's seed records (3); the others wait at a
+        //     barrier and read the mask.  (Rounds 1-3 had every wave compute the same mask and write the same records to save
+        //     that barrier — right while the kernel was latency-bound; with three workgroups per CU the vector ALUs issue 89 % of
+        //     the cycles and seven redundant copies of ~70 instructions per round cost more than the barrier: +1.5 %.)
+        u64 seeds = 0ull;
+        if (wave == 0) {
             u64 row = 0;
 #pragma unroll
             for (int wv = 0; wv < PHD_NW; ++wv) row |= (u64)L.part[wv * 64 + lane] << (PHD_COLS * wv);
@@ -629,14 +632,14 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         }
         if (STAMPS && tid == 0) tq2 = __builtin_amdgcn_s_memrealtime();
         // (3) the survivors after the window.  The round's SEEDS (typically 40 of the 64 candidates) are listed in
-        //     order as records (-2 mx, -2 my, E, window index); every wave writes the same list (identical values), so
-        //     it needs no barrier before reading it back.  The listed survivors are dealt to the waves in blocks of 64,
+        //     order as records (-2 mx, -2 my, E, window index) by wave 0.  The listed survivors are dealt to the waves in blocks of 64,
         //     one survivor per lane: the lane tests its survivor against ALL seeds (records by LDS broadcast, two seeds
         //     per packed operation, the sign bit of E_s + E_e - 2 ms.me shifted into a 64-bit mask whose ascending bits
         //     are ascending seed order) and, in the same pass, takes the exact decision on the marked seeds until the
         //     first hit.  One trip through LDS per survivor and round.
-        const int nseeds = __popcll(seeds);
-        {
+        if (wave == 0) {
+            if (lane == 0) ((LDS_T(u64)*)L.red)[0] = seeds;    // (the reduction scratch is idle during the merge)
+            const int nseeds = __popcll(seeds);
             const int rank = __popcll(seeds & lanemask_lt());
             if ((seeds >> lane) & 1ull) {
                 const int pr = 4 * (rank >> 1) + (rank & 1);
@@ -650,9 +653,15 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
                 sPf[pr] = INFINITY; sPf[pr + 2] = 0.f; sQf[rp] = 0.f;
             }
         }
+        __syncthreads();
+        {
+            const u64 sv = ((LDS_T(u64)*)L.red)[0];
+            seeds = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)sv);
+        }
+        const int nseeds = __popcll(seeds);
         const int per = (nrest + PHD_T - 1) / PHD_T;           // entries per thread
         RSTAMP(2);
-        kbase += nseeds;                                        // (uniform: every wave computes the same seed mask)
+        kbase += nseeds;                                        // (uniform: every wave read the same seed mask)
         int kept = 0;
         u32 keepbits = 0;                                       // bit q: this thread's q-th entry stays listed
 #ifdef PHD_DUP_ASSIGN
