@@ -241,8 +241,15 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     //      normalisers are known — the lanes are idle here anyway, and LDS has no room for them (phd_lds.h)
     float bg_mx = 0.f, bg_my = 0.f, bg_xx = 0.f, bg_xy = 0.f, bg_yy = 0.f;
     static_assert(PHD_MAX_MEASUREMENTS <= PHD_T, "one birth per thread");
+    // (PHD: the LAST waves take the births — thread 448 + m at up to 64 measurements: wave 0 has the predict and the hand-off, and at a
+    //  few hundred particles a workgroup's critical path is the step (61.2 k -> 62.2 k steps/s at 256 x 64 x 32); same lanes as if wave
+    //  0 took them, so the reduction of sum_m log Z_m adds the same numbers in the same order.  CPHD: the first waves — the last one
+    //  finishes the CPHD block last (2 596 against 2 537 steps/s))
+    const int birth_m = CPHD ? tid : tid - (PHD_T - 64 * ((M + 63) >> 6));
+    const bool birth_thread = birth_m >= 0 && birth_m < M;
 #ifndef PHD_EXP_BG_LATE
-    if (tid < M) birth_geometry(pose, L.z_r[tid], L.z_b[tid], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
+    if (CPHD) { if (tid < M) birth_geometry(pose, L.z_r[tid], L.z_b[tid], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy); }
+    else if (birth_thread) birth_geometry(pose, L.z_r[birth_m], L.z_b[birth_m], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
 #endif
 
     // ---- classification + per-feature EKF terms -----------------------------------------------
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #ifdef PHD_EXP_BG_LATE
             if (keep) birth_geometry(pose, L.z_r[m], L.z_b[m], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
 #endif
-            if (keep) store_survivor(L, slot, S_cap, wb, bg_mx, bg_my, bg_xx, bg_xy, bg_yy, n_in + M * n_in + m, sp, bm);   // (m = tid)
+            if (keep) store_survivor(L, slot, S_cap, wb, bg_mx, bg_my, bg_xx, bg_xy, bg_yy, n_in + M * n_in + m, sp, bm);
         }
         // missed detections of the in-range features: w (1 - pd) r1 (.bak:1445-1460)
         for (int j0 = 0; j0 < n_in; j0 += PHD_T) {
@@ -386,7 +393,8 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         }
         // (the particle's log-weight increment, log <Y0,p>, .bak:2661-2667, is handed over after pass 2 — see there)
     } else {
-    for (int m = tid; m < M; m += PHD_T) {
+    if (birth_thread) {
+        const int m = birth_m;
         float sum = pass1_feature_sum(L, p1g, m, M);
         sum += cfg.clutterDensity;                                                                    // :2213
         sum += cfg.birthWeight;                                                                       // :2214
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #ifdef PHD_EXP_BG_LATE
         if (keep) birth_geometry(pose, L.z_r[m], L.z_b[m], cfg, bg_mx, bg_my, bg_xx, bg_xy, bg_yy);
 #endif
-        if (keep) store_survivor(L, slot, S_cap, wb, bg_mx, bg_my, bg_xx, bg_xy, bg_yy, n_in + M * n_in + m, sp, bm);       // (m = tid)
+        if (keep) store_survivor(L, slot, S_cap, wb, bg_mx, bg_my, bg_xx, bg_xy, bg_yy, n_in + M * n_in + m, sp, bm);
     }
     {
         float lz_sum, pdw;
