@@ -4,7 +4,8 @@
 //   phd_defs.h     workgroup shape (PHD_NW = 8 waves, 512 threads), typedefs, the LDS pointer qualifier
 //   phd_lane.h     cross-lane exchange (DPP / v_permlane*_swap), wave and workgroup reductions and scans
 //   phd_math.h     EKF terms per feature, Joseph covariance, Mahalanobis / Hellinger distance
-//   phd_lds.h      LDS layout of the update kernel, counters, survivor slot allocation
+//   phd_lds.h      LDS pointers of the update kernel, counters, survivor slot allocation (byte layout: phd_lds_layout.h — sized
+//                  for THREE workgroups per CU at 4096 x 256 x 64)
 //   phd_sort.h     the merge's first sort: counting sort on the weight key, rank by counting, register bitonic network
 //   phd_merge.h    exact closeness decision, merge_small (<= 256 survivors, one shot), merge rounds, grouping, moments
 //   phd_predict.h  Ackerman predict, counter-based noise generator
@@ -26,9 +27,13 @@
 // components never leave registers unless they survive pruning, survivors live in LDS, and HBM
 // sees only the map read, the map write and a few bytes per particle.
 //
-// Lane mapping of the two (feature x measurement) passes: lanes <-> measurements, waves <->
-// feature slices, so the per-measurement sum over features is a private accumulator — no
-// cross-lane reduction in the inner loop (one shuffle tree per wave at the very end).
+// Lane mapping of pass 1: lanes <-> features, a wave's chunk of 8 measurements in registers (phd_pass1.h), so the
+// per-measurement sums over features are private accumulators — no LDS traffic and no cross-lane step in the inner
+// loop (one transposing reduction per chunk at the end).  Pass 2 visits the listed terms one per thread.
+//
+// Residency: the kernel is latency-bound per workgroup, so what a CU holds at a time is most of the throughput.  Two builds of
+// the template (launch bound MINW): 4 waves per SIMD = two workgroups per CU, 6 = three (80 VGPRs, a small scratch frame that
+// stays out of the hot loops); launch_update_merge picks by the filter's LDS bytes and the launch's size.
 //
 // Merge: exact greedy semantics (seed = max weight, ties -> lowest slab index; absorb d < T); see phd_merge.h.
 // A conservative trace bound (d >= 2|dm|^2/(tr Pa + tr Pb)) rejects far pairs before the exact
