@@ -243,7 +243,7 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
 # Re-record (after a deliberate kernel change): python tests/test_kernel_resources.py
 # ---------------------------------------------------------------------------------------------------------------------
 HEADLINE = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb0ELb0ELi6EEEvNS_10UpdateArgsE"    # the fused step, three per CU
-RECORDED = {"code_bytes": 168788, "instructions": 32057, "valu": 18055}
+RECORDED = {"code_bytes": 169832, "instructions": 32268, "valu": 18122}
 
 
 def static_profile(asm, sizes):
