@@ -183,8 +183,9 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
         // the atomic and the loop's set-up are paid once per chunk (at 256 in-range features: once instead of four times).
         constexpr int GPF = 32 / CH;                              // feature groups per flush
         u32 pend = 0;                                             // bit (slot * CH + q): measurement q of the chunk, group `slot` since the flush
-        int jb0 = fg * 64, slot = 0;                              // first group of the pending bits
-        auto flush = [&]() {
+        int slot = 0;
+        const int jstep = g.NF * 64;
+        auto flush = [&](int jb0) {                               // jb0: first group of the pending bits
             const int np = __popc(pend);
             const int incl = (int)wave_incl_scan((u32)np);
             const int tot = __builtin_amdgcn_readlane(incl, 63);
@@ -196,13 +197,14 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
                     const int b = __builtin_ctz(pend);
                     pend &= pend - 1;
                     const int q = b & (CH - 1), sl = b / CH;
-                    if (pos < PHD_CAND_CAP) clist[pos] = (u16)((c + q * mstep) * n_in + (jb0 + sl * g.NF * 64 + lane));
+                    if (pos < PHD_CAND_CAP) clist[pos] = (u16)((c + q * mstep) * n_in + (jb0 + sl * jstep + lane));
                     ++pos;
                 }
             }
             pend = 0;
         };
-        for (int jb = fg * 64; jb < n_in; jb += g.NF * 64) {
+        int jb = fg * 64;
+        for (; jb < n_in; jb += jstep) {
             const int j = jb + lane;
             const int jj = j < n_in ? j : n_in - 1;
             const v4f fa = L.f_a[jj];
@@ -212,12 +214,11 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
                              : fast                          ? pass1_octet<true, CH>(zr, zb, vm, fa, fc, c0m, acc)
                                                              : pass1_octet<false, CH>(zr, zb, vm, fa, fc, c0m, acc);
             if (sparse2) {
-                if (slot == 0) jb0 = jb;
                 pend |= bits << (slot * CH);
-                if (++slot == GPF) { flush(); slot = 0; }         // (uniform)
+                if (++slot == GPF) { flush(jb - (GPF - 1) * jstep); slot = 0; }   // (uniform)
             }
         }
-        if (sparse2 && slot) flush();
+        if (sparse2 && slot) flush(jb - slot * jstep);
         float tot;
         int m;
         if (CH == 8) { tot = reduce8_over_wave((float (&)[8])acc, lane); m = c + (lane >> 3) * mstep; }
