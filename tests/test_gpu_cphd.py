@@ -57,7 +57,9 @@ def make(cfg, w, cap=None, mm=64):
     return f
 
 
-@pytest.mark.parametrize("N,G,M,nmax,seed", [(12, 24, 10, 63, 1), (8, 48, 33, 255, 2), (6, 16, 70, 127, 3)])
+# (the last case: a long cardinality distribution on a small filter — the CPHD block's arrays do not fit the idle survivor planes
+#  behind the sweep rows and take the space behind the common LDS layout instead, csrc/phd_cphd.h cphd_block_in_planes)
+@pytest.mark.parametrize("N,G,M,nmax,seed", [(12, 24, 10, 63, 1), (8, 48, 33, 255, 2), (6, 16, 70, 127, 3), (6, 8, 8, 1023, 4)])
 def test_cphd_update_matches_oracle(N, G, M, nmax, seed):
     P, S = pkg(), synthetic()
     cfg = P.default_config(filterType=1, maxCardinality=nmax)
