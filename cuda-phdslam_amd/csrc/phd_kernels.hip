@@ -43,6 +43,7 @@
 
 #include <mutex>
 #include <set>
+#include <map>
 #include <atomic>
 
 #include "phd_defs.h"
@@ -1074,6 +1075,26 @@ static int device_cu_count()
     return n;
 }
 
+// Does the runtime grant the 80-register instantiation `fn` three workgroups per CU at this LDS size?  (The arithmetic below says
+// so for a CU with 160 KiB of LDS handed out in small granules; a device or driver that rounds differently would leave two — and
+// the 80-register build without its reason.)  Asked once per device, function and size.
+static bool three_granted(int fn, size_t lds_bytes)
+{
+    struct Key { int dev, fn; size_t lds; bool operator<(const Key& o) const { return dev != o.dev ? dev < o.dev : fn != o.fn ? fn < o.fn : lds < o.lds; } };
+    static std::mutex mu;
+    static std::map<Key, bool> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> g(mu);
+    const Key k{dev, fn, lds_bytes};
+    auto it = seen.find(k);
+    if (it != seen.end()) return it->second;
+    int n = 0;
+    const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_update_fns[fn], PHD_T, lds_bytes) == hipSuccess && n >= 3;
+    seen[k] = ok;
+    return ok;
+}
+
 static int update_fn_index(const UpdateArgs& a, size_t lds_bytes, int n_particles)
 {
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
@@ -1081,7 +1102,8 @@ static int update_fn_index(const UpdateArgs& a, size_t lds_bytes, int n_particle
     // the 80-register build pays ~2 % (and more on the critical path of a lone workgroup) for the right to a third resident
     // workgroup: only where LDS admits three AND the launch has more than two workgroups per CU to place
     const bool three = !sp && 3 * (lds_bytes + 1024) <= 160 * 1024 && n_particles > 2 * device_cu_count();
-    if (three) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
+    const int fn3 = (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
+    if (three && three_granted(fn3, lds_bytes)) return fn3;
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }
 
