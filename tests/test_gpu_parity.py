@@ -205,6 +205,31 @@ def test_headline_filters_sit_three_per_cu():
             assert 3 * (r["lds_bytes"] + 1024) <= 160 * 1024, r
 
 
+def test_two_and_three_per_cu_builds_agree_bit_for_bit():
+    """the same particles through both builds of the update kernel: 640 particles launch the 80-register instantiation (three
+    workgroups per CU: more than two per CU to place), their first 320 alone the 107-register one — maps, survivor lists and
+    log-weight increments of those 320 equal bit for bit (PHD and CPHD)"""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(640, 48, 24, seed=43, clustered=True)
+    half = {k: (v[:320] if isinstance(v, np.ndarray) and v.shape[:1] == (640,) else v) for k, v in w.items()}
+    half["N"] = 320
+    for ft in (0, 1):
+        cfg = P.default_config(filterType=ft, maxCardinality=63)
+        out = []
+        for ww, want in ((w, 3), (half, 2)):
+            with make_filter(cfg, ww, cap=128, mm=32) as f:
+                assert f.residency()["workgroups_per_cu"] == want, f.residency()
+                f.debug(True)
+                f.update(ww["z"][0])
+                out.append((f.get_maps(), f.weight_increments(), [f.survivors(p) for p in (0, 7, 319)]))
+        (ma, da, sa), (mb, db, sb) = out
+        for p in range(320):
+            assert np.array_equal(ma[p].view(np.uint8), mb[p].view(np.uint8)), (ft, p)
+        assert np.array_equal(da[:320].view(np.uint32), db.view(np.uint32)), ft
+        for (xa, ia), (xb, ib) in zip(sa, sb):
+            assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), ft
+
+
 def test_update_max_measurements_and_full_map():
     """M = 256 (the reference's cap) and a map that fills its slab"""
     P, S = pkg(), synthetic()
