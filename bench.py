@@ -30,9 +30,10 @@ Prints ONE JSON line (rank 0) with
                   average duration (HIP events on the filter's stream), against the 8 TB/s HBM peak.  The kernel
                   never materialises the update components, so this is bookkeeping, not efficiency — `traffic`
                   (PMC, with its source file and date) is what actually crosses the HBM interface;
-  `roofline_valu` what bounds the kernel in fact: VALU issue.  Issue fraction from the SQ counter pass kept under
-                  profiles/ (source and date labelled), algorithmic flops of §8d / kernel time against the
-                  157.3 TFLOP/s fp32 vector peak;
+  `roofline_valu` how busy the SIMDs are: the issue figure of the SQ counter pass kept under profiles/ (source and date
+                  labelled) against the MEASURED ceiling of the same formula (profiles/valu_ceiling.json, round 5: 1.91 —
+                  a SIMD issues one wave64 instruction per 2.1 cycles), algorithmic flops of §8d / kernel time against
+                  the 157.3 TFLOP/s fp32 vector peak;
   `cpu_baseline`  the CPU oracle timed on the host cores on a bounded sample of the same workload (rank 0, N = 1):
                   CPU model, single-thread and best-thread rates.
 """
@@ -244,15 +245,15 @@ def roofline_entries(P, S, cfg_id, N, G, M, ker_ms, pair_ms, gpu_ms_per_step, co
             traffic = tj.get("hbm_bytes_per_launch")
     # "bound": the roofline the contract's figures are quoted against (HBM, `achieved` / `peak` in GB/s);
     # "bound_in_fact": what the counters say limits the kernel (roofline_valu)
-    roof = {"bound": "hbm", "bound_in_fact": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "bound_in_fact": "latency (barriers, single-wave phases, LDS round trips) at about half of the measured VALU issue ceiling", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_compulsory": (b_min / ker_s / 1e9 / HBM_PEAK_GBS) if ker_s > 0 else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "note": "`frac` is the contract figure of SURVEY.md 8d: ALGORITHMIC bytes (every update component written once and read "
                     "once) / kernel time / 8 TB/s.  The fused kernel prunes before it stores, so those components never reach HBM "
                     "and `frac` may exceed 1: it carries no efficiency information.  `frac_compulsory` = compulsory bytes (map in + "
-                    "map out + 32 B per particle) / kernel time / 8 TB/s is what the HBM interface must carry; the kernel is bound "
-                    "by VALU issue, see roofline_valu",
+                    "map out + 32 B per particle) / kernel time / 8 TB/s is what the HBM interface must carry; the kernel issues "
+                    "about half of what the SIMDs sustain and waits the rest of the time, see roofline_valu",
             "kernel": "phd_update_merge_kernel", "kernel_avg_us": 1e3 * ker_ms,
             "kernel_avg_us_event_pairs": 1e3 * pair_ms, "gpu_region_ms_per_step": gpu_ms_per_step,
             "algorithmic_bytes_per_launch": b_step, "compulsory_bytes_per_launch": b_min,
@@ -263,14 +264,34 @@ def roofline_entries(P, S, cfg_id, N, G, M, ker_ms, pair_ms, gpu_ms_per_step, co
     flops = algorithmic_flops(N, G, M)
     tfl = flops / ker_s / 1e12 if ker_s > 0 else 0.0
     sq, sq_src = load_profile_json("pmc_sq_cfg%d.json" % cfg_id, build_id)
-    valu = {"bound": "valu-issue", "achieved": None, "peak": 1.0, "unit": "fraction of VALU issue cycles", "frac": None,
+    # the ceiling the issue figure is quoted against is MEASURED (round 5): tools/probes/valu_issue_probe.hip saturates a SIMD
+    # with independent full-rate vector instructions and reads the same counters with the same formula — 1.91, not 1.0: a
+    # SIMD sustains one wave64 instruction per 2.1 cycles once two waves interleave, a lone wave one per 4.2
+    # (profiles/r05_valu_ceiling.txt).  `achieved` / `peak` are the formula's readings, `frac` their quotient;
+    # `valu_instructions_per_cycle_per_simd` the same in instructions (peak: the probe's 0.477)
+    ceil = None
+    try:
+        ceil = json.load(open(os.path.join(ROOT, "profiles", "valu_ceiling.json")))
+    except Exception:
+        pass
+    peak = ceil["formula_reading_at_saturation"] if ceil else None
+    valu = {"bound": "valu-issue", "achieved": None, "peak": peak, "unit": "4 * SQ_ACTIVE_INST_VALU / SIMD-cycles (tools/pmc_sq.sh)",
+            "frac": None, "peak_source": (ceil or {}).get("source"),
+            "peak_note": "measured on a saturating stream of independent FULL-RATE vector instructions; packed fp32, DPP, 64-bit and "
+                         "32-bit-multiply instructions issue at half that rate (formula ceiling %.2f), so `frac` is a LOWER bound "
+                         "of the SIMDs' busy share" % ceil["half_rate_formula_reading"] if ceil else None,
             "source": sq_src, "algorithmic_flops_per_launch": flops, "algorithmic_tflops": tfl,
             "frac_of_fp32_vector_peak": tfl / FP32_VECTOR_PEAK_TFLOPS,
             "fp32_vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS}
     if sq:
-        valu["achieved"] = valu["frac"] = sq.get("valu_issue_fraction")
+        valu["achieved"] = sq.get("valu_issue_fraction")
+        valu["frac"] = (valu["achieved"] / peak) if (peak and valu["achieved"] is not None) else None
         valu["counters_per_launch"] = {k: sq[k] for k in sq if k.startswith("SQ_") or k.startswith("GRBM_")}
         valu["kernel_avg_us_in_counter_pass"] = sq.get("kernel_avg_us")
+        if ceil and sq.get("kernel_shader_cycles") and sq.get("SQ_INSTS_VALU"):
+            ipc = sq["SQ_INSTS_VALU"] / (4.0 * ceil["cus"] * sq["kernel_shader_cycles"])
+            valu["valu_instructions_per_cycle_per_simd"] = ipc
+            valu["valu_instructions_per_cycle_per_simd_peak"] = ceil["full_rate_ipc_per_simd"]
     return roof, valu
 
 
@@ -555,7 +576,11 @@ def verify_cpp_multi(P, S, MM, devices, exchange, cap, mm):
     w["logw"] = (lw - np.float32(np.log(np.exp(lw.astype(np.float64)).sum()))).astype(np.float32)
     cfg = P.default_config(n_particles=N, resampleThresh=0.6)
     force = [True, False, True, True]
-    out = {"equal_to_single_filter": False, "particles": N, "steps": steps, "devices": list(devices)}
+    # "exchange" is set BEFORE the create: a create that fails (PULL without peer access, an RCCL bootstrap time-out) must leave
+    # the caller its fall-back decision, not a KeyError
+    requested = {MM.EXCHANGE_ALLTOALL: "alltoall", MM.EXCHANGE_GATHERED: "gathered", MM.EXCHANGE_PULL: "pull"}.get(exchange, "auto")
+    out = {"equal_to_single_filter": False, "particles": N, "steps": steps, "devices": list(devices), "exchange": requested,
+           "exchange_requested": requested}
     try:
         with P.PhdFilter(cfg, n_particles=N, map_capacity=cap, max_measurements=mm, device=devices[0]) as f, \
                 MM.MultiFilter(cfg, n_shards=k, devices=list(devices), map_capacity=cap, max_measurements=mm, exchange=exchange,
@@ -605,7 +630,7 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
     # the exchange the timed run will use (the PULL form reads peers' memory directly and had only ever run with all shards on
     # one GPU when this was written); if it does not, the host-planned all-to-all is verified and used instead, and the line says so
     verified = verify_cpp_multi(P, S, MM, devices, ex, 2 * G, M)
-    if not verified["equal_to_single_filter"] and verified["exchange"] != "alltoall":
+    if not verified["equal_to_single_filter"] and verified.get("exchange") != "alltoall":
         second = verify_cpp_multi(P, S, MM, devices, MM.EXCHANGE_ALLTOALL, 2 * G, M)
         second["fell_back_from"] = verified
         verified = second

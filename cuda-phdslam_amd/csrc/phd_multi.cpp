@@ -112,7 +112,7 @@ int t_mark(phd_multi* m, int phase)
     return PHD_OK;
 }
 // end of a step: all shards drained, spans accumulated (the timing pass synchronises every step; the timed loop does not run it)
-int t_finish(phd_multi* m)
+int t_finish(phd_multi* m, bool count_step = true)
 {
     if (!m->timing) return PHD_OK;
     for (auto& s : m->sh) {
@@ -124,7 +124,7 @@ int t_finish(phd_multi* m)
         HIPCHK(hipEventElapsedTime(&ms, m->tev[k - 1], m->tev[k]));
         m->t_us[m->tphase[k]] += 1e3 * (double)ms;
     }
-    if (m->tmark > 1) m->t_steps += 1;
+    if (m->tmark > 1 && count_step) m->t_steps += 1;
     m->tmark = 0;
     return PHD_OK;
 }
@@ -860,28 +860,39 @@ extern "C" int phd_multi_expected_map(phd_multi* m, phd_gaussian2d* out, int cap
 // phdUpdateSynth + the global weight normalisation (every shard adopts its slice; the global nEff lands in the step report);
 // phd_multi_resample = resampleParticles over the global set (the caller decides: nEff <= threshold and the step had
 // measurements, :1286)
+// The staged calls keep their own phase marks: each call starts from an empty mark list and closes it (the timing pass
+// synchronises, like phd_multi_step_resident's), so a run of update / resample calls with timing on never fills the list.
+// A step is counted by the update; the resample of the same step only adds its spans.
 extern "C" int phd_multi_update(phd_multi* m, const phd_ackerman_control* u, const phd_ackerman_noise* noise,
                                 const phd_measurement* z, int n_meas)
 {
     CHECK_M(m);
     PHDCHK(phd_multi_upload_inputs(m, noise, z, n_meas));
     PHDCHK(peer_wait_consumed(m));
+    m->tmark = 0;
+    PHDCHK(t_mark(m, 0));
     m->scratch_current = false;
     if (m->n_meas <= 0) {
         if (u) for (auto& s : m->sh) {
             if (m->kpred > 1) PHDCHK(phd_predict_ackerman_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr));
             else PHDCHK(phd_step_local_dev(s.f, *u, m->have_noise ? s.d_noise : nullptr, s.d_z, 0));
         }
-        return PHD_OK;
+        PHDCHK(t_mark(m, PHD_MULTI_PHASE_LOCAL_STEP));
+        return t_finish(m);
     }
     PHDCHK(update_stage(m, u));
     for (int k = m->world - 1; k >= 0; --k) PHDCHK(phd_global_normalize(m->sh[k].f, m->sh[k].allw, m->world * ncur(m), nullptr));
     m->scratch_current = true;
-    return PHD_OK;
+    PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
+    return t_finish(m);
 }
 
 extern "C" int phd_multi_resample(phd_multi* m, double uniform)
 {
     CHECK_M(m);
-    return resample_stage(m, uniform, false);
+    m->tmark = 0;
+    PHDCHK(t_mark(m, 0));
+    const int rc = resample_stage(m, uniform, false);
+    if (rc != PHD_OK) { m->tmark = 0; return rc; }
+    return t_finish(m, false);
 }

@@ -25,6 +25,80 @@
 
 #define O_LOG0 (-FLT_MAX) /* src/slamtypes.h:26 */
 
+/* ------------------------------------------------------------------------------------ */
+/* per-thread scratch (round 5).  One particle's update used a dozen malloc/free pairs —   */
+/* 0.9 MB of them at 4096 x 256 x 64 — INSIDE the OpenMP loop over particles: above glibc's */
+/* mmap threshold that is an mmap/munmap pair and a fresh set of page faults per particle, */
+/* serialised on the process's address-space lock.  The work arrays now come from a        */
+/* thread-local stack that is kept between particles (frames: o_tmp_enter / o_tmp_leave;   */
+/* blocks are chained while a frame is open and merged into one when the stack empties).   */
+/* Memory only: no arithmetic is touched, the outputs are bit for bit what they were.      */
+/* ------------------------------------------------------------------------------------ */
+#define O_TMP_BLOCKS 24
+typedef struct { char* p; size_t cap, top; } o_tmp_block;
+static _Thread_local o_tmp_block o_tmp_blk[O_TMP_BLOCKS];
+static _Thread_local int o_tmp_cur = 0;               /* block in use */
+
+o_tmp_frame o_tmp_enter(void)
+{
+    o_tmp_frame f = { o_tmp_cur, o_tmp_blk[o_tmp_cur].top };
+    return f;
+}
+
+void* o_tmp_alloc(size_t bytes)
+{
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes == 0) bytes = 64;
+    o_tmp_block* b = &o_tmp_blk[o_tmp_cur];
+    if (b->p && b->top + bytes <= b->cap) { void* r = b->p + b->top; b->top += bytes; return r; }
+    /* next block: at least twice everything held so far (so the chain stays short) */
+    size_t held = 0;
+    for (int i = 0; i <= o_tmp_cur; i++) held += o_tmp_blk[i].cap;
+    int k = b->p ? o_tmp_cur + 1 : o_tmp_cur;
+    if (k >= O_TMP_BLOCKS) return NULL;
+    size_t want = bytes > 2 * held ? bytes : 2 * held;
+    if (want < ((size_t)1 << 16)) want = (size_t)1 << 16;
+    o_tmp_block* nb = &o_tmp_blk[k];
+    if (nb->cap < want) {
+        free(nb->p);
+        nb->p = (char*)aligned_alloc(64, want);
+        nb->cap = nb->p ? want : 0;
+        if (!nb->p) return NULL;
+    }
+    nb->top = bytes;
+    o_tmp_cur = k;
+    return nb->p;
+}
+
+void o_tmp_leave(o_tmp_frame f)
+{
+    o_tmp_cur = f.block;
+    o_tmp_blk[f.block].top = f.top;
+    if (f.block == 0 && f.top == 0 && o_tmp_blk[1].p) {
+        /* the stack is empty and it needed more than one block: keep ONE block of the total size for the next particle */
+        size_t total = 0;
+        for (int i = 0; i < O_TMP_BLOCKS; i++) { total += o_tmp_blk[i].cap; free(o_tmp_blk[i].p); o_tmp_blk[i].p = NULL; o_tmp_blk[i].cap = 0; o_tmp_blk[i].top = 0; }
+        o_tmp_blk[0].p = (char*)aligned_alloc(64, total);
+        o_tmp_blk[0].cap = o_tmp_blk[0].p ? total : 0;
+    }
+}
+
+/* give the calling thread's scratch back (a long-lived host that is done with the oracle) */
+void o_tmp_release(void)
+{
+    for (int i = 0; i < O_TMP_BLOCKS; i++) { free(o_tmp_blk[i].p); o_tmp_blk[i].p = NULL; o_tmp_blk[i].cap = 0; o_tmp_blk[i].top = 0; }
+    o_tmp_cur = 0;
+}
+
+int o_omp_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* src/device_math.cuh:9-16 */
 float o_safe_log(float x) { return (x <= 0) ? O_LOG0 : logf(x); }
 
@@ -476,9 +550,11 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
         if (margin_out) { margin_out[0] = margin_d; margin_out[1] = margin_w; }
         return 0;
     }
-    o_sortkey* order = (o_sortkey*)malloc(sizeof(o_sortkey) * n);
-    uint8_t* merged = (uint8_t*)calloc(n, 1);
-    uint8_t* member = (uint8_t*)malloc(n);
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    o_sortkey* order = (o_sortkey*)o_tmp_alloc(sizeof(o_sortkey) * n);
+    uint8_t* merged = (uint8_t*)o_tmp_alloc(n);
+    uint8_t* member = (uint8_t*)o_tmp_alloc(n);
+    memset(merged, 0, n);
     for (int i = 0; i < n; i++) { order[i].w = in[i].weight; order[i].idx = i; }
     /* the arg-max of :2750-2788 with ties broken towards the lowest index == walking the
      * components in (weight desc, index asc) order and taking the first unmerged one */
@@ -554,7 +630,7 @@ int o_merge(const o_gaussian* in, int n, const o_config* cfg, o_gaussian* out, f
         }
         out[n_out++] = mg;                                              /* :2885-2887 */
     }
-    free(order); free(merged); free(member);
+    o_tmp_leave(tmp_frame);
     if (margin_out) { margin_out[0] = margin_d; margin_out[1] = margin_w; }
     return n_out;
 }
@@ -616,9 +692,11 @@ int o_merge_follow(const o_gaussian* ref, const o_gaussian* in, int n, const o_c
     for (int k = 0; k < 9; k++) stats[k] = 0;
     if (n <= 0) return 0;
     int n_out = 0;
-    o_sortkey* order = (o_sortkey*)malloc(sizeof(o_sortkey) * n);
-    uint8_t* merged = (uint8_t*)calloc(n, 1);
-    uint8_t* member = (uint8_t*)malloc(n);
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    o_sortkey* order = (o_sortkey*)o_tmp_alloc(sizeof(o_sortkey) * n);
+    uint8_t* merged = (uint8_t*)o_tmp_alloc(n);
+    uint8_t* member = (uint8_t*)o_tmp_alloc(n);
+    memset(merged, 0, n);
     for (int i = 0; i < n; i++) { order[i].w = ref[i].weight; order[i].idx = i; }
     qsort(order, n, sizeof(o_sortkey), o_cmp_desc);
     int first = 0;
@@ -722,7 +800,7 @@ int o_merge_follow(const o_gaussian* ref, const o_gaussian* in, int n, const o_c
         /* (a seed that is not close to itself under ref's decision stays unmerged and is picked again: the loop then ends
          *  with W == 0 exactly as o_merge's does, because the decision is ref's) */
     }
-    free(order); free(merged); free(member);
+    o_tmp_leave(tmp_frame);
     return n_out;
 }
 
@@ -749,9 +827,11 @@ static float o_chol_dist(const o_gaussian* a, const o_gaussian* b)
 int o_gm_reduce(const o_gaussian* in, int n, float min_distance, o_gaussian* out)
 {
     if (n <= 0) return 0;
-    o_sortkey* order = (o_sortkey*)malloc(sizeof(o_sortkey) * n);
-    uint8_t* gone = (uint8_t*)calloc(n, 1);
-    int* mlist = (int*)malloc(sizeof(int) * n);
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    o_sortkey* order = (o_sortkey*)o_tmp_alloc(sizeof(o_sortkey) * n);
+    uint8_t* gone = (uint8_t*)o_tmp_alloc(n);
+    int* mlist = (int*)o_tmp_alloc(sizeof(int) * n);
+    memset(gone, 0, n);
     for (int i = 0; i < n; i++) { order[i].w = in[i].weight; order[i].idx = i; }
     qsort(order, n, sizeof(o_sortkey), o_cmp_desc);                       /* :75-77 */
     int n_out = 0;
@@ -792,7 +872,7 @@ int o_gm_reduce(const o_gaussian* in, int n, float min_distance, o_gaussian* out
         r.cov[0] = c00 / W; r.cov[1] = c10 / W; r.cov[2] = c01 / W; r.cov[3] = c11 / W; /* :119-129 */
         out[n_out++] = r;
     }
-    free(order); free(gone); free(mlist);
+    o_tmp_leave(tmp_frame);
     return n_out;
 }
 
@@ -815,14 +895,15 @@ int o_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, c
                          o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out,
                          float* margin_out, o_gaussian* slab_all_out)
 {
-    int8_t* cls = (int8_t*)malloc(n_map > 0 ? n_map : 1);
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    int8_t* cls = (int8_t*)o_tmp_alloc(n_map > 0 ? n_map : 1);
     o_classify(map, n_map, pose, cfg, cls);
     int n_in = 0, n_near = 0, n_out0 = 0;
     for (int i = 0; i < n_map; i++) { n_in += cls[i] == 1; n_near += cls[i] == 2; n_out0 += cls[i] == 0; }
     /* stable 3-way partition, src/phdfilter.cu:3048-3056 */
-    o_gaussian* f_in = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_in + 1));
-    o_gaussian* f_near = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_near + 1));
-    o_gaussian* f_out = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_out0 + 1));
+    o_gaussian* f_in = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_in + 1));
+    o_gaussian* f_near = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_near + 1));
+    o_gaussian* f_out = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_out0 + 1));
     int a = 0, b = 0, c = 0;
     for (int i = 0; i < n_map; i++) {
         if (cls[i] == 1) f_in[a++] = map[i];
@@ -830,11 +911,11 @@ int o_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, c
         else f_out[c++] = map[i];
     }
     size_t n_update = (size_t)n_in * (M + 1) + M;
-    o_gaussian* births = (o_gaussian*)malloc(sizeof(o_gaussian) * (M + 1));
-    o_gaussian* pre = (o_gaussian*)malloc(sizeof(o_gaussian) * ((size_t)n_in * M + 1));
-    float* pd = (float*)malloc(sizeof(float) * (n_in + 1));
-    o_gaussian* slab = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_update + n_near + 1));
-    uint8_t* flag = (uint8_t*)malloc(n_update + 1);
+    o_gaussian* births = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (M + 1));
+    o_gaussian* pre = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * ((size_t)n_in * M + 1));
+    float* pd = (float*)o_tmp_alloc(sizeof(float) * (n_in + 1));
+    o_gaussian* slab = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_update + n_near + 1));
+    uint8_t* flag = (uint8_t*)o_tmp_alloc(n_update + 1);
     o_births(pose, z, M, cfg, births);
     o_preupdate(pose, f_in, n_in, z, M, cfg, pd, pre);
     o_update(f_in, pd, pre, births, n_in, M, cfg, slab, flag, dlogw);
@@ -860,7 +941,7 @@ int o_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_map, c
     int nm = o_merge(slab, ns, cfg, map_out, margin_out);
     /* append the out-of-range features (src/phdfilter.cu:3311-3318) */
     for (int i = 0; i < n_out0; i++) map_out[nm++] = f_out[i];
-    free(cls); free(f_in); free(f_near); free(f_out); free(births); free(pre); free(pd); free(slab); free(flag);
+    o_tmp_leave(tmp_frame);
     return nm;
 }
 

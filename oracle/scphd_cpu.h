@@ -24,6 +24,7 @@
 #ifndef SCPHD_CPU_H
 #define SCPHD_CPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -58,6 +59,14 @@ typedef struct {
      *   1  float sums in (weight desc) order, seed first — the order of src/gm_reduce.cpp:103-118 */
     int32_t mergeSums;
 } o_config;
+
+/* per-thread scratch stack of the per-particle routines (scphd_cpu.c: why) */
+typedef struct { int block; size_t top; } o_tmp_frame;
+o_tmp_frame o_tmp_enter(void);
+void* o_tmp_alloc(size_t bytes);
+void o_tmp_leave(o_tmp_frame f);
+void o_tmp_release(void);
+int o_omp_max_threads(void);
 
 float o_safe_log(float x);
 float o_wrap_angle(float a);

@@ -340,3 +340,29 @@ def test_phase_timing_holds_the_longest_step():
             m.step_resident((2.0, 0.05), 0.4, force_resample=False)
         ph, k = m.timing_read()
         assert k == 3 and ph["import"] > 0 and ph["send_recv"] > 0 and ph["plan_export"] > 0 and ph["weights"] > 0, ph
+
+
+@pytest.mark.parametrize("exchange", ["alltoall", "pull"])
+def test_phase_timing_survives_a_run_of_staged_calls(exchange):
+    """phd_multi_update / phd_multi_resample record phase marks too, and only phd_multi_step_resident used to
+    empty the list — with timing on, the sixth staged call or so failed THE FILTER STEP with "more phase marks … than the
+    timing pass holds".  Each staged call now opens and closes its own list: 12 update + resample pairs run, every pair counts
+    as one step, and the sharded filter still equals a single one."""
+    P, S, MM = pkg(), synthetic(), mod()
+    N, steps = 64, 12
+    w = S.make_workload(N, 12, 8, seed=93, n_meas_sets=steps)
+    cfg = P.default_config(n_particles=N)
+    ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]
+    ref = run_single(cfg, w, steps, 96, 16, False, [True] * steps)
+    with MM.MultiFilter(cfg, n_shards=2, devices=[0, 0], map_capacity=96, max_measurements=16, exchange=ex, gathered_limit_bytes=1) as m:
+        m.seed(77)
+        m.set_particles(w["poses"], w["logw"])
+        m.set_maps(w["maps"], w["sizes"])
+        m.timing(True)
+        for k in range(steps):
+            m.update((2.0, 0.05 - 0.01 * k), w["noise"][k], w["z"][k])
+            m.resample(w["uniform"][k])
+            p, lw = m.get_particles()
+            assert np.array_equal(p, ref[k][1]) and np.array_equal(lw, ref[k][2]), k
+        ph, n = m.timing_read()
+        assert n == steps and ph["local_step"] > 0 and ph["all_gather"] > 0 and ph["weights"] > 0 and ph["import"] > 0, (n, ph)

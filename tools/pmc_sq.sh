@@ -6,7 +6,7 @@
 cfg=${1:-3}; tag=${2:-r02}
 steps=20; [ "$cfg" = "2" ] && steps=60
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU \
   --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_cfg${cfg}_$tag -- \
   python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --bare --steps $steps --warmup 5 --preroll-ms 0 > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_cfg${cfg}_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
@@ -44,6 +44,17 @@ if m:
            "any_issue_fraction": 4.0 * m["SQ_ACTIVE_INST_ANY"] / (1024.0 * kcyc),
            "mean_waves_per_simd": 4.0 * m["SQ_WAVE_CYCLES"] / (1024.0 * kcyc),
            "formula": "valu_issue_fraction = 4 * SQ_ACTIVE_INST_VALU / (1024 * SQ_BUSY_CYCLES / 32)"}
+    # the formula's ceiling is MEASURED (tools/valu_ceiling.sh, profiles/valu_ceiling.json): 1.91 on a saturating stream of
+    # independent full-rate vector instructions (a SIMD issues one per 2.1 cycles once two waves interleave) - not 1.0
+    try:
+        ceil = json.load(open("profiles/valu_ceiling.json"))
+        out["valu_issue_ceiling_measured"] = ceil["formula_reading_at_saturation"]
+        out["valu_issue_fraction_of_ceiling"] = out["valu_issue_fraction"] / ceil["formula_reading_at_saturation"]
+        if m.get("SQ_INSTS_VALU"):
+            out["valu_instructions_per_cycle_per_simd"] = m["SQ_INSTS_VALU"] / (1024.0 * kcyc)
+            out["valu_instructions_per_cycle_per_simd_ceiling"] = ceil["full_rate_ipc_per_simd"]
+    except Exception as e:
+        out["valu_issue_ceiling_measured"] = None
     out.update(m)
     json.dump(out, open("gpurun_out/pmc_sq_cfg%s.json" % cfg, "w"), indent=1)
     print(json.dumps(out))
