@@ -79,6 +79,55 @@ def physical_cores():
     return len(seen)
 
 
+def cpu_quota_info():
+    """what may cap the host threads besides the affinity mask: the cgroup CPU quota (v2 cpu.max / v1 cfs_quota_us), how often
+    this cgroup has been throttled so far, the OpenMP environment, the load average"""
+    def rd(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+    info = {"cgroup_v2_cpu_max": rd("/sys/fs/cgroup/cpu.max"), "cgroup_v1_cfs_quota_us": rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"),
+            "cgroup_v1_cfs_period_us": rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us"),
+            "omp_env": {k: os.environ[k] for k in ("OMP_NUM_THREADS", "OMP_THREAD_LIMIT", "OMP_PROC_BIND", "OMP_PLACES", "GOMP_CPU_AFFINITY")
+                        if k in os.environ}}
+    try:                                                   # the process's own cgroup (v2: "0::/path")
+        for line in open("/proc/self/cgroup"):
+            f = line.strip().split(":", 2)
+            if f[0] == "0" and len(f) == 3 and f[2] not in ("", "/"):
+                info["cgroup_v2_path"] = f[2]
+                info["cgroup_v2_cpu_max_own"] = rd("/sys/fs/cgroup" + f[2] + "/cpu.max")
+    except OSError:
+        pass
+    q = None
+    try:
+        if info["cgroup_v2_cpu_max"] and info["cgroup_v2_cpu_max"].split()[0] != "max":
+            a, b = info["cgroup_v2_cpu_max"].split()[:2]
+            q = float(a) / float(b)
+        elif info["cgroup_v1_cfs_quota_us"] and int(info["cgroup_v1_cfs_quota_us"]) > 0:
+            q = int(info["cgroup_v1_cfs_quota_us"]) / float(info["cgroup_v1_cfs_period_us"] or 100000)
+    except Exception:
+        pass
+    info["quota_cpus"] = q
+    try:
+        info["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    return info
+
+
+def cpu_throttle_counters():
+    """(nr_throttled, throttled microseconds) of this cgroup so far, or None"""
+    for path, key_n, key_t, scale in (("/sys/fs/cgroup/cpu.stat", "nr_throttled", "throttled_usec", 1.0),
+                                      ("/sys/fs/cgroup/cpu/cpu.stat", "nr_throttled", "throttled_time", 1e-3)):
+        try:
+            d = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            return int(d[key_n]), float(d[key_t]) * scale
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(w, cfg_id, budget_s):
     """the CPU oracle (a port of the reference algorithm: kind "port") on the host cores, SURVEY.md §8d: the FULL particle
     set of the configuration (no slice, no n/N scaling), compiled -O3 -march=native on THIS host (oracle.build_native),
@@ -99,12 +148,25 @@ def cpu_baseline(w, cfg_id, budget_s):
         one = O.make_stepper(w["poses"], lw, maps, w["sizes"], cap, 0.05, 2.0, w["noise"][0], w["z"][0], ocfg, w["uniform"][0],
                              True, clutter_rate=20.0, cn=cn0)
 
+        busy = {}                                      # threads -> process CPU seconds / wall seconds of that run: the
+                                                       # cores the OS actually gave (a quota or a busy host shows HERE)
+
         def timed(threads, k):
+            c0 = os.times()
             t0 = time.perf_counter()
             for _ in range(k):
                 one(threads)
-            return (time.perf_counter() - t0) / k
+            dt = time.perf_counter() - t0
+            c1 = os.times()
+            busy[threads] = ((c1.user - c0.user) + (c1.system - c0.system)) / max(dt, 1e-9)
+            return dt / k
 
+        quota = cpu_quota_info()
+        thr0 = cpu_throttle_counters()
+        try:
+            omp_max = int(O.lib().o_omp_max_threads())
+        except Exception:
+            omp_max = None
         t_start = time.perf_counter()
         # thread scan: powers of two, the physical core count, everything visible — one full step each (the first call at
         # the widest count also warms the pages of every buffer)
@@ -126,9 +188,24 @@ def cpu_baseline(w, cfg_id, budget_s):
             sb, kb = s1, k1
         best, single = 1.0 / sb, 1.0 / s1
         total = time.perf_counter() - t_start
+        thr1 = cpu_throttle_counters()
+        throttled = None if (thr0 is None or thr1 is None) else {"periods": thr1[0] - thr0[0], "seconds": 1e-6 * (thr1[1] - thr0[1])}
+        # why the scan flattens, from what was measured: the cores the OS gave (process CPU time / wall time) against the threads
+        # asked for, the quota, the throttle counters
+        widest = max(scan) if scan else 1
+        limit = None
+        if throttled and throttled["periods"] > 0:
+            limit = "cgroup CPU quota: throttled %d periods (%.2f s) during the scan; quota %s CPUs" % (
+                throttled["periods"], throttled["seconds"], quota.get("quota_cpus"))
+        elif busy.get(widest, widest) < 0.7 * widest:
+            limit = "the OS gave %.1f cores to %d threads (process CPU time / wall time): fewer cores than the affinity mask shows" % (busy[widest], widest)
+        elif scan and scan[widest] > 1.2 * min(scan.values()):
+            limit = "threads were busy (%.1f cores for %d threads) but slower than fewer threads: SMT siblings / memory bandwidth / NUMA" % (busy[widest], widest)
     finally:
         O.use_library(None)
-    return {"value": best, "unit": "steps/s", "cores": best_t, "kind": "port",
+    return {"value": best, "unit": "steps/s", "cores": best_t, "kind": "port", "omp_max_threads": omp_max,
+            "cores_given_by_threads": {str(t): round(busy[t], 2) for t in sorted(busy)}, "host_limits": quota, "throttled_during_scan": throttled,
+            "scaling_limit": limit,
             "cpu_model": cpu_model(), "cores_visible": avail, "cores_physical": phys,
             "single_thread_steps_per_s": single, "best_thread_steps_per_s": best,
             "thread_scan_s_per_step": {str(t): scan[t] for t in sorted(scan)},

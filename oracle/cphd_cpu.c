@@ -102,7 +102,8 @@ void o_cphd_log_factorials(float* lfact, int n)                      /* initCphd
  * every IEEE machine.  Output: log e_j, j = 0..M. */
 static void esf_xf(const float* xi, int M, int skip, float* le)
 {
-    xf* e = (xf*)malloc(sizeof(xf) * (M + 1));
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    xf* e = (xf*)o_tmp_alloc(sizeof(xf) * (M + 1));
     e[0].m = 0.5f; e[0].k = 1;                                       /* e_0 = 1 */
     for (int j = 1; j <= M; j++) { e[j].m = 0; e[j].k = XF_ZERO_K; }
     int done = 0;
@@ -112,7 +113,7 @@ static void esf_xf(const float* xi, int M, int skip, float* le)
         done++;
     }
     for (int j = 0; j <= M; j++) le[j] = xf_log(e[j]);
-    free(e);
+    o_tmp_leave(tmp_frame);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -164,7 +165,8 @@ static void esf_f64(const float* xi, int M, float* le)
 /* lz[m] = -((llam - lkap) + log <Y1[Z\m],p> - lY0) for every m, prefix/suffix form in double */
 static void leave_one_out_f64(const float* xi, const float* I1, int M, float llam, float lam, float lkap, float lY0, float* lz)
 {
-    double* rows = (double*)malloc(sizeof(double) * (size_t)M * 65);
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    double* rows = (double*)o_tmp_alloc(sizeof(double) * (size_t)M * 65);
     int kp[64];
     double P[66];
     int kP = 0;
@@ -205,7 +207,7 @@ static void leave_one_out_f64(const float* xi, const float* I1, int M, float lla
             if (((M - 1 - m) & (F64_RENORM - 1)) == F64_RENORM - 1) kT += row_renorm(T, M);
         }
     }
-    free(rows);
+    o_tmp_leave(tmp_frame);
 }
 
 /*
@@ -222,15 +224,16 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
 {
     const int Nmax = cn_len - 1;
     const int LF = (Nmax > M ? Nmax : M) + 2;
-    float* lfact = (float*)malloc(sizeof(float) * LF);
-    float* cnp = (float*)malloc(sizeof(float) * cn_len);
-    float* cnb = (float*)malloc(sizeof(float) * (M + 1));
-    float* lxi = (float*)malloc(sizeof(float) * (M + 1));
-    float* e = (float*)malloc(sizeof(float) * (M + 1));
-    float* em = (float*)malloc(sizeof(float) * (M + 1));
-    float* I0 = (float*)malloc(sizeof(float) * (M + 1));
-    float* I1 = (float*)malloc(sizeof(float) * (M + 1));
-    float* t = (float*)malloc(sizeof(float) * (cn_len + M + 2));
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    float* lfact = (float*)o_tmp_alloc(sizeof(float) * LF);
+    float* cnp = (float*)o_tmp_alloc(sizeof(float) * cn_len);
+    float* cnb = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* lxi = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* e = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* em = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* I0 = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* I1 = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* t = (float*)o_tmp_alloc(sizeof(float) * (cn_len + M + 2));
     o_cphd_log_factorials(lfact, LF);
     const float llam = o_safe_log(clutter_rate), lkap = o_safe_log(clutter_density);
     const float lbw = o_safe_log(birth_weight), l1bw = o_safe_log(1 - birth_weight);
@@ -286,9 +289,9 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
          *   <Y1[Z\m],p> = sum_a P_m[a] T_{m+1}[a],   T_{m+1}[a] = sum_b S_{m+1}[b] c_{a+b},
          * and T obeys the same one-root recursion run backwards: T_m[a] = T_{m+1}[a] + xi_m T_{m+1}[a+1],
          * T_M = c.  All terms are positive: no cancellation.  (The device kernel does exactly this.) */
-        xf* T = (xf*)malloc(sizeof(xf) * (size_t)M * M);             /* row m holds T_{m+1}[0..m] */
-        xf* cur = (xf*)malloc(sizeof(xf) * (M + 1));
-        xf* P = (xf*)malloc(sizeof(xf) * (M + 1));
+        xf* T = (xf*)o_tmp_alloc(sizeof(xf) * (size_t)M * M);             /* row m holds T_{m+1}[0..m] */
+        xf* cur = (xf*)o_tmp_alloc(sizeof(xf) * (M + 1));
+        xf* P = (xf*)o_tmp_alloc(sizeof(xf) * (M + 1));
         for (int a = 0; a < M; a++) cur[a] = xf_from_log(I1[a] + ((float)(M - 1 - a) * llam - clutter_rate));
         for (int a = 0; a < M; a++) T[(size_t)(M - 1) * M + a] = cur[a];
         for (int m = M - 1; m >= 1; m--) {
@@ -309,7 +312,7 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
             lz[m] = -((llam - lkap) + xf_log(D) - lY0);
             for (int a = m + 1; a >= 1; a--) P[a] = xf_axpy(P[a], P[a - 1], lxi[m]);
         }
-        free(T); free(cur); free(P);
+        /* (T, cur, P: released with the frame) */
     }
     *r1_out = expf(lY1 - lY0);
     /* 6. updated cardinality (.bak:1409-1411) */
@@ -321,7 +324,7 @@ void o_cphd_terms(const float* cn_prior, int cn_len, const float* S, int M, floa
         cn_out[n] = cnp[n] + lse_n(t, jmax + 1) - lY0;
     }
     *lY0_out = lY0;
-    free(lfact); free(cnp); free(cnb); free(lxi); free(e); free(em); free(I0); free(I1); free(t);
+    o_tmp_leave(tmp_frame);
 }
 
 /* o_update for the CPHD variant: same slab layout [non-detect | detect m-major | births] */
@@ -331,8 +334,9 @@ void o_cphd_update(const o_gaussian* feat, const float* pd, const o_gaussian* pr
                    o_gaussian* slab, uint8_t* prune_flag, float* dlogw, float* cn_out, float* r1_out)
 {
     const int n_update = n * (M + 1) + M;
-    float* S = (float*)malloc(sizeof(float) * (M + 1));
-    float* lz = (float*)malloc(sizeof(float) * (M + 1));
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    float* S = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
+    float* lz = (float*)o_tmp_alloc(sizeof(float) * (M + 1));
     float pdw = 0;
     for (int j = 0; j < n; j++) pdw += pd[j] * feat[j].weight;
     for (int m = 0; m < M; m++) {
@@ -360,7 +364,7 @@ void o_cphd_update(const o_gaussian* feat, const float* pd, const o_gaussian* pr
     *dlogw = lY0;
     if (r1_out) *r1_out = r1;
     for (int i = 0; i < n_update; i++) prune_flag[i] = (slab[i].weight < cfg->minFeatureWeight) ? 1 : 0;
-    free(S); free(lz);
+    o_tmp_leave(tmp_frame);
 }
 
 /* o_update_particle for the CPHD variant; features outside the field of view (pD = 0) take the
@@ -383,7 +387,8 @@ int o_cphd_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_m
                               o_gaussian* survivors_out, int32_t* surv_slab_idx, int* n_survivors_out, float* r1_out,
                               float* margin_out, o_gaussian* slab_all_out)
 {
-    int8_t* cls = (int8_t*)malloc(n_map > 0 ? n_map : 1);
+    o_tmp_frame tmp_frame = o_tmp_enter();
+    int8_t* cls = (int8_t*)o_tmp_alloc(n_map > 0 ? n_map : 1);
     o_classify(map, n_map, pose, cfg, cls);
     int n_in = 0, n_near = 0, n_out0 = 0;
     float w_all = 0;
@@ -391,9 +396,9 @@ int o_cphd_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_m
         n_in += cls[i] == 1; n_near += cls[i] == 2; n_out0 += cls[i] == 0;
         w_all += map[i].weight;
     }
-    o_gaussian* f_in = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_in + 1));
-    o_gaussian* f_near = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_near + 1));
-    o_gaussian* f_out = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_out0 + 1));
+    o_gaussian* f_in = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_in + 1));
+    o_gaussian* f_near = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_near + 1));
+    o_gaussian* f_out = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_out0 + 1));
     int a = 0, b = 0, c = 0;
     for (int i = 0; i < n_map; i++) {
         if (cls[i] == 1) f_in[a++] = map[i];
@@ -401,11 +406,11 @@ int o_cphd_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_m
         else f_out[c++] = map[i];
     }
     size_t n_update = (size_t)n_in * (M + 1) + M;
-    o_gaussian* births = (o_gaussian*)malloc(sizeof(o_gaussian) * (M + 1));
-    o_gaussian* pre = (o_gaussian*)malloc(sizeof(o_gaussian) * ((size_t)n_in * M + 1));
-    float* pd = (float*)malloc(sizeof(float) * (n_in + 1));
-    o_gaussian* slab = (o_gaussian*)malloc(sizeof(o_gaussian) * (n_update + n_near + 1));
-    uint8_t* flag = (uint8_t*)malloc(n_update + 1);
+    o_gaussian* births = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (M + 1));
+    o_gaussian* pre = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * ((size_t)n_in * M + 1));
+    float* pd = (float*)o_tmp_alloc(sizeof(float) * (n_in + 1));
+    o_gaussian* slab = (o_gaussian*)o_tmp_alloc(sizeof(o_gaussian) * (n_update + n_near + 1));
+    uint8_t* flag = (uint8_t*)o_tmp_alloc(n_update + 1);
     float r1 = 1;
     o_births(pose, z, M, cfg, births);
     o_preupdate(pose, f_in, n_in, z, M, cfg, pd, pre);
@@ -443,7 +448,7 @@ int o_cphd_update_particle_ex(const o_pose* pose, const o_gaussian* map, int n_m
         nm++;
     }
     if (r1_out) *r1_out = r1;
-    free(cls); free(f_in); free(f_near); free(f_out); free(births); free(pre); free(pd); free(slab); free(flag);
+    o_tmp_leave(tmp_frame);
     return nm;
 }
 

@@ -131,6 +131,8 @@ def lib():
         L.o_safe_log.restype = f32; L.o_safe_log.argtypes = [f32]
         L.o_wrap_angle.restype = f32; L.o_wrap_angle.argtypes = [f32]
         L.o_det_exp.restype = f64; L.o_det_exp.argtypes = [f32]
+        L.o_omp_max_threads.restype = i32; L.o_omp_max_threads.argtypes = []
+        L.o_tmp_release.restype = None; L.o_tmp_release.argtypes = []
         L.o_predict_ackerman.restype = None; L.o_predict_ackerman.argtypes = [vp, i32, f32, f32, vp, cp]
         L.o_predicted_measurement.restype = None; L.o_predicted_measurement.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.o_classify.restype = None; L.o_classify.argtypes = [vp, i32, vp, cp, vp]

@@ -6,7 +6,10 @@ the reference's own state100.bin snapshot, src/main.cpp:1262-1269,1314-1321).
 
 3 seeds x {1 x 64 x 32, 8 x 64 x 32, 4 x 256 x 64 (clustered landmarks)}: inputs (poses, log-weights, maps, measurement
 set, control noise, resampling uniform), predicted poses, per-particle survivors (pruned update components + slab
-indices), merged maps, log-weight increments, decision margins, normalised weights, resampling indices.
+indices), merged maps, log-weight increments, decision margins, normalised weights, resampling indices, and (round 5) the
+unpruned slab as far as an admissible device survivor can index it (`slab_keep`, `slab_keep_idx`), the class counts and the
+float64 log-weight increment — what tests/parity_utils.compare_particle_with_oracle needs to hold the device to this file
+with its first-order proofs.
 `out_maps` are the merged maps under the exact, order-free moment sums (o_config.mergeSums = 0: what the device computes);
 `out_maps_float` the same merge with float sums in weight order (mergeSums = 1) — bit for bit the `out_maps` of the file as
 it stood before round 3 (checked when the file was regenerated).
@@ -46,11 +49,22 @@ def make_case(n, g, m, seed):
     pred = O.predict_ackerman(w["poses"], CONTROL[1], CONTROL[0], w["noise"][0], ocfg)
     ocfg_float = oracle_config_from(cfg, mergeSums=1)       # the merge with float sums in weight order (round 2's definition)
     surv, sidx, nsurv, maps, maps_float, sizes, dlogw, margins = [], [], [], [], [], [], [], []
+    keep, keep_idx, nkeep, counts, extra = [], [], [], [], []
     for p in range(n):
         r = oracle_full_update(pred[p], w["maps"][p, :w["sizes"][p]], z, ocfg)
         surv.append(r["survivors"]); sidx.append(r["slab_idx"]); nsurv.append(len(r["survivors"]))
         maps.append(r["map"]); sizes.append(len(r["map"])); dlogw.append(r["dlogw"])
         margins.append((r["prune_margin"], r["margin"][0], r["margin"][1]))
+        # round 5: the UNPRUNED slab, as far as any admissible device survivor can index it — every update component whose
+        # weight reaches half the prune threshold (a member only one side keeps must be within 5e-4 of it) and all nearly-in-range
+        # features — so that the device is held to THIS FILE by the proof machinery of parity_utils.compare_particle_with_oracle
+        # (the oracle's own values under the device's decisions), not by fixed margins
+        sa, nu = r["slab_all"], r["n_update"]
+        k = np.flatnonzero((np.arange(len(sa)) >= nu) | (sa["weight"] >= 0.5 * ocfg.minFeatureWeight)).astype(np.int32)
+        assert np.isin(r["slab_idx"], k).all()
+        keep.append(sa[k]); keep_idx.append(k); nkeep.append(len(k))
+        counts.append((r["n_in"], len(sa) - nu, int((r["cls"] == 0).sum()), len(sa)))
+        extra.append((r["card"], r["dlogw_f64"]))
         rf = oracle_full_update(pred[p], w["maps"][p, :w["sizes"][p]], z, ocfg_float)
         assert len(rf["map"]) == len(r["map"])             # the two definitions differ in roundings, never in structure
         maps_float.append(rf["map"])
@@ -64,6 +78,10 @@ def make_case(n, g, m, seed):
         "out_maps": np.concatenate(maps), "out_maps_float": np.concatenate(maps_float),
         "out_sizes": np.array(sizes, np.int32), "dlogw": dlogw,
         "margins": np.array(margins, np.float64), "logw_norm": lw, "neff": np.float32(O.neff(lw)), "idx": idx,
+        # (added in round 5; everything above is bit for bit the round-3 file)
+        "slab_keep": np.concatenate(keep), "slab_keep_idx": np.concatenate(keep_idx), "nkeep": np.array(nkeep, np.int32),
+        "counts": np.array(counts, np.int32),                  # per particle: n_in, n_near, n_out0, len(slab_all)
+        "card_f64": np.array(extra, np.float64),               # per particle: predicted cardinality, float64 log-weight increment
     }
 
 
@@ -75,6 +93,14 @@ def main():
             out[case_key(n, g, m, seed) + "/" + k] = v
         print(case_key(n, g, m, seed), "survivors", c["nsurv"].tolist(), "map sizes", c["out_sizes"].tolist())
     path = os.path.join(HERE, "oracle_steps.npz")
+    if os.path.exists(path):
+        # a regeneration that only ADDS arrays must leave every existing array bit-identical
+        old = np.load(path)
+        changed = [k for k in old.files if k not in out or not (old[k].dtype == out[k].dtype and old[k].shape == out[k].shape
+                                                                  and old[k].tobytes() == out[k].tobytes())]
+        print("arrays of the existing file that would change:", changed or "none")
+        if changed and "--allow-changes" not in sys.argv:
+            raise SystemExit("refusing to overwrite: pass --allow-changes for a deliberate change of the oracle's semantics")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -132,6 +132,17 @@ class Observed:
 OBS = Observed()
 
 
+def assert_few_early_exits(n_compared, what="", frac=0.01):
+    """Particles that `compare_particle_with_oracle` lets go with less than the full comparison — a Hellinger decision the oracle
+    itself reports within 1e-5 of the threshold (only a size check), NaN merge distances (the map under followed decisions is not
+    compared) — are COUNTED by OBS; a test that compares n particles asserts here that they stay a small share (<= 1 %, and none
+    at all under the Mahalanobis metric, where neither can happen)"""
+    early = OBS.count.get("hellinger_marginal_particles", 0) + OBS.count.get("nan_distance_particles", 0)
+    assert early <= frac * n_compared, "%s: %d of %d compared particles left the comparison early (Hellinger-marginal %d, NaN distances %d)" % (
+        what, early, n_compared, OBS.count.get("hellinger_marginal_particles", 0), OBS.count.get("nan_distance_particles", 0))
+    return early
+
+
 def oracle_config_from(cfg, **over):
     """o_config mirroring a SlamConfig (the same numbers reach both sides)"""
     oc = O.OConfig(dt=cfg.dt, minRange=cfg.minRange, maxRange=cfg.maxRange, maxBearing=cfg.maxBearing,

@@ -5,19 +5,23 @@ import numpy as np
 import pytest
 
 from golden_utils import CASES, CONTROL, load_case
-from parity_utils import assert_maps_close, dlogw_tolerance, pkg
+from parity_utils import OBS, compare_particle_with_oracle, oracle_config_from, pkg
 
 pytestmark = pytest.mark.gpu
-
-PRUNE_MARGIN = 2e-3
-MERGE_MARGIN = 2e-4
 
 
 @pytest.mark.parametrize("n,g,m,seed", CASES)
 def test_device_reproduces_the_frozen_oracle_outputs(n, g, m, seed):
+    """EVERY particle of the file (39 in all) goes through parity_utils.compare_particle_with_oracle with the FILE as the
+    oracle's side: log-weight increment, merge stage bit for bit, survivor set (a member only one side keeps must be marginal),
+    and the device's map cluster by cluster against the file's values merged under the device's decisions — every decision the
+    file's values alone would take differently proven by its first-order sensitivity.  (Rounds 1-4 compared structure only
+    where fixed margins of the file said "clear", and let half of the particles go uncompared.)"""
     P = pkg()
     c = load_case(n, g, m, seed)
     cfg = P.default_config()
+    ocfg = oracle_config_from(cfg)
+    OBS.clear()
     n_struct = 0
     with P.PhdFilter(cfg, n_particles=n, map_capacity=2 * g, max_measurements=m) as f:
         f.set_particles(c["poses"], c["logw"])
@@ -33,20 +37,16 @@ def test_device_reproduces_the_frozen_oracle_outputs(n, g, m, seed):
         dlw = f.weight_increments()
         _, lw = f.get_particles()
         for p in range(n):
-            card = 0.95 * float(c["maps"][p, :c["sizes"][p]]["weight"].sum()) + m * 1e-4    # predicted cardinality (upper bound)
-            assert abs(dlw[p] - c["dlogw"][p]) < dlogw_tolerance(c["dlogw"][p], m, card, g), (p, dlw[p], c["dlogw"][p])
-            pm, mm = c["margins"][p, 0], c["margins"][p, 1]
-            if pm > PRUNE_MARGIN:
-                surv, sidx = f.survivors(p)
-                assert np.array_equal(sidx, c["sidx_of"](p)), "particle %d: survivor set differs from the frozen one" % p
-                assert_maps_close(surv, c["surv_of"](p), ordered=True, what="survivors of particle %d" % p)
-                if mm > MERGE_MARGIN:
-                    n_struct += 1
-                    assert_maps_close(maps[p], c["map_of"](p), what="map of particle %d" % p)
+            surv, sidx = f.survivors(p)
+            r = compare_particle_with_oracle(maps[p], surv, sidx, c["ref_of"](p), ocfg, m, dlw=dlw[p],
+                                             what="golden %dx%dx%d seed %d particle %d" % (n, g, m, seed, p))
+            n_struct += bool(r["structural"])
         assert np.abs(lw - c["logw_norm"]).max() < 2e-3
         # resampling from the FROZEN normalised weights: bit-exact indices (fixed-point CDF)
         f.set_particles(None, c["logw_norm"])
         assert abs(f.neff() - float(c["neff"])) < 1e-5 * max(1.0, float(c["neff"]))
         idx = f.resample(float(c["uniform"]))
         assert np.array_equal(idx, c["idx"])
-    assert n_struct >= 0.5 * n, (n_struct, n)
+    # Mahalanobis metric: no particle may leave the comparison early (Hellinger-marginal / NaN distances do not exist here)
+    assert OBS.count.get("hellinger_marginal_particles", 0) == 0 and OBS.count.get("nan_distance_particles", 0) == 0, OBS.report()
+    print("\n  golden %dx%dx%d seed %d: %d / %d particles with the file's own clusters; %s" % (n, g, m, seed, n_struct, n, OBS.report()))

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from parity_utils import (OBS, assert_maps_close, compare_particle_with_oracle, oracle_config_from, oracle_full_cphd_update,
+from parity_utils import (OBS, assert_few_early_exits, assert_maps_close, compare_particle_with_oracle, oracle_config_from, oracle_full_cphd_update,
                           oracle_full_update, pkg, synthetic)
 
 pytestmark = pytest.mark.gpu
@@ -576,6 +576,7 @@ def test_full_size_properties(cfg_id, sample):
     print("config %d: %d of %d sampled particles have the oracle's own structure (the rest: every differing decision proven marginal, "
           "maps compared under the device's decisions)" % (cfg_id, n_ok, len(picks)))
     assert not bad, bad
+    assert_few_early_exits(len(picks), "cfg %d" % cfg_id)
     # floor: on hardware EVERY sampled particle has the oracle's own clusters (profiles/r04_parity_observed.txt: 128/128, 128/128,
     # 64/64; the margin-based criterion of rounds 1-3 could compare 126/128, 100/128, 56/64); a little slack for another libm
     assert n_ok >= 0.95 * len(picks), "only %d of %d sampled particles have the oracle's own structure" % (n_ok, len(picks))
@@ -671,6 +672,7 @@ def test_bench_path_at_bench_size(cfg_id, sample):
                         live = ref["cn"] > -40
                         OBS.note("cphd_cardinality_row_abs", np.abs(cn_pre[p][live] - ref["cn"][live]).max())
                         assert np.allclose(cn_pre[p][live], ref["cn"][live], atol=CPHD_CN_ATOL), (p, np.abs(cn_pre[p][live] - ref["cn"][live]).max())
+                    assert_few_early_exits(len(picks), "cfg 5 (bench path)")
                     print("config 5 bench path: %d sampled particles compared with the CPHD oracle component by component, %d of them "
                           "with the oracle's own structure (the rest: explained flips / marginal prune members)" % (len(picks), n_ok))
                     continue
@@ -679,6 +681,7 @@ def test_bench_path_at_bench_size(cfg_id, sample):
                 print("config %d bench path: %d of %d sampled particles have the oracle's own structure (the rest: every differing "
                       "decision proven marginal, maps compared under the device's decisions)" % (cfg_id, n_ok, len(picks)))
                 assert not bad, bad
+                assert_few_early_exits(len(picks), "cfg %d (bench path)" % cfg_id)
                 # floor: on hardware all 256 of 256 (profiles/r04_parity_observed.txt; rounds 1-3: 255/256, 208/256 comparable)
                 assert n_ok >= 0.95 * len(picks), (n_ok, len(picks))
         sa, sb = a.status(), b.status()
