@@ -78,6 +78,7 @@ struct phd_filter {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     size_t lds_bytes = 0;
+    bool three_per_cu = false;     // the build of the update kernel this filter runs (80 registers, three workgroups per CU): decided at create
 
     float* maps[2] = {nullptr, nullptr};
     int* counts[2] = {nullptr, nullptr};
@@ -110,6 +111,8 @@ struct phd_filter {
     int* h_plan = nullptr;    // pinned [2 n]: per slot the local parent (or -1) | the received row: phd_global_resample_plan -> _end
     int* d_plan = nullptr;
     unsigned* ticket = nullptr; // arrival counter of the fused step (zero between launches)
+    unsigned* gw_sync = nullptr;   // block form of the weights routine (n > 4096): counters of its grid-wide barriers (zero between launches)
+    float* gw_part = nullptr;      // ... and one 8-word record per block of 256 weights
     bool fuse_enabled = true;
     // staging for AoS <-> SoA
     phd_gaussian2d* d_concat = nullptr;
@@ -254,6 +257,12 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         delete f;
         return fail(PHD_ERR_CAPACITY, "phd_create: map_capacity/survivor_capacity need more than 160 KiB of LDS");
     }
+    // the build this filter runs, for its whole life (PHD_UPDATE_BUILD=2 / 3 overrides: the tests compare the two builds bit for bit)
+    f->three_per_cu = update_takes_three_per_cu(f->cphd, f->spill_cap != 0, f->lds_bytes, f->n_base);
+    if (const char* e = getenv("PHD_UPDATE_BUILD")) {
+        if (e[0] == '2') f->three_per_cu = false;
+        else if (e[0] == '3' && !f->spill_cap && 3 * (f->lds_bytes + 1024) <= 160 * 1024) f->three_per_cu = true;
+    }
     if (o.stream) {
         f->stream = (hipStream_t)o.stream;
     } else {
@@ -284,6 +293,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     A(dalloc(&f->d_plan, 2 * (size_t)f->n_max));
     A(hipHostMalloc((void**)&f->h_plan, 2 * (size_t)f->n_max * sizeof(int)));
     A(dalloc(&f->ticket, 1));
+    A(dalloc(&f->gw_sync, 4)); A(dalloc(&f->gw_part, 8 * ((gmax + 255) / 256 + 1)));
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, gmax));
     if (f->spill_cap) {
         A(dalloc(&f->spill_rec, (size_t)f->n_max * 2 * f->spill_cap * 8));
@@ -307,6 +317,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     hipMemsetAsync(f->counts[1], 0, f->n_max * sizeof(int), f->stream);
     hipMemsetAsync(f->report, 0, 8 * 4, f->stream);
     hipMemsetAsync(f->ticket, 0, 4, f->stream);
+    hipMemsetAsync(f->gw_sync, 0, 16, f->stream);
     for (int k = 0; k < 3; ++k) launch_iota(f->parent[k], f->n_max, f->stream);
     if (f->cphd) {
         // uniform cardinality -log(maxCardinality+1) (src/main.cpp:1142); log factorials by the reference's
@@ -343,7 +354,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
     hipFree(f->report); hipFree(f->state_pose); hipFree(f->state_argmax);
-    hipFree(f->d_tmp_int); hipFree(f->ticket); hipFree(f->d_plan);
+    hipFree(f->d_tmp_int); hipFree(f->ticket); hipFree(f->gw_sync); hipFree(f->gw_part); hipFree(f->d_plan);
     if (f->h_plan) hipHostFree(f->h_plan);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
     hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
@@ -696,6 +707,14 @@ struct FusedWeights {
 };
 static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms, int n_uniforms, double u0,
                               WeightArgs& w, int& free_pose);
+// every launch of the weights routine goes through here: the block form (n > 4096) needs the filter's barrier counters and block
+// records, and reports a time-out in the filter's status word
+static hipError_t launch_weights_f(phd_filter* f, WeightArgs& w)
+{
+    w.gsync = f->gw_sync;
+    w.gpart = f->gw_part;
+    return launch_weights(w, f->stream, f->status);
+}
 static int interpret_report(phd_filter* f, const unsigned raw[8], phd_step_report* out);
 static void commit_weights(phd_filter* f, int mode, int free_pose);
 
@@ -782,6 +801,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
 #ifdef PHD_EXP_TRACE
         {
             static unsigned long long* g_trace = nullptr;
+            if (f->n + 1 > 70000) return fail(PHD_ERR_CAPACITY, "PHD_EXP_TRACE: the trace buffer holds 70000 workgroups");
             if (!g_trace) hipMalloc(&g_trace, sizeof(unsigned long long) * 8 * 70000);
             a.trace = g_trace;
             g_exp_trace = g_trace;
@@ -789,7 +809,7 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
 #endif
     }
     t_begin(f, PHD_K_UPDATE_MERGE);
-    HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream));
+    HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream, f->three_per_cu));
     HIPCHK(launch_merge_spill(a, f->n, f->stream));   // (a no-op without a spill list) particles whose survivors outgrew LDS
     t_end(f);
     f->last_M = M;
@@ -832,6 +852,8 @@ static void build_weight_args(phd_filter* f, int mode, const double* d_uniforms,
     w.parent_out = f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1];
     w.n_weight_norm = f->n_global;
     if (f->want_stamps && f->stamps) w.wstamps = f->stamps + (size_t)f->n * PHD_STAMP_ROW;
+    w.gsync = f->gw_sync;
+    w.gpart = f->gw_part;
 }
 
 static void commit_weights(phd_filter* f, int mode, int free_pose)
@@ -851,10 +873,10 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
     build_weight_args(f, mode, d_uniforms, n_uniforms, u0, w, free_pose);
     // large sets: the routine's searches run on several workgroups that do not wait for each other, so the weights are
     // written out of place (launch_weights) and the buffers swapped
-    const bool out_of_place = !f->frozen && f->n > 1024 && (mode & (WM_RESAMPLE_FORCE | WM_RESAMPLE_AUTO));
+    const bool out_of_place = !f->frozen && f->n > 1024 && f->n <= weights_grid_min_particles() && (mode & (WM_RESAMPLE_FORCE | WM_RESAMPLE_AUTO));
     if (out_of_place) w.logw = f->logw_alt;
     t_begin(f, PHD_K_WEIGHTS);
-    HIPCHK(launch_weights(w, f->stream));
+    HIPCHK(launch_weights_f(f, w));
     t_end(f);
     if (out_of_place) std::swap(f->logw, f->logw_alt);
     commit_weights(f, mode, free_pose);
@@ -866,8 +888,12 @@ static int do_weights(phd_filter* f, int mode, const double* d_uniforms, int n_u
 // launch's fixed cost is a measurable share of the step.
 static bool can_fuse(const phd_filter* f)
 {
-    return f->fuse_enabled && !f->want_stamps && f->n == f->n_base && f->n <= update_fuse_max_particles() &&
-           (size_t)f->n * 8 <= f->lds_bytes;
+    if (!f->fuse_enabled || f->want_stamps || f->n != f->n_base || f->n > update_fuse_max_particles()) return false;
+    // up to 4096 particles the tail is ONE workgroup with the fixed-point CDF in LDS; above, the block form on several
+    // workgroups (phd_weights.h: weights_grid_body), which needs the block ends of the CDF there
+    if (f->n <= weights_grid_min_particles()) return (size_t)f->n * 8 <= f->lds_bytes;
+    // (carried by the three-per-CU builds of the update kernel only: phd_kernels.hip)
+    return f->three_per_cu && !f->cphd && weights_grid_lds_bytes(f->n) <= f->lds_bytes;
 }
 
 extern "C" int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_out, uint64_t* lds_bytes_out)
@@ -879,7 +905,7 @@ extern "C" int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_ou
     a.cphd = f->cphd ? 1 : 0;
     a.spill_rec = f->spill_rec;
     a.fuse_weights = can_fuse(f) ? 1 : 0;
-    if (workgroups_per_cu_out) *workgroups_per_cu_out = update_workgroups_per_cu(a, f->lds_bytes, f->n);
+    if (workgroups_per_cu_out) *workgroups_per_cu_out = update_workgroups_per_cu(a, f->lds_bytes, f->three_per_cu);
     if (lds_bytes_out) *lds_bytes_out = f->lds_bytes;
     return PHD_OK;
 }
@@ -1283,7 +1309,7 @@ extern "C" int phd_global_normalize(phd_filter* f, const float* d_all_logw, int 
     w.did_resample = f->did;
     w.n_weight_norm = f->n_global;
     t_begin(f, PHD_K_WEIGHTS);
-    HIPCHK(launch_weights(w, f->stream));
+    HIPCHK(launch_weights_f(f, w));
     t_end(f);
     if (!f->frozen)
         HIPCHK(hipMemcpyAsync(f->logw, f->logw_scratch + off_cur(f), f->n * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
@@ -1320,7 +1346,7 @@ extern "C" int phd_global_resample_indices(phd_filter* f, const float* d_all_log
     w.did_resample = f->did;
     w.n_weight_norm = f->n_global;
     t_begin(f, PHD_K_WEIGHTS);
-    HIPCHK(launch_weights(w, f->stream));
+    HIPCHK(launch_weights_f(f, w));
     t_end(f);
     if (idx_out) {
         HIPCHK(hipMemcpyAsync(idx_out, f->idx, n_global * sizeof(int), hipMemcpyDeviceToHost, f->stream));
@@ -1450,7 +1476,7 @@ static int global_resample_launch(phd_filter* f, const float* d_all_logw, bool n
     w.did_resample = f->did;
     w.n_weight_norm = f->n_global;
     t_begin(f, PHD_K_WEIGHTS);
-    HIPCHK(launch_weights(w, f->stream));
+    HIPCHK(launch_weights_f(f, w));
     t_end(f);
     if (d_idx_out) *d_idx_out = f->idx;
     return PHD_OK;
@@ -1737,7 +1763,7 @@ extern "C" int phd_global_resample_gathered(phd_filter* f, const void* d_all_row
         return PHD_OK;
     }
     t_begin(f, PHD_K_WEIGHTS);
-    HIPCHK(launch_weights(w, f->stream));
+    HIPCHK(launch_weights_f(f, w));
     t_end(f);
     // copy_particles (src/slamtypes.h:313-333): slot j <- gathered row idx[off + j]; weights <- -log N and the map
     // indirection back to identity in the same launch
@@ -1843,12 +1869,21 @@ static int interpret_report(phd_filter* f, const unsigned raw[8], phd_step_repor
     if (out) *out = r;
     if (r.status & PHD_STATUS_TAIL_TIMEOUT) {
         (void)hipStreamSynchronize(f->stream);
+        // what the waiters saw (diagnostics): the hand-off ticket, the arrival counters of the block form's two barriers, its
+        // leavers, and the code of the wait that gave up first (1: ticket, 2 / 3: first / second barrier; << 8: what it read)
+        unsigned seen[5] = {0, 0, 0, 0, 0};
+        (void)hipMemcpy(&seen[0], f->ticket, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&seen[1], f->gw_sync, 16, hipMemcpyDeviceToHost);
+        char where[160];
+        snprintf(where, sizeof(where), " [ticket %u, barrier arrivals %u / %u, leavers %u, first time-out: wait %u read %u]", seen[0], seen[1], seen[2],
+                 seen[3], seen[4] & 255u, seen[4] >> 8);
         (void)hipMemsetAsync(f->ticket, 0, 4, f->stream);
+        (void)hipMemsetAsync(f->gw_sync, 0, 16, f->stream);
         const unsigned cleared = r.status & ~(unsigned)PHD_STATUS_TAIL_TIMEOUT;
         (void)hipMemcpyAsync(f->status, &cleared, 4, hipMemcpyHostToDevice, f->stream);
         (void)hipStreamSynchronize(f->stream);
-        return fail(PHD_ERR_HIP, "fused step: the weights workgroup timed out waiting for the particles' workgroups "
-                                 "(step failed; the hand-off counter has been reset)");
+        return fail(PHD_ERR_HIP, std::string("fused step: the weights workgroup timed out waiting for the particles' workgroups "
+                                             "(step failed; the hand-off counter has been reset)") + where);
     }
     if (r.status) return fail(PHD_ERR_CAPACITY, std::string("device capacity overflow:") + ((r.status & 1) ? " map_capacity" : "") +
                                                     ((r.status & 2) ? " survivor_capacity" : ""));

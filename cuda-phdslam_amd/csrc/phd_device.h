@@ -57,6 +57,10 @@ struct WeightArgs {
     int* parent_out;
     int n_weight_norm;
     unsigned long long* wstamps; // [8] phase stamps (diagnostics) or NULL
+    // block form of the routine (n > 4096, phd_weights.h: weights_grid_body): arrival counters of its grid-wide barriers
+    // ([0], [1]: the two barriers, [2]: leavers; zero between launches) and one record of 8 words per block of 256 weights
+    unsigned* gsync;
+    float* gpart;
 };
 
 struct UpdateArgs {
@@ -127,9 +131,14 @@ size_t cphd_lds_bytes(int S_cap, int cn_len, int MM);   // extra LDS of the CPHD
 hipError_t launch_copy_rows(const float* src, size_t src_stride, const int* a, const int* b, float* dst, size_t dst_stride,
                             const int* c, int len, int n, hipStream_t st);
 int update_fuse_max_particles();
+int weights_grid_min_particles();          // particle counts above this take the block form of the weights routine
+int weights_grid_workgroups(int n);        // workgroups it runs on
+size_t weights_grid_lds_bytes(int n);      // LDS it needs (block ends of the CDF)
 
-hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st);
-int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, int n_particles);   // what the runtime says a CU holds (-1: query failed)
+// three_per_cu: the filter's build, decided once at phd_create by update_takes_three_per_cu() (the 80-register instantiations)
+bool update_takes_three_per_cu(bool cphd, bool spill, size_t lds_bytes, int n_base);
+hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st, bool three_per_cu);
+int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_per_cu);   // what the runtime says a CU holds (-1: query failed)
 #define PHD_MAX_PEERS 16        // shards whose memory one pull kernel can read (phd_global_resample_pull)
 hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank, float* dst,
                                 int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,
@@ -142,7 +151,7 @@ hipError_t launch_predict_shotgun(const phd_pose* in, phd_pose* out, int n_pred,
                                   const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,
                                   const int* parent_in, int* parent_out, const float* logw_in, float* logw_out,
                                   hipStream_t st);
-hipError_t launch_weights(const WeightArgs& a, hipStream_t st);
+hipError_t launch_weights(const WeightArgs& a, hipStream_t st, unsigned* status);   // status: the filter's status word (time-out bit of the block form)
 hipError_t launch_pack_maps(const phd_gaussian2d* concat, const int* offsets, const int* sizes, float* slabs, int cap,
                             int n, hipStream_t st);
 hipError_t launch_unpack_maps(const float* slabs, const int* parent, const int* offsets, const int* counts,

@@ -75,7 +75,19 @@ namespace phd {
 #endif
 #ifndef PHD_PART_TU
 size_t update_lds_bytes(int S, int C, int MM) { return lds_offsets(S, C, MM).total + PHD_LDS_PAD; }
-int update_fuse_max_particles() { return PHD_T * 8; } // weights_body<PHD_T, 8> of the fused step
+// the fused step: up to 4096 particles weights_body<PHD_T, 8> in one workgroup of the launch, above (up to 2^18) the block form
+// on grid_weights_workgroups(n) workgroups behind the particles' (phd_weights.h)
+int update_fuse_max_particles() { return 1 << 18; }
+int weights_grid_min_particles() { return PHD_GRID_WEIGHTS_MIN; }
+int weights_grid_workgroups(int n) { return grid_weights_workgroups(n); }
+size_t weights_grid_lds_bytes(int n) { return grid_weights_lds_bytes(n); }
+
+// the block form of the weights routine as a launch of its own (a plain __global__ function: defined once, here)
+__global__ __launch_bounds__(PHD_T) void phd_weights_grid_kernel(WeightArgs A, unsigned* status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_gwdyn[];
+    weights_grid_body<false>(A, (int)blockIdx.x, (int)gridDim.x, s_gwdyn, status, nullptr);
+}
 size_t cphd_lds_bytes(int S_cap, int cn_len, int MM) { return cphd_extra_lds_bytes(S_cap, cn_len, MM); }
 
 #endif // !PHD_PART_TU
@@ -131,7 +143,12 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #define PHD_TRACE_HANDOFF() do {} while (0)
 #define PHD_TRACE_AT(k) do {} while (0)
 #endif
-    if (FUSEW && blockIdx.x == gridDim.x - 1) {
+    // GRID_TAIL: the builds whose fused tail may be the block form of the weights routine (several workgroups behind the particles',
+    // N > 4096) - the three-per-CU PHD builds.  Every other build keeps the single tail workgroup and, textually, the code it had:
+    // the 80-register CPHD build lost 3.3 % at 4096 x 256 x 64 to 27 more spilled scalars when this branch merely tested
+    // `blockIdx.x >= A.wa.n` (its code generation moves with unrelated source).
+    constexpr bool GRID_TAIL = MINW >= 6 && !CPHD;
+    if (FUSEW && (GRID_TAIL ? (int)blockIdx.x >= A.wa.n : blockIdx.x == gridDim.x - 1)) {
         // ---- fused step: the weights / nEff / resample routine has a workgroup of its own (the grid is N + 1).
         // It needs the particles' log-weight increments, predicted poses and map indirection — all known once a
         // particle's workgroup is past pass 1 — but not the merged maps (resampling moves indices, not maps).  So it
@@ -140,7 +157,12 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         // stores agent-scope, drains them and adds one to the ticket counter; this workgroup polls the counter
         // (agent scope, bounded) and then reads with sc1 loads.  Only this workgroup ever waits, and for workgroups
         // that wait for nothing, so the order in which the dispatcher places them does not matter.
-        const unsigned n_wg = gridDim.x - 1;
+        // Above 4096 particles the routine is the block form on several workgroups (phd_weights.h: weights_grid_body) - the grid is
+        // N + W; each of them waits for the particles' tickets itself, and the LAST to leave re-arms the counters.  The dispatcher
+        // starts workgroups in index order, so these take slots that the end of the launch would leave empty anyway; and should
+        // they start early they hold slots, not progress: a particle's workgroup never waits for them.
+        const unsigned n_wg = GRID_TAIL ? (unsigned)A.wa.n : gridDim.x - 1;
+        const bool grid_form = GRID_TAIL && A.wa.n > PHD_GRID_WEIGHTS_MIN;
         __shared__ int s_tail_ok;
         if (tid == 0) {
             unsigned spins = 0;
@@ -157,8 +179,13 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
             // time-out: the particles' workgroups are still adding to the ticket, so it is NOT reset here and the routine
             // does NOT run on incomplete data; the status bit makes the host fail the step and re-zero the ticket
             // (phd_device_status / phd_step_report)
-            if (ok) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            else atomicOr(A.status, PHD_STATUS_TAIL_TIMEOUT);
+            // (the block form re-arms the ticket itself: by the last of its workgroups to leave)
+            if (ok) { if (!grid_form) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // ready for the next launch
+            else {
+                atomicOr(A.status, PHD_STATUS_TAIL_TIMEOUT);
+                if constexpr (GRID_TAIL)
+                    if (A.wa.gsync) atomicCAS(&A.wa.gsync[3], 0u, 1u | (__hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8));
+            }
             s_tail_ok = ok ? 1 : 0;
         }
         __syncthreads();
@@ -171,7 +198,14 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         // phd_step_dev and the staged calls agree bit for bit.  Up to 512 particles that is four waves; the other
         // four leave first: the routine's barriers then wait for half as many waves
         const bool shrink = A.wa.n_new <= A.wa.n;   // (the register-resident routine commits logw[j], j < n)
-        if (A.wa.n <= 256 && shrink) {
+        if (grid_form) {
+            // (only the three-per-CU builds of the PHD filter carry it: the 80-register CPHD build lost 3.3 % at 4096 x 256 x 64 with
+            // the routine inlined - its code generation moves with unrelated source, DESIGN.md section 7 - and a CPHD filter of more
+            // than 4096 particles takes the second launch as before; a launch of more than 4096 particles always has more than two workgroups per
+            // CU to place; inlined into the two-per-CU builds its scalar values made the PARTICLES' path of the CPHD instantiation
+            // reload spilled LDS pointers inside merge_small's inner loops, tests/test_kernel_resources.py.  phd_api.cpp: can_fuse)
+            if constexpr (GRID_TAIL) weights_grid_body<true>(A.wa, (int)blockIdx.x - A.wa.n, (int)gridDim.x - A.wa.n, lds_raw, A.status, A.ticket);
+        } else if (A.wa.n <= 256 && shrink) {
             if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread
         } else if (A.wa.n <= 512 && shrink) {
             if (tid < 256) weights_body<256, 2, true>(A.wa, lds_raw);
@@ -1095,19 +1129,27 @@ static bool three_granted(int fn, size_t lds_bytes)
     return ok;
 }
 
-static int update_fn_index(const UpdateArgs& a, size_t lds_bytes, int n_particles)
+// Which build a filter runs is decided ONCE, when the filter is created (phd_create stores the answer): the 80-register
+// build pays ~2 % (and more on the critical path of a lone workgroup) for the right to a third resident workgroup, so it is taken
+// only where LDS admits three, the runtime grants them AND the filter's base particle count has more than two workgroups per CU
+// to place.  (Until round 4 this was re-derived from the launch's particle count on every launch: two hipGetDevice calls, a mutex
+// and a map lookup per launch, and a filter whose count changes (the particle shotgun, phd_set_particle_count) could hop between
+// builds.)  Call with the filter's device current.
+bool update_takes_three_per_cu(bool cphd, bool spill, size_t lds_bytes, int n_base)
+{
+    if (spill || 3 * (lds_bytes + 1024) > 160 * 1024 || n_base <= 2 * device_cu_count()) return false;
+    return three_granted(cphd ? 13 : 10, lds_bytes);
+}
+
+static int update_fn_index(const UpdateArgs& a, bool three)
 {
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
     const bool fused = a.fuse_weights && !a.stamps;
-    // the 80-register build pays ~2 % (and more on the critical path of a lone workgroup) for the right to a third resident
-    // workgroup: only where LDS admits three AND the launch has more than two workgroups per CU to place
-    const bool three = !sp && 3 * (lds_bytes + 1024) <= 160 * 1024 && n_particles > 2 * device_cu_count();
-    const int fn3 = (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
-    if (three && three_granted(fn3, lds_bytes)) return fn3;
+    if (three && !sp) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }
 
-hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st)
+hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st, bool three_per_cu)
 {
     // function attributes are per device: set once for every device this process launches on (thread-safe: filters on
     // different devices may be driven by different host threads)
@@ -1126,18 +1168,19 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         if (e != hipSuccess) return e;
     }
     const bool fused = a.fuse_weights && !a.stamps;
-    const int fn = update_fn_index(a, lds_bytes, n_particles);
-    const dim3 grid(n_particles + (fused ? 1 : 0)), b(PHD_T);      // + the weights workgroup of the fused step
+    const int fn = update_fn_index(a, three_per_cu);
+    // + the weights workgroup(s) of the fused step: one up to 4096 particles, the block form's above
+    const dim3 grid(n_particles + (fused ? (n_particles > PHD_GRID_WEIGHTS_MIN ? grid_weights_workgroups(n_particles) : 1) : 0)), b(PHD_T);
     UpdateArgs args = a;
     void* argv[] = {(void*)&args};
     return hipLaunchKernel(k_update_fns[fn], grid, b, argv, lds_bytes, st);
 }
 
 // workgroups of the update kernel a CU holds at a time for this filter (the runtime's own count: LDS, registers, waves)
-int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, int n_particles)
+int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_per_cu)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_update_fns[update_fn_index(a, lds_bytes, n_particles)], PHD_T, lds_bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_update_fns[update_fn_index(a, three_per_cu)], PHD_T, lds_bytes) != hipSuccess) return -1;
     return n;
 }
 
@@ -1175,8 +1218,14 @@ hipError_t launch_predict_shotgun(const phd_pose* in, phd_pose* out, int n_pred,
     return hipGetLastError();
 }
 
-hipError_t launch_weights(const WeightArgs& a, hipStream_t st)
+hipError_t launch_weights(const WeightArgs& a, hipStream_t st, unsigned* status)
 {
+    // above 4096 weights: the block form on several workgroups (phd_weights.h) - chosen by n ALONE, so that every caller and
+    // every launch shape (this launch, the fused tail of the update kernel, every shard of a sharded filter) gets the same bits
+    if (a.n > PHD_GRID_WEIGHTS_MIN && a.n_new <= a.n && a.gsync && a.gpart) {
+        hipLaunchKernelGGL(phd_weights_grid_kernel, dim3(grid_weights_workgroups(a.n)), dim3(PHD_T), grid_weights_lds_bytes(a.n), st, a, status);
+        return hipGetLastError();
+    }
     // one workgroup; small particle sets use a small one (cheaper barriers, same results: the
     // reductions are fixed trees per block size)
     // (the commit of the small kernel writes logw[j] for j < n: it needs n_new <= n, true for every caller)

@@ -458,4 +458,313 @@ __global__ __launch_bounds__(BT) void phd_weights_small_kernel(WeightArgs A)
     weights_body<BT, R, false>(A, s_wdyn);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Large particle sets (n > PHD_GRID_WEIGHTS_MIN): the routine on SEVERAL workgroups, no CDF in LDS (round 5).
+//
+// The single-workgroup forms above keep the fixed-point CDF of all n weights in LDS (128 KB at 16 384 particles: a whole CU,
+// 27-31 us, a second launch after the update kernel, and on a sharded filter pure serial tail repeated by every shard).  Here the
+// vector is cut into BLOCKS of 256 consecutive weights; a workgroup of 512 threads takes two blocks per pass, one weight per
+// thread, and the workgroups meet at two grid-wide barriers (an arrival counter in HBM; data crosses with sc1 stores, a drained
+// vmcnt and sc1 loads - the hand-off of the fused step, cdna guide Guideline 16):
+//
+//   pass A   x_i = logw_i (+ dlogw_i);  per block  m_b = max x_i,  s_b = sum expf(x_i - m_b)            -> part[b]
+//   -------- barrier --------
+//   combine  mx = max_b m_b;  S = SUM_b s_b expf(m_b - mx);  lse = safe_log(S) + mx                        (every workgroup, same bits)
+//   pass B   w_i = x_i - lse -> logw;  per block  e_b = sum expf(2 w_i);  q_i = fixed-point det_exp(w_i); in-block inclusive
+//            scan of q -> cdf[i] (HBM, u64), block total, first maximum of p                              -> part[b]
+//   -------- barrier --------
+//   combine  nEff = 1 / (SUM_b e_b) / n, decision; block prefix of the totals (integers: associative)      (every workgroup)
+//   search   a workgroup draws ONLY ITS OWN slots j: threshold T_j, block by a search over the block ends (LDS), position by a
+//            search over that block's scan (8 probes, L2), copy_particles for the slot
+//
+// THE BITS DEPEND ON n ALONE - not on the number of workgroups, not on which of them takes a block: a block's sums are
+// one fixed tree (64-lane butterfly, then the four waves in order), SUM_b is one fixed tree over the block values (lane l adds
+// the blocks l, l + 64, ... in order, then the butterfly), the CDF is integers.  So the staged launch, the fused tail of the
+// update kernel, every shard of a sharded filter and the gathered vector of a multi-GPU run agree bit for bit by construction,
+// and the resampling indices equal the oracle's (o_resample) on the same weights as before.  (The log-sum-exp differs from the
+// one-workgroup forms in its rounding - per-block maxima folded by expf(m_b - mx) - which is why the form is chosen by n alone.)
+// ------------------------------------------------------------------------------------------
+#define PHD_GRID_WEIGHTS_MIN 4096        // n above this takes the block form (every caller, every launch shape)
+#define PHD_GW_REC 8                     // 32-bit words per block record: m, s, e2, besti, Qtot (2), best (2)
+
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 ld_sc1(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// grid-wide barrier of the W workgroups of the routine: every thread has issued its sc1 stores; drain them, meet, one lane
+// arrives and polls.  -> false on a time-out (~seconds: never in practice; the caller leaves without touching the counters)
+__device__ __forceinline__ bool grid_weights_barrier(unsigned* ctr, unsigned W, int tid, LDS_T(int)* s_ok, unsigned* diag, unsigned code)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < W) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) { ok = false; break; }
+        }
+        if (!ok) atomicCAS(diag, 0u, code | (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8));   // (first time-out only)
+        *s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// the fixed tree over block values: lane l adds the blocks l, l + 64, ... in order, then the butterfly (one wave; every lane
+// returns the result).  `term(b)` is evaluated for b < B only.
+template <class F>
+__device__ __forceinline__ float blocks_sum(int B, int lane, F term)
+{
+    float acc = 0.f;
+    for (int b = lane; b < B; b += 64) acc += term(b);
+    return wave_sum(acc);
+}
+
+// g: this workgroup's index among the W of the routine.  s_dyn: (B + 16) * 8 bytes of LDS.  ticket (fused step): the arrival
+// counter of the particles' workgroups, reset by the last workgroup of the routine to leave.
+template <bool HANDOFF>
+__device__ __forceinline__ void weights_grid_body(const WeightArgs& A, int g, int W, unsigned char* s_dyn, unsigned* status, unsigned* ticket)
+{
+    // (PHD_T = 512 threads: two blocks of 256 per pass)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = tid >> 8, wq = wv & 3;   // wq: wave within its block
+    const int n = A.n, B = (n + 255) >> 8;
+    LDS_T(u64)* const s_qend = (LDS_T(u64)*)(LDS_T(unsigned char)*)s_dyn;                        // [B] inclusive block ends of the CDF
+    LDS_T(float)* const s_f = (LDS_T(float)*)(s_qend + B);                                       // [16] wave partials, [16..20) globals
+    LDS_T(u64)* const s_q = (LDS_T(u64)*)(s_f + 24);                                             // [8]
+    LDS_T(double)* const s_bv = (LDS_T(double)*)(s_q + 8);                                       // [8]
+    LDS_T(int)* const s_bi = (LDS_T(int)*)(s_bv + 8);                                            // [8] + [8] flags
+    LDS_T(int)* const s_ok = s_bi + 8;
+    float* const part = A.gpart;
+    u64* const cdf = (u64*)A.cdf;
+    const bool normalize = (A.mode & W_NORMALIZE) != 0;
+    const bool may_resample = (A.mode & (W_RESAMPLE_FORCE | W_RESAMPLE_AUTO)) != 0;
+    const size_t ls = A.in_stride ? (size_t)A.in_stride : 1;
+    auto load_x = [&](int i) -> float {
+        float x = A.logw_in[(size_t)i * ls];
+        if (A.mode & W_ACCUMULATE) x += ld_f32<HANDOFF>(&A.dlogw[i]);
+        return x;
+    };
+    // sum of a block's 256 values: butterfly per wave, then the block's four waves in order
+    auto block_sum4 = [&](float v) -> float {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) s_f[wv] = v;
+        __syncthreads();
+        const int w0 = half * 4;
+        return ((s_f[w0] + s_f[w0 + 1]) + s_f[w0 + 2]) + s_f[w0 + 3];
+    };
+    float lse = 0.f;
+    // ---- pass A: block maxima and shifted sums (only when the vector is to be normalised)
+    if (normalize) {
+        for (int b0 = 2 * g; b0 < B; b0 += 2 * W) {
+            const int b = b0 + half, i = 256 * b + (tid & 255);
+            const bool live = b < B && i < n;
+            const float x = live ? load_x(i) : -FLT_MAX;
+            if (live && A.raw_out) A.raw_out[i] = x;
+            float m = wave_max_f(x);
+            __syncthreads();
+            if (lane == 0) s_f[8 + wv] = m;
+            __syncthreads();
+            const int w0 = 8 + half * 4;
+            m = fmaxf(fmaxf(s_f[w0], s_f[w0 + 1]), fmaxf(s_f[w0 + 2], s_f[w0 + 3]));
+            const float s = block_sum4(live ? expf(x - m) : 0.f);
+            if (b < B && (tid & 255) == 0) { st_sc1(&part[PHD_GW_REC * b], m); st_sc1(&part[PHD_GW_REC * b + 1], s); }
+        }
+        if (!grid_weights_barrier(&A.gsync[0], (unsigned)W, tid, s_ok, &A.gsync[3], 2u)) { if (tid == 0) atomicOr(status, PHD_STATUS_TAIL_TIMEOUT); return; }
+        if (wv == 0) {
+            float mx = -FLT_MAX;
+            for (int b = lane; b < B; b += 64) mx = fmaxf(mx, ld_sc1(&part[PHD_GW_REC * b]));
+            mx = wave_max_f(mx);
+            const float S = blocks_sum(B, lane, [&](int b) { return ld_sc1(&part[PHD_GW_REC * b + 1]) * expf(ld_sc1(&part[PHD_GW_REC * b]) - mx); });
+            if (lane == 0) s_f[16] = safe_log(S) + mx;
+        }
+        __syncthreads();
+        lse = s_f[16];
+    } else if (A.raw_out && (A.mode & W_ACCUMULATE)) {
+        for (int b0 = 2 * g; b0 < B; b0 += 2 * W) {
+            const int i = 256 * (b0 + half) + (tid & 255);
+            if (i < n) A.raw_out[i] = load_x(i);
+        }
+    }
+    // ---- pass B: normalised weights out, nEff terms, fixed-point CDF per block
+    const int sb = cdf_scale_bits(n);
+    const double scale = ldexp(1.0, sb);
+    for (int b0 = 2 * g; b0 < B; b0 += 2 * W) {
+        const int b = b0 + half, i = 256 * b + (tid & 255);
+        const bool live = b < B && i < n;
+        float w = -FLT_MAX;
+        if (live) {
+            w = load_x(i);
+            if (normalize) w -= lse;
+            if (A.logw) A.logw[i] = w;
+        }
+        const float e2 = block_sum4(live ? expf(2 * w) : 0.f);
+        u64 q = 0, qtot = 0;
+        double best = -1.0;
+        int besti = 0x7FFFFFFF;
+        if (may_resample) {
+            if (live) {
+                const double p = det_exp(w);
+                q = cdf_quantise(p, scale);
+                best = p; besti = i;
+            }
+            u64 incl = wave_incl_scan(q);
+            // first maximum of p in the wave (strict '>': the lowest index among equals)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = xor_lane(best, off);
+                const int oi = xor_lane(besti, off);
+                if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+            }
+            if (lane == 63) s_q[wv] = incl;
+            if (lane == 0) { s_bv[wv] = best; s_bi[wv] = besti; }
+            __syncthreads();
+            const int w0 = half * 4;
+            u64 before = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 c = s_q[w0 + k];
+                if (k < wq) before += c;
+                qtot += c;
+                if (s_bv[w0 + k] > best || (s_bv[w0 + k] == best && s_bi[w0 + k] < besti)) { best = s_bv[w0 + k]; besti = s_bi[w0 + k]; }
+            }
+            incl += before;
+            if (live) st_sc1(&cdf[i], incl);
+            __syncthreads();
+        }
+        if (b < B && (tid & 255) == 0) {
+            st_sc1(&part[PHD_GW_REC * b + 2], e2);
+            st_sc1((int*)&part[PHD_GW_REC * b + 3], besti);
+            st_sc1((u64*)&part[PHD_GW_REC * b + 4], qtot);
+            st_sc1((u64*)&part[PHD_GW_REC * b + 6], (u64)__double_as_longlong(best));
+        }
+    }
+    if (!grid_weights_barrier(&A.gsync[1], (unsigned)W, tid, s_ok, &A.gsync[3], 3u)) { if (tid == 0) atomicOr(status, PHD_STATUS_TAIL_TIMEOUT); return; }
+    // ---- nEff and the decision (src/main.cpp:1281-1297): every workgroup, the same bits
+    if (wv == 0) {
+        const float s2 = blocks_sum(B, lane, [&](int b) { return ld_sc1(&part[PHD_GW_REC * b + 2]); });
+        if (lane == 0) s_f[17] = s2;
+    }
+    // block ends of the CDF: inclusive prefix of the block totals (wave 1; integers)
+    if (wv == 1 && may_resample) {
+        u64 run = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            const u64 incl = wave_incl_scan(b < B ? ld_sc1((const u64*)&part[PHD_GW_REC * b + 4]) : 0ull) + run;
+            if (b < B) s_qend[b] = incl;
+            run = lane63_u64(incl);
+        }
+    }
+    __syncthreads();
+    const float s2 = s_f[17];
+    const float neff = (float)(1.0 / (double)s2 / (double)n);
+    int doit = 0;
+    if (A.mode & W_RESAMPLE_FORCE) doit = 1;
+    else if ((A.mode & W_RESAMPLE_AUTO) && (neff <= A.resample_thresh) && (A.mode & W_HAD_MEAS)) doit = 1;   // :1286
+    if (g == 0 && tid == 0) { A.neff_out[0] = neff; A.did_resample[0] = doit; }
+    const int n_new = A.n_new;
+    if (!doit) {
+        const int lim = (A.mode & W_COMMIT) ? n : n_new;
+        for (int b0 = 2 * g; b0 < B; b0 += 2 * W) {
+            const int j = 256 * (b0 + half) + (tid & 255);
+            if (j < lim) {
+                A.idx_out[j] = j;                                                                          // :1292-1296
+                if (A.mode & W_COMMIT) { A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[j]); A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[j]); }
+            }
+        }
+    } else {
+        const u64 ctot = s_qend[B - 1];
+        const double interval = 1.0 / n_new;
+        // the overflow guard (src/main.cpp:475-494): the arg-max of p, needed only if the last threshold exceeds the total mass
+        int argmax = 0;
+        {
+            const int jl = n_new - 1;
+            const double ul = (A.n_uniforms == 1) ? A.u0 : A.uniforms[jl];
+            if ((u64)ceil((jl * interval + ul * interval) * scale) > ctot) {   // uniform
+                if (wv == 0) {
+                    double best = -1.0;
+                    int besti = 0x7FFFFFFF;
+                    for (int b = lane; b < B; b += 64) {
+                        const double ob = __longlong_as_double((long long)ld_sc1((const u64*)&part[PHD_GW_REC * b + 6]));
+                        const int oi = ld_sc1((const int*)&part[PHD_GW_REC * b + 3]);
+                        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double ob = xor_lane(best, off);
+                        const int oi = xor_lane(besti, off);
+                        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+                    }
+                    if (lane == 0) s_bi[0] = besti;
+                }
+                __syncthreads();
+                argmax = s_bi[0];
+            }
+        }
+        const float nlw = (float)(-log((double)A.n_weight_norm));
+        int top = 1;
+        while (top < B) top <<= 1;
+        for (int b0 = 2 * g; b0 < B; b0 += 2 * W) {
+            const int j = 256 * (b0 + half) + (tid & 255);
+            if (j >= n_new) continue;
+            const double u = (A.n_uniforms == 1) ? A.u0 : A.uniforms[j];
+            const u64 T = (u64)ceil((j * interval + u * interval) * scale);                               // :468
+            int idx;
+            if (T > ctot) idx = argmax;                                                                    // :475-494
+            else {
+                // the block: blocks whose end is below T (branch-free lower bound over the block ends, LDS)
+                int c = 0;
+                for (int step = top; step > 0; step >>= 1) {
+                    const int probe = c + step;
+                    if (probe <= B && s_qend[probe - 1] < T) c = probe;
+                }
+                // c < B here (T <= ctot).  Inside block c: entries whose global CDF value is below T (L2, written by another
+                // workgroup: sc1 loads)
+                const u64 base = c ? s_qend[c - 1] : 0ull;
+                const int lo = 256 * c, len = (n - lo < 256) ? (n - lo) : 256;
+                int pos = 0;
+#pragma unroll
+                for (int step = 256; step > 0; step >>= 1) {
+                    const int probe = pos + step;
+                    if (probe <= len && base + ld_sc1(&cdf[lo + probe - 1]) < T) pos = probe;
+                }
+                idx = lo + pos;
+            }
+            A.idx_out[j] = idx;
+            if (A.mode & W_COMMIT) {                                    // copy_particles (src/slamtypes.h:313-333)
+                A.pose_out[j] = ld_pose<HANDOFF>(&A.pose_in[idx]);
+                A.parent_out[j] = ld_i32<HANDOFF>(&A.parent_in[idx]);
+                if (A.logw) A.logw[j] = nlw;
+            }
+        }
+    }
+    // ---- leave: the last workgroup re-arms the counters (and the fused step's ticket) for the next launch
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&A.gsync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == (unsigned)W - 1u) {
+            __hip_atomic_store(&A.gsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.gsync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.gsync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// workgroups the block form runs on: one per two blocks, at most 64 (a workgroup then loops over its blocks)
+__host__ __device__ inline int grid_weights_workgroups(int n)
+{
+    const int w = ((n + 255) / 256 + 1) / 2;
+    return w < 1 ? 1 : (w > 64 ? 64 : w);
+}
+__host__ __device__ inline size_t grid_weights_lds_bytes(int n) { return ((size_t)(n + 255) / 256 + 40) * 8; }
+
+// (phd_weights_grid_kernel, the stand-alone launch of the block form: phd_kernels.hip, main translation unit)
+
 } // namespace phd

@@ -366,3 +366,29 @@ def test_phase_timing_survives_a_run_of_staged_calls(exchange):
             assert np.array_equal(p, ref[k][1]) and np.array_equal(lw, ref[k][2]), k
         ph, n = m.timing_read()
         assert n == steps and ph["local_step"] > 0 and ph["all_gather"] > 0 and ph["weights"] > 0 and ph["import"] > 0, (n, ph)
+
+
+@pytest.mark.parametrize("shards,exchange", [(2, "pull"), (4, "alltoall"), (1, "pull")])
+def test_sharded_filter_above_4096_particles_equals_one_filter(shards, exchange):
+    """8192 particles: every shard runs the BLOCK FORM of the weights routine (round 5: several workgroups, two grid-wide barriers,
+    the bits a function of n alone) on the gathered vector, the single filter runs it fused behind its update workgroups (grid
+    N + W) and staged — particles, weights and maps bit for bit, forced and nEff-triggered resamples"""
+    P, S, MM = pkg(), synthetic(), mod()
+    N, steps = 8192, 3
+    w = S.make_workload(N, 6, 4, seed=411, n_meas_sets=steps)
+    w["logw"] = (w["logw"] + np.linspace(0, 5.0, N).astype(np.float32)).astype(np.float32)
+    cfg = P.default_config(n_particles=N, resampleThresh=0.6)
+    ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]
+    force = [True, False, True]
+    ref = run_single(cfg, w, steps, 32, 8, False, force)
+    with MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=32, max_measurements=8, exchange=ex, gathered_limit_bytes=1) as m:
+        m.seed(77)
+        m.set_particles(w["poses"], w["logw"])
+        m.set_maps(w["maps"], w["sizes"])
+        for k in range(steps):
+            did = m.step((2.0, 0.05 - 0.01 * k), w["noise"][k], w["z"][k], w["uniform"][k], force_resample=force[k])
+            assert did == ref[k][0], k
+            p, lw = m.get_particles()
+            assert np.array_equal(p, ref[k][1]) and np.array_equal(lw, ref[k][2]), k
+            for a, b in zip(m.get_maps(), ref[k][3]):
+                assert np.array_equal(a, b), k

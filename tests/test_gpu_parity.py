@@ -230,6 +230,48 @@ def test_two_and_three_per_cu_builds_agree_bit_for_bit():
             assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), ft
 
 
+@pytest.mark.parametrize("ft", [0, 1])
+def test_two_and_three_per_cu_builds_agree_at_the_headline_layout(ft, monkeypatch):
+    """the two builds were compared only at 640 / 320 particles with 128 map slots.  Here the HEADLINE layout —
+    1024 survivor slots, map capacity 512, 64 measurements, the clustered bench map of 256 Gaussians — runs the same 768
+    particles through the 107-register build (PHD_UPDATE_BUILD=2) and the 80-register build (=3; the filter's build is fixed at
+    phd_create since round 5) and through the fused single-launch step of both: maps, log-weight increments, survivor lists,
+    normalised weights and resampling indices agree bit for bit (PHD and CPHD)."""
+    P, S = pkg(), synthetic()
+    import torch
+    N, G, M = 768, 256, 64
+    w = S.make_workload(N, G, M, seed=0x5EED0003, clustered=True)
+    cfg = P.default_config(filterType=ft, maxCardinality=255)
+    dev = torch.device("cuda:0")
+    dz = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    dn = torch.from_numpy(w["noise"][0].copy()).to(dev)
+    out = []
+    for build in ("2", "3"):
+        monkeypatch.setenv("PHD_UPDATE_BUILD", build)
+        with make_filter(cfg, w, cap=2 * G, mm=M) as f, make_filter(cfg, w, cap=2 * G, mm=M) as g:
+            r = f.residency()
+            assert r["workgroups_per_cu"] == int(build), r
+            f.debug(True)
+            f.predict((2.0, 0.05), w["noise"][0])
+            f.update(w["z"][0])
+            st = f.status()
+            staged = (f.get_maps(), f.weight_increments(), [f.survivors(p) for p in (0, 5, 400, 767)])
+            torch.cuda.synchronize()
+            g.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, w["uniform"][0], force_resample=True)
+            g.sync()
+            pg, lg = g.get_particles()
+            out.append((staged, (g.get_maps(), pg, lg), st))
+    (sa, fa, sta), (sb, fb, stb) = out
+    assert sta["max_survivors"] == stb["max_survivors"] > 512 and sta["max_map"] == stb["max_map"]
+    for p in range(N):
+        assert np.array_equal(sa[0][p].view(np.uint8), sb[0][p].view(np.uint8)), (ft, p)
+        assert np.array_equal(fa[0][p].view(np.uint8), fb[0][p].view(np.uint8)), (ft, "fused", p)
+    assert np.array_equal(sa[1].view(np.uint32), sb[1].view(np.uint32))
+    assert np.array_equal(fa[1], fb[1]) and np.array_equal(fa[2].view(np.uint32), fb[2].view(np.uint32))
+    for (xa, ia), (xb, ib) in zip(sa[2], sb[2]):
+        assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), ft
+
+
 def test_update_max_measurements_and_full_map():
     """M = 256 (the reference's cap) and a map that fills its slab"""
     P, S = pkg(), synthetic()
@@ -315,7 +357,7 @@ def test_capacity_overflow_is_reported():
 # ----------------------------------------------------------------------------------------------
 # particle weights, nEff, resampling
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 255, 256, 2048, 2049, 5000, 16384, 65536])
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 2048, 2049, 4096, 4097, 5000, 8191, 16384, 33000, 65536])
 def test_resample_bit_exact(n):
     P = pkg()
     rng = np.random.default_rng(n)
@@ -348,6 +390,40 @@ def test_resample_overflow_guard():
         idx = f.resample(0.9)
         assert np.array_equal(idx, O.resample(lw, 0.9))
         assert idx[-1] == 1
+
+
+@pytest.mark.parametrize("n", [4097, 16384, 20000])
+def test_resample_block_form_corners(n):
+    """the block form of the weights routine (n > 4096: several workgroups, block records, two-level search): the overflow guard
+    with the first of several equal maxima in a LATER block than its copies' (src/main.cpp:475-494), all the mass on one particle
+    (first / last / a block boundary), and weights that underflow to q = 0 over whole blocks - indices bit for bit the oracle's"""
+    P = pkg()
+    rng = np.random.default_rng(n)
+    cfg = P.default_config()
+    with P.PhdFilter(cfg, n_particles=n, map_capacity=8, max_measurements=8) as f:
+        # (1) un-normalised weights summing to ~0.6: the tail goes to the arg-max, ties to the lowest index
+        lw = np.full(n, np.log(0.6 / n), np.float32)
+        lw[[300, 2900, n - 5]] = np.float32(np.log(3.0 / n))
+        f.set_particles(None, lw)
+        idx = f.resample(0.77)
+        ref = O.resample(lw, 0.77)
+        assert np.array_equal(idx, ref) and idx[-1] == 300
+        # (2) all the mass on one particle
+        for hot in (0, 255, 256, 4095, 4096, n - 1):
+            lw = np.full(n, -120.0, np.float32)
+            lw[hot] = 0.0
+            f.set_particles(None, lw)
+            idx = f.resample(0.31)
+            assert np.array_equal(idx, O.resample(lw, 0.31)) and np.all(idx == hot), hot
+        # (3) blocks of weights far below the CDF's resolution between live ones
+        lw = rng.normal(0, 1.0, n).astype(np.float32)
+        lw[512:3072] = -90.0
+        lw[n // 2:n // 2 + 700] = -200.0
+        lw = O.normalize_weights(lw)
+        f.set_particles(None, lw)
+        for u in (0.0, 0.5, 0.999999):
+            assert np.array_equal(f.resample(u), O.resample(lw, u)), u
+            f.set_particles(None, lw)
 
 
 def test_resample_carries_maps_and_composes():
@@ -465,11 +541,13 @@ def test_step_sequence_matches_staged_calls_and_oracle():
     assert (sizes == r["sizes"]).mean() > 0.8
 
 
-@pytest.mark.parametrize("N", [1, 2, 65, 256, 257, 512, 513, 1024, 1025, 3000, 4096])
+@pytest.mark.parametrize("N", [1, 2, 65, 256, 257, 512, 513, 1024, 1025, 3000, 4096, 4097, 4608, 5000, 16384, 33000])
 def test_fused_step_equals_staged_calls_across_sizes(N):
     """the single-launch step (update kernel + the weights workgroup that runs beside the merges) against the staged calls,
     bit for bit, at particle counts on both sides of every instantiation boundary of the weights routine (256 / 512 /
-    1024 / 4096), over several steps with forced and nEff-triggered resampling"""
+    1024 / 4096), over several steps with forced and nEff-triggered resampling.  Above 4096 particles both sides run the BLOCK
+    FORM of the routine (round 5: several workgroups, two grid-wide barriers) - as the tail of the one launch (grid N + W) and as
+    a launch of its own: one block short of a pair, a ragged last block, more blocks than workgroups (33 000: 129 blocks on 64)"""
     P, S = pkg(), synthetic()
     w = S.make_workload(N, 6, 4, seed=600 + N % 97, n_meas_sets=4)
     cfg = P.default_config()
