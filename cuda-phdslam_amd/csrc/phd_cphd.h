@@ -944,12 +944,58 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // (the inner products' sums and exponents wait in the — still unused — logZ / zpart arrays for their logarithms)
     LDS_T(int)* const dexp_ = (LDS_T(int)*)L.logZ;
     if (tiles != 1 && wave == PHD_FW) cphd_full_set(Q, M, lane, llam, lam);
+    // Round 5: the UPDATED CARDINALITY beside the backward chains.  The chains occupy waves 0-3 (one per SIMD) for ~10 us while
+    // waves 4-7 used to wait at the barrier - and the cardinality update (p(n) Y0(n) / <Y0,p>: the full-set ESFs, B_n, <Y0,p>;
+    // nothing of the chains) then took the whole workgroup another ~5 us behind it.  Waves 4-7 now run it DURING the chains:
+    // wave 7 takes <Y0,p> / <Y1,p> first, the four waves the table of reciprocals and the scaled a_j, then one n per thread -
+    // the same loop, the same bits.  (On waves 4 and 5 alone - the SIMDs of the upper chain, which has 3 us of slack - the update
+    // itself became the phase's critical path: 13.0 instead of 11.4 us.)  Measured at 4096 x 256 x 64: "weights + cardinality
+    // update" 6.3 -> 0.9 us, the chains 9.7 -> 11.4 us (they share their SIMDs now), 2 590 -> 2 650 steps/s.  Its two tables (1/d, exp(a_j - max a): 8 (cn_len + M + 1) bytes) cannot sit where the serial
+    // form keeps them (zpart and I0 belong to the chains now): they go behind the block's arrays in the survivor planes, when
+    // the block lives there and the planes have the room (4096 x 256 x 64: 2.6 of 9 KB free); else the serial form below.
+    u32 cq_off[12];
+    const u32 blk_bytes = cphd_lds_layout(cn_len, MM, cq_off);
+    const u32 conc_need = align16u(8u * (u32)cn_len) + align16u(8u * (u32)(M + 1));
+    const bool lin_upd = finite_w && (size_t)8 * cn_len <= (size_t)32 * MM;
+    const bool conc = tiles == 1 && lin_upd && cphd_block_in_planes(S_cap, cn_len, MM) &&
+                      32u * (u32)S_cap >= cphd_rows_bytes(MM) + blk_bytes + conc_need;
     if (tiles == 1) {
-        if (rows_in_lds) cphd_esf_chains_f64<true>(Q, (const LDS_T(double)*)rows_l, 64, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
-        else cphd_esf_chains_f64<false>(Q, (const double*)rows_g, MM, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
-        GSTAMP(21, 0);       // wave 0's share of the backward sweep done
-        GSTAMP(22, 192);     // wave 3's
-        if (wave == PHD_NW - 1) cphd_full_set(Q, M, lane, llam, lam);   // (after its share of the sweep: every wave takes part in it)
+        if (conc && wave >= 4) {
+            LDS_T(double)* const inv = (LDS_T(double)*)((lds_u8)L.w + cphd_rows_bytes(MM) + blk_bytes);   // [cn_len] 1 / d
+            LDS_T(double)* const ad = inv + (align16u(8u * (u32)cn_len) >> 3);                            // [M + 1] exp(a_j - max a)
+            LDS_T(int)* const cctr = (LDS_T(int)*)&L.ctr[CTR_WSYNC2];
+            const int t4 = tid - 4 * 64, T4 = PHD_T - 4 * 64;
+            int target = 0;
+            if (wave == PHD_NW - 1) cphd_full_set(Q, M, lane, llam, lam);
+            else {
+                for (int j = t4; j <= M; j += T4 - 64) Q.cnb[j] = Q.efull[j] + ((float)(M - j) * llam - lam) - (float)j * lWq;
+                for (int d = t4; d <= Nmax; d += T4 - 64) inv[d] = d ? 1.0 / (double)d : 0.0;
+            }
+            waves_sync(cctr, 4, target, lane);
+            float amax = -FLT_MAX;
+            for (int j = lane; j <= M; j += 64) amax = fmaxf(amax, Q.cnb[j]);     // every wave the same maximum
+            amax = wave_max_f(amax);
+            for (int j = t4; j <= M; j += T4) ad[j] = Q.cnb[j] > -1e30f ? exp((double)(Q.cnb[j] - amax)) : 0.0;
+            waves_sync(cctr, 4, target, lane);
+            const float lY0c = Q.scal[CQ_LY0];
+            for (int n = t4; n <= Nmax; n += T4) {
+                const int jm = n < M ? n : M;
+                double r = 1.0, sd = ad[jm];
+                for (int j = jm - 1; j >= 0; --j) {
+                    r *= inv[n - j];
+                    if (r < sd * 5.551115123125783e-17) break;                             // 2^-54
+                    sd = __builtin_fma(ad[j], r, sd);
+                }
+                cn_out[n] = sd > 0.0 ? Q.cnq[n] + ((log_scaled(sd, 0) + amax) - Q.lfact[n - jm]) - lY0c : LOG0F;
+            }
+            GSTAMP(23, 256);     // the concurrent cardinality update done (first of its waves)
+        } else {
+            if (rows_in_lds) cphd_esf_chains_f64<true>(Q, (const LDS_T(double)*)rows_l, 64, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
+            else cphd_esf_chains_f64<false>(Q, (const double*)rows_g, MM, M, hsplit, lane, wave, llam, lam, dsum, dexp_, c_lds, sh_row, sh_exp);
+            GSTAMP(21, 0);       // wave 0's share of the backward sweep done
+            GSTAMP(22, 192);     // wave 3's
+            if (wave == PHD_NW - 1) cphd_full_set(Q, M, lane, llam, lam);   // (after its share of the sweep: every wave takes part in it)
+        }
     }
     else if (tiles == 2) cphd_esf_backward_dot<2>(Q, T_scratch, M, lane, wave, llam, lam);
     else cphd_esf_backward_dot<4>(Q, T_scratch, M, lane, wave, llam, lam);
@@ -965,7 +1011,9 @@ __device__ __forceinline__ void cphd_block(const Lds& L, const CphdLds& Q, const
     // updated cardinality (.bak:1409-1411): p(n) Y0(n) / <Y0,p>.  With B_n as above and a_j = log e_j + (M-j) log lambda
     // - lambda - j log Wq (in the cnb array, free by now) the term is B_n + a_j - log (n-j)!: the sum over j costs two LDS
     // reads and a subtraction per term
-    if (finite_w && (size_t)8 * cn_len <= (size_t)32 * MM) {
+    if (conc) {
+        // (done beside the chains, above)
+    } else if (finite_w && (size_t)8 * cn_len <= (size_t)32 * MM) {
         // the same sum in the LINEAR domain (doubles): with a~_j = exp(a_j - max a) and the factorial ratio carried as a
         // running product, sum_j exp(a_j - log (n-j)!) = exp(max a) / (n-jm)! * sum_j a~_j r_j,  r_jm = 1, r_{j-1} = r_j / (n-j+1)
         // (jm = min(n, M): the largest term's factorial is the unit, every other ratio is below one) — a multiply and an fma

@@ -106,7 +106,7 @@ __device__ __forceinline__ Lds lds_carve(lds_u8 base, int S, int C, int MM)
 
 enum { CTR_NSURV = 0, CTR_NIN = 1, CTR_NOUT = 2, CTR_OVERFLOW = 3, CTR_KOUT = 4, CTR_NHEAD = 5, CTR_TMP = 6 /* ..+PHD_NW*2 <= 22 */,
        CTR_NPAIR = 24 /* merge_small: candidate pairs listed for the exact closeness test */,
-       CTR_NCAND = 25 /* pass 1: terms listed for pass 2 */, CTR_WSYNC = 26 /* CPHD block: arrival counter of waves_sync */,
+       CTR_NCAND = 25 /* pass 1: terms listed for pass 2 */, CTR_WSYNC = 26 /* CPHD block: arrival counter of waves_sync */, CTR_WSYNC2 = 27 /* ... of the cardinality update that runs beside the chains */,
        CTR_NNEAR = 30 };
 
 // The merge's first sort is a counting sort on the weight key (phd_sort.h).  Its bucket of a survivor is a FIXED function of
