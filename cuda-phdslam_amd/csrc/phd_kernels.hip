@@ -121,7 +121,11 @@ __device__ __forceinline__ void handoff_ticket(unsigned* ticket)
 // MINW: waves per SIMD the register allocation must allow.  4 = two workgroups per CU (<= 128 VGPRs, what the code wants: 107);
 // 6 = three (<= 80 VGPRs: ~50 registers live in scratch — measured 1.7 % slower at equal residency, 22 % faster when LDS lets the
 // third workgroup in, profiles/r04_three_workgroups.txt).  launch_update_merge picks by the filter's LDS size.
-template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL, int MINW = PHD_MIN_WAVES>
+// GRIDT: the fused step's tail is the BLOCK FORM of the weights routine on several workgroups (launches of more than 4096 particles,
+// grid N + W; phd_weights.h) - an instantiation of its own, so that every other one keeps, textually, the code it had: the routine
+// inlined beside the single tail workgroup cost the 80-register CPHD build 3.3 % (27 more spilled scalars from a changed branch
+// condition alone) and raised the headline build's spills from 451 to 537 VGPRs.
+template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL, int MINW = PHD_MIN_WAVES, bool GRIDT = false>
 __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -143,11 +147,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #define PHD_TRACE_HANDOFF() do {} while (0)
 #define PHD_TRACE_AT(k) do {} while (0)
 #endif
-    // GRID_TAIL: the builds whose fused tail may be the block form of the weights routine (several workgroups behind the particles',
-    // N > 4096) - the three-per-CU PHD builds.  Every other build keeps the single tail workgroup and, textually, the code it had:
-    // the 80-register CPHD build lost 3.3 % at 4096 x 256 x 64 to 27 more spilled scalars when this branch merely tested
-    // `blockIdx.x >= A.wa.n` (its code generation moves with unrelated source).
-    constexpr bool GRID_TAIL = MINW >= 6 && !CPHD;
+    constexpr bool GRID_TAIL = GRIDT;
     if (FUSEW && (GRID_TAIL ? (int)blockIdx.x >= A.wa.n : blockIdx.x == gridDim.x - 1)) {
         // ---- fused step: the weights / nEff / resample routine has a workgroup of its own (the grid is N + 1).
         // It needs the particles' log-weight increments, predicted poses and map indirection — all known once a
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         // starts workgroups in index order, so these take slots that the end of the launch would leave empty anyway; and should
         // they start early they hold slots, not progress: a particle's workgroup never waits for them.
         const unsigned n_wg = GRID_TAIL ? (unsigned)A.wa.n : gridDim.x - 1;
-        const bool grid_form = GRID_TAIL && A.wa.n > PHD_GRID_WEIGHTS_MIN;
+        const bool grid_form = GRID_TAIL;
         __shared__ int s_tail_ok;
         if (tid == 0) {
             unsigned spins = 0;
@@ -199,11 +199,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         // four leave first: the routine's barriers then wait for half as many waves
         const bool shrink = A.wa.n_new <= A.wa.n;   // (the register-resident routine commits logw[j], j < n)
         if (grid_form) {
-            // (only the three-per-CU builds of the PHD filter carry it: the 80-register CPHD build lost 3.3 % at 4096 x 256 x 64 with
-            // the routine inlined - its code generation moves with unrelated source, DESIGN.md section 7 - and a CPHD filter of more
-            // than 4096 particles takes the second launch as before; a launch of more than 4096 particles always has more than two workgroups per
-            // CU to place; inlined into the two-per-CU builds its scalar values made the PARTICLES' path of the CPHD instantiation
-            // reload spilled LDS pointers inside merge_small's inner loops, tests/test_kernel_resources.py.  phd_api.cpp: can_fuse)
+            // (the GRIDT instantiation only: see the template)
             if constexpr (GRID_TAIL) weights_grid_body<true>(A.wa, (int)blockIdx.x - A.wa.n, (int)gridDim.x - A.wa.n, lds_raw, A.status, A.ticket);
         } else if (A.wa.n <= 256 && shrink) {
             if (tid < 256) weights_body<256, 1, true>(A.wa, lds_raw);   // one weight per thread
@@ -700,9 +696,11 @@ extern const void* const k_update_cphd_w6_fns[3] = {(const void*)phd_update_merg
                                                     (const void*)phd_update_merge_kernel<false, true, true, false, 6>};
 #elif defined(PHD_W6_TU)
 // <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
-extern const void* const k_update_w6_fns[3] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
+// + the fused step with the block-form tail (more than 4096 particles)
+extern const void* const k_update_w6_fns[4] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
-                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6>};
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>};
 #elif defined(PHD_CPHD_TU)
 // <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
 extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
@@ -712,7 +710,7 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
                                                  (const void*)phd_update_merge_kernel<false, true, true, true>};
 #else
 extern const void* const k_update_cphd_fns[5];
-extern const void* const k_update_w6_fns[3];
+extern const void* const k_update_w6_fns[4];
 extern const void* const k_update_cphd_w6_fns[3];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
@@ -1050,7 +1048,7 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-static const void* const k_update_fns[16] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
+static const void* const k_update_fns[17] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
                                              k_update_cphd_fns[0], k_update_cphd_fns[1], k_update_cphd_fns[2],
@@ -1058,8 +1056,9 @@ static const void* const k_update_fns[16] = {(const void*)phd_update_merge_kerne
                                              (const void*)phd_update_merge_kernel<false, true, false, true>,
                                              k_update_cphd_fns[3], k_update_cphd_fns[4],
                                              k_update_w6_fns[0], k_update_w6_fns[1], k_update_w6_fns[2],
-                                             k_update_cphd_w6_fns[0], k_update_cphd_w6_fns[1], k_update_cphd_w6_fns[2]};
-#define PHD_N_UPDATE_FNS 16
+                                             k_update_cphd_w6_fns[0], k_update_cphd_w6_fns[1], k_update_cphd_w6_fns[2],
+                                             k_update_w6_fns[3]};
+#define PHD_N_UPDATE_FNS 17
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1141,10 +1140,12 @@ bool update_takes_three_per_cu(bool cphd, bool spill, size_t lds_bytes, int n_ba
     return three_granted(cphd ? 13 : 10, lds_bytes);
 }
 
-static int update_fn_index(const UpdateArgs& a, bool three)
+static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0)
 {
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
     const bool fused = a.fuse_weights && !a.stamps;
+    // the fused step of more than 4096 particles: the instantiation with the block-form tail (three-per-CU PHD build only: can_fuse)
+    if (three && !sp && fused && !a.cphd && n_particles > PHD_GRID_WEIGHTS_MIN) return 16;
     if (three && !sp) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }
@@ -1168,7 +1169,7 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         if (e != hipSuccess) return e;
     }
     const bool fused = a.fuse_weights && !a.stamps;
-    const int fn = update_fn_index(a, three_per_cu);
+    const int fn = update_fn_index(a, three_per_cu, n_particles);
     // + the weights workgroup(s) of the fused step: one up to 4096 particles, the block form's above
     const dim3 grid(n_particles + (fused ? (n_particles > PHD_GRID_WEIGHTS_MIN ? grid_weights_workgroups(n_particles) : 1) : 0)), b(PHD_T);
     UpdateArgs args = a;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the summaries of one tools/gpu_round.sh visit from gpurun_out/ (scratch) into profiles/ (tracked): bash tools/collect_profiles.sh <tag> [prefix]
-tag=${1:?tag}; pre=${2:-r04}
+tag=${1:?tag}; pre=${2:-r05}
 g=gpurun_out; p=profiles
 cp $g/pmc_traffic_cfg2.json $g/pmc_traffic_cfg3.json $g/pmc_sq_cfg2.json $g/pmc_sq_cfg3.json $p/
 cp $g/gpu_tests_$tag.log $p/${pre}_gpu_tests.log
