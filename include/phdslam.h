@@ -391,11 +391,13 @@ int phd_debug_get_survivors(phd_filter* f, int particle, phd_gaussian2d* out, in
                             int capacity, int32_t* n_out);
 int phd_debug_get_weight_increments(phd_filter* f, float* dlogw_out);
 /* how the update kernel of this filter sits on a CU: dynamic LDS bytes per workgroup (one workgroup = one particle) and the
- * workgroups the runtime says a CU holds at a time (registers, LDS and waves taken together; 3 at 4096 x 256 x 64).  Diagnostic. */
+ * workgroups the runtime says a CU holds at a time (registers, LDS and waves taken together; 3 at 4096 x 256 x 64) - for the build
+ * of the kernel this filter was given at phd_create (fixed for its life; environment PHD_UPDATE_BUILD=2|3 forces one).  Diagnostic. */
 int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_out, uint64_t* lds_bytes_out);
 /* status word accumulated on the device: bit0 map overflow, bit1 survivor overflow (-> PHD_ERR_CAPACITY), bit2 the weights
- * workgroup of a fused step gave up waiting for the particles' workgroups (-> PHD_ERR_HIP; a bounded spin of seconds, never
- * seen in practice) */
+ * workgroup(s) of a fused step - or a workgroup of the block-form weights routine (more than 4096 particles) at one of its two
+ * grid-wide barriers - gave up waiting (-> PHD_ERR_HIP; a bounded spin of seconds, never seen in practice; the error text names
+ * the wait and what it read) */
 int phd_device_status(phd_filter* f, uint32_t* status_out, int32_t* max_survivors_out, int32_t* max_map_out);
 /* everything the driver loop tests after a step, in ONE download (replaces the separate phd_device_status + phd_neff
  * round trips; run_synth's tests: src/main.cpp:1281-1311): the sticky status word and high-water marks, and the nEff /

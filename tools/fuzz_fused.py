@@ -32,6 +32,10 @@ def main():
         N = int(rng.choice([1, 2, 7, 64, 65, 200, 256, 257, 511, 600, 1100]))
         G = int(rng.choice([1, 6, 17, 48, 96]))
         M = int(rng.choice([1, 4, 13, 32, 40]))
+        if rng.random() < 0.12:
+            # above 4096 particles: the block form of the weights routine as the fused tail (grid N + W) against the staged launch
+            N = int(rng.choice([4097, 4608, 5000, 7000, 9001]))
+            G, M = int(rng.choice([1, 6])), int(rng.choice([1, 4]))
         over = {}
         if rng.random() < 0.3:
             over.update(filterType=1, maxCardinality=int(rng.choice([31, 63, 127])))
