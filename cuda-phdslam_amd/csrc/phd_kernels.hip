@@ -378,6 +378,12 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     // ---- pass 1: normalisers (phd_pass1.h) -----------------------------------------------------------
     const Pass1Grid p1g = pass1_grid(M);
     pass1_normalisers(L, n_in, M, A.MM, tid, sparse2, c0m);
+#ifdef PHD_DUP_PASS1   // (tools/ab_bench.sh: the sweep run twice - its marginal cost; the candidate list restarted, the sums rewritten)
+    __syncthreads();
+    if (tid == 0) L.ctr[CTR_NCAND] = 0;
+    __syncthreads();
+    pass1_normalisers(L, n_in, M, A.MM, tid, sparse2, c0m);
+#endif
     if (STAMPS && tid == 0) st[23] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (STAMPS && tid == 0) st[24] = __builtin_amdgcn_s_memrealtime();
