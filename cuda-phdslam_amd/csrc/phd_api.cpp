@@ -892,8 +892,8 @@ static bool can_fuse(const phd_filter* f)
     // up to 4096 particles the tail is ONE workgroup with the fixed-point CDF in LDS; above, the block form on several
     // workgroups (phd_weights.h: weights_grid_body), which needs the block ends of the CDF there
     if (f->n <= weights_grid_min_particles()) return (size_t)f->n * 8 <= f->lds_bytes;
-    // (carried by the three-per-CU builds of the update kernel only: phd_kernels.hip)
-    return f->three_per_cu && !f->cphd && weights_grid_lds_bytes(f->n) <= f->lds_bytes;
+    // (PHD filters without a spill list: the instantiations that carry it, phd_kernels.hip)
+    return !f->cphd && !f->spill_cap && weights_grid_lds_bytes(f->n) <= f->lds_bytes;
 }
 
 extern "C" int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_out, uint64_t* lds_bytes_out)

@@ -1054,7 +1054,7 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-static const void* const k_update_fns[17] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
+static const void* const k_update_fns[18] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
                                              k_update_cphd_fns[0], k_update_cphd_fns[1], k_update_cphd_fns[2],
@@ -1063,8 +1063,10 @@ static const void* const k_update_fns[17] = {(const void*)phd_update_merge_kerne
                                              k_update_cphd_fns[3], k_update_cphd_fns[4],
                                              k_update_w6_fns[0], k_update_w6_fns[1], k_update_w6_fns[2],
                                              k_update_cphd_w6_fns[0], k_update_cphd_w6_fns[1], k_update_cphd_w6_fns[2],
-                                             k_update_w6_fns[3]};
-#define PHD_N_UPDATE_FNS 17
+                                             k_update_w6_fns[3],
+                                             // [17] the same block-form tail on the two-per-CU build (a layout that admits two workgroups per CU)
+                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, true>};
+#define PHD_N_UPDATE_FNS 18
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1150,8 +1152,8 @@ static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0)
 {
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
     const bool fused = a.fuse_weights && !a.stamps;
-    // the fused step of more than 4096 particles: the instantiation with the block-form tail (three-per-CU PHD build only: can_fuse)
-    if (three && !sp && fused && !a.cphd && n_particles > PHD_GRID_WEIGHTS_MIN) return 16;
+    // the fused step of more than 4096 particles: the instantiations with the block-form tail (PHD filters without a spill list: can_fuse)
+    if (!sp && fused && !a.cphd && n_particles > PHD_GRID_WEIGHTS_MIN) return three ? 16 : 17;
     if (three && !sp) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }

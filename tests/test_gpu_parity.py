@@ -577,6 +577,43 @@ def test_fused_step_equals_staged_calls_across_sizes(N):
         b.status()
 
 
+@pytest.mark.parametrize("build", ["2", "3"])
+def test_fused_block_form_tail_on_both_builds(build, monkeypatch):
+    """above 4096 particles the fused step's tail is the block form of the weights routine (grid N + W) in an instantiation of its
+    own - one for the three-per-CU build, one for the two-per-CU build; both against the staged calls (update launch + the block
+    form as a launch of its own), bit for bit, forced and nEff-triggered resamples"""
+    P, S = pkg(), synthetic()
+    import torch
+    monkeypatch.setenv("PHD_UPDATE_BUILD", build)
+    N = 6000
+    w = S.make_workload(N, 6, 4, seed=777, n_meas_sets=3)
+    cfg = P.default_config()
+    dev = torch.device("cuda:0")
+    with make_filter(cfg, w, cap=32, mm=8) as a, make_filter(cfg, w, cap=32, mm=8) as b:
+        assert a.residency()["workgroups_per_cu"] >= int(build), a.residency()
+        b.debug(4)
+        for k in range(3):
+            dz = torch.from_numpy(w["z"][k].view(np.uint8).copy()).to(dev)
+            dn = torch.from_numpy(w["noise"][k].copy()).to(dev)
+            torch.cuda.synchronize()
+            force = k != 1
+            a.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), len(w["z"][k]), w["uniform"][k], force_resample=force)
+            a.sync()
+            b.predict((2.0, 0.05), w["noise"][k])
+            b.update(w["z"][k])
+            if force:
+                b.resample(w["uniform"][k])
+            else:
+                b.resample_if_needed(w["uniform"][k], had_measurements=True)
+            pa, la = a.get_particles()
+            pb, lb = b.get_particles()
+            assert np.array_equal(pa, pb) and np.array_equal(la, lb), (build, k)
+            for x, y in zip(a.get_maps(), b.get_maps()):
+                assert np.array_equal(x, y)
+        a.status()
+        b.status()
+
+
 def test_frozen_steps_restart_from_the_same_snapshot():
     """the bench protocol: frozen steps do not commit, so every iteration does identical work"""
     P, S = pkg(), synthetic()

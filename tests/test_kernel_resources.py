@@ -64,8 +64,9 @@ def compiled(tmp_path_factory):
 # <STAMPS, FUSEW, CPHD, SPILL>: the staged / multi-GPU step, the fused single-GPU step, the CPHD variants, and the same
 # with the spill list
 # (+ the launch bound: Li4 = two workgroups per CU, Li6 = three)
-TAGS = ("ILb0ELb0ELb0ELb0ELi4E", "ILb0ELb1ELb0ELb0ELi4E", "ILb0ELb0ELb1ELb0ELi4E", "ILb0ELb1ELb1ELb0ELi4E",
-        "ILb0ELb0ELb0ELb1ELi4E", "ILb0ELb1ELb0ELb1ELi4E", "ILb0ELb0ELb1ELb1ELi4E", "ILb0ELb1ELb1ELb1ELi4E")
+TAGS = ("ILb0ELb0ELb0ELb0ELi4ELb0E", "ILb0ELb1ELb0ELb0ELi4ELb0E", "ILb0ELb0ELb1ELb0ELi4ELb0E", "ILb0ELb1ELb1ELb0ELi4ELb0E",
+        "ILb0ELb0ELb0ELb1ELi4ELb0E", "ILb0ELb1ELb0ELb1ELi4ELb0E", "ILb0ELb0ELb1ELb1ELi4ELb0E", "ILb0ELb1ELb1ELb1ELi4ELb0E",
+        "ILb0ELb1ELb0ELb0ELi4ELb1E")          # (the last: the fused step with the block-form tail, launches above 4096 particles)
 # (+ the GRIDT flag, round 5: the fused step with the block-form tail of the weights routine, launches above 4096 particles)
 TAGS_W6 = ("ILb0ELb0ELb0ELb0ELi6ELb0E", "ILb0ELb1ELb0ELb0ELi6ELb0E", "ILb0ELb0ELb1ELb0ELi6ELb0E", "ILb0ELb1ELb1ELb0ELi6ELb0E",
            "ILb0ELb1ELb0ELb0ELi6ELb1E")
@@ -224,7 +225,7 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
         deep = sum(v for d, v in by_depth.items() if d >= 2)
         # (the spill-list instantiations — filters created with survivor_capacity > 2048, a correctness path, DESIGN.md §7 —
         # carry two more pointers and reload them in the survivor emit loop: per emitted component, not per pair)
-        with_spill_list = "ELb1ELi" in tag[12:]          # the SPILL flag is the fourth
+        with_spill_list = "ELb1ELi" in tag[12:21]          # the SPILL flag is the fourth
         assert deep <= (8 if with_spill_list else 0), (tag, by_depth)
         # depth 1 = the bodies of the phase loops (once per merge round / measurement chunk / CPHD chain step, hundreds to
         # thousands of instructions each): the moves there must stay a small share of the body they sit in
