@@ -1074,7 +1074,7 @@ struct OncePerDevice {
     std::mutex mu;
     std::set<int> done;
 };
-static OncePerDevice g_update_attr, g_weights_attr;
+static OncePerDevice g_update_attr;
 template <typename F>
 static hipError_t once_per_device(OncePerDevice& o, F&& setup)
 {
@@ -1235,37 +1235,28 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st, unsigned* status)
         hipLaunchKernelGGL(phd_weights_grid_kernel, dim3(grid_weights_workgroups(a.n)), dim3(PHD_T), grid_weights_lds_bytes(a.n), st, a, status);
         return hipGetLastError();
     }
-    // one workgroup; small particle sets use a small one (cheaper barriers, same results: the
-    // reductions are fixed trees per block size)
+    // up to 4096 weights: one workgroup, the fixed-point CDF in LDS; small particle sets use a small one (cheaper barriers, same
+    // results: the reductions are fixed trees per block size)
     // (the commit of the small kernel writes logw[j] for j < n: it needs n_new <= n, true for every caller)
-    {
-        const hipError_t e = once_per_device(g_weights_attr, [] {
-            hipError_t e = hipFuncSetAttribute((const void*)phd_weights_split_kernel<1024, 16, 8>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-            if (e != hipSuccess) return e;
-            return hipFuncSetAttribute((const void*)phd_weights_small_kernel<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-        });
-        if (e != hipSuccess) return e;
-    }
     const size_t dyn = (size_t)a.n * 8; // the fixed-point CDF, one u64 per particle
-    // one table for this launcher and for the fused tail of the update kernel : 256 threads up
-    // to 512 particles, 512 up to 4096, 1024 above; R = registers per thread
-    const bool small = a.n_new <= a.n && a.n <= 16384;
+    // one table for this launcher and for the fused tail of the update kernel: 256 threads up
+    // to 512 particles, 512 up to 4096; R = registers per thread.  (Round 4 also had 1024-thread forms with a 128 KB CDF for up to
+    // 16 384 weights: replaced by the block form above.)
+    const bool small = a.n_new <= a.n && a.n <= PHD_GRID_WEIGHTS_MIN;
     if (small) {
         WeightArgs b = a;
         // a pure index draw leaves the weights as they are: no write-back (and no alias for the split kernel to mind)
         if (b.logw == b.logw_in && !(b.mode & (W_ACCUMULATE | W_NORMALIZE | W_COMMIT))) b.logw = nullptr;
         const bool split = (b.mode & (W_RESAMPLE_FORCE | W_RESAMPLE_AUTO)) && b.n > 1024 && b.logw != b.logw_in;
         // (above 1024 particles the index searches and copy_particles are split over 8 workgroups: same bits, a third of the time)
-        if (split && b.n <= 4096) hipLaunchKernelGGL((phd_weights_split_kernel<512, 8, 8>), dim3(8), dim3(512), dyn, st, b);
-        else if (split) hipLaunchKernelGGL((phd_weights_split_kernel<1024, 16, 8>), dim3(8), dim3(1024), dyn, st, b);
+        if (split) hipLaunchKernelGGL((phd_weights_split_kernel<512, 8, 8>), dim3(8), dim3(512), dyn, st, b);
         else if (b.n <= 256) hipLaunchKernelGGL((phd_weights_small_kernel<256, 1>), dim3(1), dim3(256), dyn, st, b);
         else if (b.n <= 512) hipLaunchKernelGGL((phd_weights_small_kernel<256, 2>), dim3(1), dim3(256), dyn, st, b);
         else if (b.n <= 1024) hipLaunchKernelGGL((phd_weights_small_kernel<512, 2>), dim3(1), dim3(512), dyn, st, b);
-        else if (b.n <= 4096) hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, b);
-        else hipLaunchKernelGGL((phd_weights_small_kernel<1024, 16>), dim3(1), dim3(1024), dyn, st, b);
+        else hipLaunchKernelGGL((phd_weights_small_kernel<512, 8>), dim3(1), dim3(512), dyn, st, b);
         return hipGetLastError();
     }
+    // (a resample that GROWS the set, or a caller without the block form's scratch: the general one-workgroup kernel, CDF in HBM)
     if (a.n <= 1024) hipLaunchKernelGGL(phd_weights_kernel<256>, dim3(1), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(phd_weights_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();

@@ -126,29 +126,45 @@ template <int CH>
 __device__ __forceinline__ u32 pass1_octet_packed(const float (&zr)[CH], const float (&zb)[CH], const v4f fa, const v2f fc,
                                                   float c0m, float (&acc)[CH])
 {
-    const float PI_F = 3.14159274f, TWO_PI_F = 6.2831855f, B = -1.7484555e-7f;
+    const float TWO_PI_F = 6.2831855f, B = -1.7484555e-7f;
     const v2f r2 = (v2f){fa.x, fa.x}, b2 = (v2f){fa.y, fa.y}, s00 = (v2f){fa.z, fa.z}, s01 = (v2f){fa.w, fa.w},
-              s11 = (v2f){fc.x, fc.x}, lwb = (v2f){fc.y, fc.y};
+              s11 = (v2f){fc.x, fc.x};
+    // the log-weight straight in base 2 (round 5: one packed multiply less per pair of measurements, +0.6 % at 4096 x 256 x 64):
+    // l2 = lwb log2 e - (0.5 log2 e) d, candidates by l2 against c0m log2 e (c0m carries 1e-3 of slack for exactly such roundings)
+    const float LOG2E = 1.44269504f;
+    const float lwb2s = fc.y * LOG2E, c0m2 = c0m * LOG2E;
+    const v2f lwb2 = (v2f){lwb2s, lwb2s};
     u32 bits = 0;
+    const v2f c0m22 = (v2f){c0m2, c0m2};
 #pragma unroll
-    for (int q = 0; q < CH; q += 2) {
+    for (int q = CH - 2; q >= 0; q -= 2) {                  // descending: v_alignbit shifts the mask left, bit q ends at position q
         const v2f i0 = (v2f){zr[q], zr[q + 1]} - r2;
         const v2f a = (v2f){zb[q], zb[q + 1]} - b2;
         v2f k;
-        k.x = (fabsf(a.x) >= PI_F) ? copysignf(1.f, a.x) : 0.f;
-        k.y = (fabsf(a.y) >= PI_F) ? copysignf(1.f, a.y) : 0.f;
+        // k = sign(a) [|a| >= pi] as trunc(a / pi) (round 5): with c = fl(1 / pi_f) = 0.31830987 the correctly rounded product fl(a c)
+        // is monotone in a, 1.0 at a = pi_f (3.14159274) and 0.99999994 at the float below it, 1.9999999 at the largest difference
+        // this path can see (|z_b|, |b| <= 3.1415925) - the same k for every float, three instructions per pair of measurements
+        // instead of six (compare / copysign / select twice): +0.5 % at 4096 x 256 x 64, the same bits
+        const v2f kt = a * (v2f){0.31830987f, 0.31830987f};
+        k.x = __builtin_truncf(kt.x);
+        k.y = __builtin_truncf(kt.y);
         v2f i1 = __builtin_elementwise_fma((v2f){-TWO_PI_F, -TWO_PI_F}, k, a);
         i1 = __builtin_elementwise_fma((v2f){-B, -B}, k, i1);
         v2f dist = (i0 * i0) * s00;                                                                    // :1908-1910
         dist = __builtin_elementwise_fma(i0 * i1, s01, dist);
         dist = __builtin_elementwise_fma(i1 * i1, s11, dist);
-        const v2f lw = __builtin_elementwise_fma(dist, (v2f){-0.5f, -0.5f}, lwb);
-        const v2f l2 = lw * (v2f){1.44269504f, 1.44269504f};
-        acc[q] += __builtin_amdgcn_exp2f(l2.x);                                                       // :2205 (= __expf)
+        const v2f l2 = __builtin_elementwise_fma(dist, (v2f){-0.5f * 1.44269504f, -0.5f * 1.44269504f}, lwb2);
+        acc[q] += __builtin_amdgcn_exp2f(l2.x);                                                       // :2205 (= __expf up to the rounding of its argument)
         acc[q + 1] += __builtin_amdgcn_exp2f(l2.y);
-        bits |= (!(lw.x < c0m) ? (1u << q) : 0u) | (!(lw.y < c0m) ? (2u << q) : 0u);                  // NaN stays a candidate
+        // candidate <=> !(l2 < c0m2) (a NaN stays a candidate, as in the dense test), without the compare -> scalar mask -> select -> or
+        // chain and its wait states (7 of the block's 117 instructions were s_nop; round 5): min(l2, c0m2) is c0m2 exactly for a
+        // candidate AND for a NaN (v_min returns the other operand), below it otherwise - so the SIGN BIT of min(l2, c0m2) - c0m2 is set
+        // exactly for the terms that cannot survive, and two v_alignbit shift the pair's bits into the mask
+        const v2f t = (v2f){fminf(l2.x, c0m2), fminf(l2.y, c0m2)} - c0m22;
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t.y), 31);
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t.x), 31);
     }
-    return bits;
+    return ~bits & ((1u << CH) - 1u);
 }
 
 template <int CH>
