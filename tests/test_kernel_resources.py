@@ -247,7 +247,7 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
 # ---------------------------------------------------------------------------------------------------------------------
 HEADLINE = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb0ELb0ELi6ELb0EEEvNS_10UpdateArgsE"    # the fused step, three per CU
 # (round 5: the block-form tail of launches above 4096 particles has an instantiation of its own; this one is round 4's code)
-RECORDED = {"code_bytes": 169880, "instructions": 32265, "valu": 18161}
+RECORDED = {"code_bytes": 169232, "instructions": 32150, "valu": 18151}
 
 
 def static_profile(asm, sizes):
@@ -275,7 +275,7 @@ def test_headline_kernel_code_size_and_instruction_counts(compiled):
 # steps/s).  Its static profile and its spill counts are held to recorded values, so the next such move shows up HERE, with the numbers, and
 # not in a bench three weeks later.  Re-record after a deliberate change of the CPHD path: python tests/test_kernel_resources.py
 CPHD_HEADLINE = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb1ELb0ELi6ELb0EEEvNS_10UpdateArgsE"
-RECORDED_CPHD = {"instructions": 44698, "valu": 25987, "sgpr_spill": 81, "vgpr_spill": 458}
+RECORDED_CPHD = {"instructions": 44663, "valu": 25979, "sgpr_spill": 82, "vgpr_spill": 459}
 
 
 def cphd_profile(text, asm):
