@@ -80,6 +80,18 @@ struct phd_filter {
     size_t lds_bytes = 0;
     bool three_per_cu = false;     // the build of the update kernel this filter runs (80 registers, three workgroups per CU): decided at create
 
+    // the map buffers are ONE allocation — [buffer 0 | buffer 1 | guests], n_max slabs each; the guests only on a shard — so
+    // that the indirection, which counts slabs from the start of the CURRENT buffer, can name a slab of either buffer or a
+    // guest: the copy-free resample of a shard (phd_global_resample_pull / _end, phd_kernels.hip) parks a remote parent in a
+    // guest slab and leaves local ones where they are.  counts / CPHD rows: the same layout, so the same index serves all three.
+    float* maps_arena = nullptr;
+    int* counts_arena = nullptr;
+    float* cn_arena = nullptr;
+    float* maps_g = nullptr;      // guests (NULL: not a shard among several)
+    int* counts_g = nullptr;
+    float* cn_g = nullptr;
+    bool copy_free = true;        // PHD_COPY_FREE=0: the copying forms (A/B, tests)
+    int copy_free_resamples = 0;  // global resamples that took the copy-free form (diagnostics)
     float* maps[2] = {nullptr, nullptr};
     int* counts[2] = {nullptr, nullptr};
     int cur = 0;
@@ -108,7 +120,7 @@ struct phd_filter {
     int* max_surv = nullptr;
     int* max_map = nullptr;
     int* d_tmp_int = nullptr; // n entries (selection / slot lists)
-    int* h_plan = nullptr;    // pinned [2 n]: per slot the local parent (or -1) | the received row: phd_global_resample_plan -> _end
+    int* h_plan = nullptr;    // pinned [3 n]: per slot the local parent (or -1) | the received row | the first slot that row fills: phd_global_resample_plan -> _end
     int* d_plan = nullptr;
     unsigned* ticket = nullptr; // arrival counter of the fused step (zero between launches)
     unsigned* gw_sync = nullptr;   // block form of the weights routine (n > 4096): counters of its grid-wide barriers (zero between launches)
@@ -137,7 +149,7 @@ struct phd_filter {
     int lfact_len = 0;
     float2* cphd_scratch = nullptr; // [n_max][MM][MM]: rows of the ESF backward sweep (phd_kernels.hip, cphd_block)
     // migration plan of a global resample in flight (phd_global_resample_begin .. _end)
-    std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots, plan_recv_rows;
+    std::vector<int32_t> plan_idx, plan_local_parent, plan_send, plan_recv_slots, plan_recv_rows, plan_row_first;
     void* send_buf = nullptr;
     size_t send_buf_bytes = 0;
     void* rows_target = nullptr; // caller-owned destination of phd_step_local_rows_dev's rows (in-place all-gather)
@@ -162,6 +174,15 @@ struct phd_filter {
 static int shard_world(const phd_filter* f) { return f->n_base > 0 ? std::max(f->n_global / f->n_base, 1) : 1; }
 static int ng_cur(const phd_filter* f) { return shard_world(f) * f->n; }
 static int off_cur(const phd_filter* f) { return f->n_base > 0 ? (f->global_offset / f->n_base) * f->n : 0; }
+// the first guest slab, counted from the start of the current buffer (the unit of the indirection)
+static int guest_offset(const phd_filter* f) { return (2 - f->cur) * f->n_max; }
+// may this resample take the copy-free form?  Only while the indirection is the identity (no resample since the last update:
+// a guest slab an older indirection names must not be overwritten, and a peer must not find a guest index in this shard's
+// view while this shard rewrites its guests), and, where a parent can be remote, only with a guest buffer
+static bool copy_free_ok(const phd_filter* f, bool remote_possible)
+{
+    return f->copy_free && !f->parent_dirty && f->n == f->n_base && (!remote_possible || f->maps_g != nullptr);
+}
 
 static void fill_devcfg(const phd_slam_config& c, DevConfig& d)
 {
@@ -277,7 +298,15 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     const size_t gmax = std::max<size_t>(std::max(f->n_max, f->n_global), (size_t)shard_world(f) * f->n_max);
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
-    for (int k = 0; k < 2; ++k) { A(dalloc(&f->maps[k], slab)); A(dalloc(&f->counts[k], f->n_max)); }
+    {
+        const int nbuf = shard_world(f) > 1 ? 3 : 2;            // (a guest buffer only where a parent can be remote)
+        A(dalloc(&f->maps_arena, nbuf * slab)); A(dalloc(&f->counts_arena, (size_t)nbuf * f->n_max));
+        if (e == hipSuccess) {
+            for (int k = 0; k < 2; ++k) { f->maps[k] = f->maps_arena + k * slab; f->counts[k] = f->counts_arena + (size_t)k * f->n_max; }
+            if (nbuf == 3) { f->maps_g = f->maps_arena + 2 * slab; f->counts_g = f->counts_arena + 2 * (size_t)f->n_max; }
+        }
+        if (const char* ev = getenv("PHD_COPY_FREE")) f->copy_free = ev[0] != '0';
+    }
     for (int k = 0; k < 3; ++k) { A(dalloc(&f->parent[k], f->n_max)); A(dalloc(&f->pose[k], f->n_max)); }
     A(dalloc(&f->logw, f->n_max)); A(dalloc(&f->logw_alt, f->n_max)); A(dalloc(&f->logw_scratch, gmax));
     A(dalloc(&f->logw_raw, f->n_max)); A(dalloc(&f->dlogw, f->n_max));
@@ -290,8 +319,8 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     f->neff = (float*)f->report + 3; f->did = (int*)f->report + 4;
     A(dalloc(&f->state_pose, 6)); A(dalloc(&f->state_argmax, 1));
     A(dalloc(&f->d_tmp_int, f->n_max));
-    A(dalloc(&f->d_plan, 2 * (size_t)f->n_max));
-    A(hipHostMalloc((void**)&f->h_plan, 2 * (size_t)f->n_max * sizeof(int)));
+    A(dalloc(&f->d_plan, 3 * (size_t)f->n_max));
+    A(hipHostMalloc((void**)&f->h_plan, 3 * (size_t)f->n_max * sizeof(int)));
     A(dalloc(&f->ticket, 1));
     A(dalloc(&f->gw_sync, 4)); A(dalloc(&f->gw_part, 8 * ((gmax + 255) / 256 + 1)));
     A(dalloc(&f->d_offsets, f->n_max + 1)); A(dalloc(&f->d_sizes, gmax));
@@ -303,7 +332,9 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         A(dalloc(&f->spill_tmp, (size_t)f->n_max * f->spill_cap));
     }
     if (f->cphd) {
-        A(dalloc(&f->cn[0], (size_t)f->n_max * f->cn_len)); A(dalloc(&f->cn[1], (size_t)f->n_max * f->cn_len));
+        const size_t rows = (size_t)f->n_max * f->cn_len;
+        A(dalloc(&f->cn_arena, (f->maps_g ? 3 : 2) * rows));
+        if (e == hipSuccess) { f->cn[0] = f->cn_arena; f->cn[1] = f->cn_arena + rows; if (f->maps_g) f->cn_g = f->cn_arena + 2 * rows; }
         A(dalloc(&f->d_lfact, f->lfact_len));
         A(dalloc(&f->cphd_scratch, (size_t)f->n_max * f->MM * f->MM));
     }
@@ -311,10 +342,8 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
         phd_destroy(f);
         return fail(PHD_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(e));
     }
-    hipMemsetAsync(f->maps[0], 0, slab * sizeof(float), f->stream);
-    hipMemsetAsync(f->maps[1], 0, slab * sizeof(float), f->stream);
-    hipMemsetAsync(f->counts[0], 0, f->n_max * sizeof(int), f->stream);
-    hipMemsetAsync(f->counts[1], 0, f->n_max * sizeof(int), f->stream);
+    hipMemsetAsync(f->maps_arena, 0, (f->maps_g ? 3 : 2) * slab * sizeof(float), f->stream);
+    hipMemsetAsync(f->counts_arena, 0, (f->maps_g ? 3 : 2) * (size_t)f->n_max * sizeof(int), f->stream);
     hipMemsetAsync(f->report, 0, 8 * 4, f->stream);
     hipMemsetAsync(f->ticket, 0, 4, f->stream);
     hipMemsetAsync(f->gw_sync, 0, 16, f->stream);
@@ -349,7 +378,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipSetDevice(f->device);
     if (f->stream) hipStreamSynchronize(f->stream);
     for (auto& ev : f->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-    for (int k = 0; k < 2; ++k) { hipFree(f->maps[k]); hipFree(f->counts[k]); }
+    hipFree(f->maps_arena); hipFree(f->counts_arena); hipFree(f->cn_arena);
     for (int k = 0; k < 3; ++k) { hipFree(f->parent[k]); hipFree(f->pose[k]); }
     hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
@@ -357,7 +386,7 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->d_tmp_int); hipFree(f->ticket); hipFree(f->gw_sync); hipFree(f->gw_part); hipFree(f->d_plan);
     if (f->h_plan) hipHostFree(f->h_plan);
     hipFree(f->d_concat); hipFree(f->d_offsets); hipFree(f->d_sizes);
-    hipFree(f->cn[0]); hipFree(f->cn[1]); hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
+    hipFree(f->d_lfact); hipFree(f->cphd_scratch); hipFree(f->send_buf);
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     hipFree(f->spill_rec); hipFree(f->spill_meta); hipFree(f->spill_out); hipFree(f->spill_acc); hipFree(f->spill_tmp);
     gm_workspace_destroy(f->gm);
@@ -548,8 +577,10 @@ extern "C" int phd_get_map_sizes(phd_filter* f, int32_t* sizes_out)
     CHECK_F(f);
     if (!sizes_out) return fail(PHD_ERR_INVALID_ARG, "null output");
     // a parent may be any slab written while the particle set was larger (shotgun): all n_max counts
-    std::vector<int> cnt(f->n_max), par(f->n);
-    HIPCHK(hipMemcpyAsync(cnt.data(), f->counts[f->cur], f->n_max * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    // (and, after a shard's copy-free resample, a slab of the guest buffer: everything from the current buffer to the end)
+    const size_t reach = (size_t)((f->maps_g ? 3 : 2) - f->cur) * f->n_max;
+    std::vector<int> cnt(reach), par(f->n);
+    HIPCHK(hipMemcpyAsync(cnt.data(), f->counts[f->cur], reach * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(par.data(), f->parent[f->pcur], f->n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
     for (int p = 0; p < f->n; ++p) sizes_out[p] = cnt[par[p]];
@@ -1193,6 +1224,7 @@ extern "C" int phd_expected_map(phd_filter* f, phd_gaussian2d* out, int capacity
 }
 
 extern "C" int phd_debug_gm_rounds(phd_filter* f) { return f ? f->gm_rounds : 0; }
+extern "C" int phd_debug_copy_free_resamples(phd_filter* f) { return f ? f->copy_free_resamples : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // CPHD variant: the per-particle cardinality distributions (SynthSLAM::cardinalities, src/slamtypes.h:296)
@@ -1516,6 +1548,8 @@ extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int w
     // a parent equal to the previous one from the same source (systematic indices are non-decreasing, so that is every
     // repeat; were they not, the rule is still the same on both sides).  The receiver fans a row out to its slots.
     f->plan_recv_rows.clear();
+    std::vector<int32_t>& first_slot = f->plan_row_first;     // the first slot each received row fills (the copy-free form parks it there)
+    first_slot.clear();
     int row = -1;
     for (int r = 0; r < world; ++r) {
         send_counts[r] = recv_counts[r] = 0;
@@ -1526,15 +1560,18 @@ extern "C" int phd_global_resample_plan(phd_filter* f, const int32_t* idx, int w
         last = -1;
         for (int j = 0; j < n; ++j)                                 // what this rank needs from rank r, in slot order
             if ((unsigned)(idx[off + j] - r * n) < (unsigned)n) {
-                if (idx[off + j] != last) { ++recv_counts[r]; ++row; last = idx[off + j]; }
+                if (idx[off + j] != last) { ++recv_counts[r]; ++row; last = idx[off + j]; first_slot.push_back(j); }
                 f->plan_recv_slots.push_back(j);
                 f->plan_recv_rows.push_back(row);
             }
     }
     // per-slot form of the same plan for phd_global_resample_end's single launch (pinned: the upload does not stage).  The
     // previous step's upload has completed: the caller synchronised to read this step's indices.
-    for (int j = 0; j < n; ++j) { f->h_plan[j] = f->plan_local_parent[j]; f->h_plan[n + j] = -1; }
-    for (size_t k = 0; k < f->plan_recv_slots.size(); ++k) f->h_plan[n + f->plan_recv_slots[k]] = f->plan_recv_rows[k];
+    for (int j = 0; j < n; ++j) { f->h_plan[j] = f->plan_local_parent[j]; f->h_plan[n + j] = -1; f->h_plan[2 * n + j] = -1; }
+    for (size_t k = 0; k < f->plan_recv_slots.size(); ++k) {
+        f->h_plan[n + f->plan_recv_slots[k]] = f->plan_recv_rows[k];
+        f->h_plan[2 * n + f->plan_recv_slots[k]] = first_slot[f->plan_recv_rows[k]];
+    }
     int rc = ensure_send_buffer(f, std::max<size_t>(f->plan_send.size(), 1) * phd_particle_pack_bytes(f));
     if (rc) return rc;
     if (!f->plan_send.empty()) {
@@ -1580,8 +1617,23 @@ extern "C" int phd_global_resample_end(phd_filter* f, const void* d_recv_buffer)
     // src/slamtypes.h:313-333; the staged trio phd_apply_parents / phd_import_particles_dev / phd_finish_resample does the same
     // in three uploads and four launches)
     const int n = f->n;
-    HIPCHK(hipMemcpyAsync(f->d_plan, f->h_plan, 2 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_plan, f->h_plan, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
     const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3; // a frozen fused predict parks the predicted poses in +1
+    if (copy_free_ok(f, !f->plan_recv_slots.empty())) {
+        // the copy-free form: local parents by indirection, received rows into the guest slabs; the buffers do not flip
+        HIPCHK(launch_resample_end_free(f->parent[f->pcur], f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], f->d_plan, n,
+                                        d_recv_buffer, phd_particle_pack_bytes(f), f->maps_g, f->counts_g, f->cphd ? f->cn_g : nullptr,
+                                        guest_offset(f), f->pose[pnext], f->cap, f->frozen ? nullptr : f->logw,
+                                        (float)(-log((double)f->n_global)), f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1], f->cn_len,
+                                        f->stream));
+        f->plan_local_parent.clear();
+        f->copy_free_resamples++;
+        if (f->frozen) return PHD_OK;
+        f->pose_cur = (f->pose_cur + 1) % 3;
+        f->pcur ^= 1;
+        f->parent_dirty = true;       // the indirection names slabs of the current buffer and guests until the next update
+        return PHD_OK;
+    }
     HIPCHK(launch_resample_end(f->maps[f->cur], f->counts[f->cur], f->parent[f->pcur],
                                f->pose_for_update ? f->pose_for_update : f->pose[f->pose_cur], f->d_plan, n, d_recv_buffer,
                                phd_particle_pack_bytes(f), f->maps[f->cur ^ 1], f->counts[f->cur ^ 1], f->pose[pnext], f->cap,
@@ -1620,6 +1672,20 @@ extern "C" int phd_global_resample_pull(phd_filter* f, const phd_peer_view* view
     // after the resample (src/main.cpp:1289 resamples back to n_particles)
     const int n_src = f->n, n_dst = f->n_base;
     const int pnext = (f->pose_cur + (f->pose_for_update ? 2 : 1)) % 3; // a frozen fused predict parks the predicted poses in +1
+    if (copy_free_ok(f, world > 1)) {
+        // the copy-free form (phd_kernels.hip): only the first slot of a remote parent moves a map, into its guest slab
+        HIPCHK(launch_resample_pull_free(views, world, f->idx, rank * n_dst, n_src, n_dst, rank, f->maps_g, f->counts_g,
+                                         f->cphd ? f->cn_g : nullptr, guest_offset(f), f->pose[pnext], f->cap,
+                                         f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
+                                         f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1], f->cn_len, f->stream));
+        f->copy_free_resamples++;
+        if (f->frozen) return PHD_OK;
+        f->n = n_dst;
+        f->pose_cur = (f->pose_cur + 1) % 3;
+        f->pcur ^= 1;
+        f->parent_dirty = true;       // the indirection names slabs of the current buffer and guests until the next update
+        return PHD_OK;
+    }
     HIPCHK(launch_resample_pull(views, world, f->idx, rank * n_dst, n_src, n_dst, rank, f->maps[f->cur ^ 1], f->counts[f->cur ^ 1],
                                 f->pose[pnext], f->cap, f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
                                 f->frozen ? nullptr : f->parent[f->pcur ^ 1], f->cphd ? f->cn[f->cur ^ 1] : nullptr, f->cn_len,

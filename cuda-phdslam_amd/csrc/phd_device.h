@@ -143,6 +143,14 @@ int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_p
 hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank, float* dst,
                                 int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,
                                 float* cn_dst, int cn_len, hipStream_t st);
+// the copy-free forms (phd_kernels.hip): local parents by indirection, remote ones into the guest slabs; goff = the first guest
+// slab counted from the filter's current buffer
+hipError_t launch_resample_pull_free(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank,
+                                     float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
+                                     float nlw, int* parent_next, int cn_len, hipStream_t st);
+hipError_t launch_resample_end_free(const int* parent, const phd_pose* pose_src, const int* plan, int n, const void* recv, size_t stride,
+                                    float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
+                                    float nlw, int* parent_next, int cn_len, hipStream_t st);
 hipError_t launch_merge_spill(const UpdateArgs& a, int n_particles, hipStream_t st);   // no-op unless a.spill_rec
 hipError_t launch_predict(const phd_pose* in, phd_pose* out, int n, phd_ackerman_control u,
                           const phd_ackerman_noise* noise, uint64_t seed, uint64_t counter, const DevConfig& cfg,

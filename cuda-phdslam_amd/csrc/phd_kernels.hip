@@ -1004,6 +1004,84 @@ __global__ void phd_resample_pull_kernel(PeerViews V, const int* __restrict__ id
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The COPY-FREE forms of the two exchanges above (round 5).  A single filter's resample moves no map: slot j's next update
+// reads slab parent[j].  A shard's resample copied every slot — 32 us at 16 384 x 256, all of it LOCAL traffic — because a
+// remote parent needs a slab of its own on this device.  The map buffers of a filter are ONE allocation [buffer 0 | buffer 1 |
+// guests], n_max slabs each (phd_api.cpp), and the indirection counts slabs from the start of the CURRENT buffer, so it can
+// name a guest: slab goff + j, goff = (2 - cur) n_max.  Local parents stay where they are (parent_next[j] = their slab, as in a
+// single filter); the FIRST slot of a remote parent copies it into guest slab j — the only map traffic, and the only reads that
+// cross the link — and the other slots that parent fills name the same guest.  The next update reads through the indirection
+// and writes the other buffer; nothing is flipped here.  Counts and CPHD cardinality rows are laid out the same way.
+// One workgroup of 64 threads per slot (most write two words and leave).  The callers use these forms only while the shard's
+// indirection is the identity (no resample since the last update): a guest slab named by an older indirection must not be
+// overwritten — the copying forms above take that case.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void copy_slab_wave(const float* __restrict__ a, int cnt, int cap, float* __restrict__ b, int tid, int nt)
+{
+    for (int pl = 0; pl < 6; ++pl)
+        for (int i = tid; i < cnt; i += nt) b[pl * cap + i] = a[pl * cap + i];
+}
+
+__global__ void phd_resample_pull_free_kernel(PeerViews V, const int* __restrict__ idx, int off, int n, int rank,
+                                              float* __restrict__ guests, int* __restrict__ counts_g, float* __restrict__ cn_g,
+                                              int goff, phd_pose* __restrict__ pose_dst, int cap, float* __restrict__ logw_fill,
+                                              float nlw, int* __restrict__ parent_next, int cn_len)
+{
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int g = idx[off + j];
+    const int owner = g / n, lp = g - owner * n;
+    const phd_peer_view& P = V.v[owner];
+    if (tid < 6) ((float*)&pose_dst[j])[tid] = ((const float*)&P.poses[lp])[tid];
+    const int s = P.parent ? P.parent[lp] : lp;          // the owner's slab of that particle (counted from ITS current buffer)
+    if (owner == rank) {
+        if (tid == 7) { if (parent_next) parent_next[j] = s; if (logw_fill) logw_fill[j] = nlw; }
+        return;
+    }
+    const bool first = j == 0 || idx[off + j - 1] != g;
+    if (!first) {
+        if (tid == 7) {
+            int lo = 0, hi = j;                              // the first slot this parent fills: lower bound of g in idx[off .. off + j)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (idx[off + mid] < g) lo = mid + 1; else hi = mid; }
+            if (parent_next) parent_next[j] = goff + lo;
+            if (logw_fill) logw_fill[j] = nlw;
+        }
+        return;
+    }
+    const int cnt = P.counts[s];
+    copy_slab_wave(P.maps + (size_t)s * 6 * cap, cnt, cap, guests + (size_t)j * 6 * cap, tid, (int)blockDim.x);
+    if (cn_g)
+        for (int i = tid; i < cn_len; i += blockDim.x) cn_g[(size_t)j * cn_len + i] = P.cn[(size_t)s * cn_len + i];
+    if (tid == 6) counts_g[j] = cnt;
+    if (tid == 7) { if (parent_next) parent_next[j] = goff + j; if (logw_fill) logw_fill[j] = nlw; }
+}
+
+// plan: [n] the local parent or -1 | [n] the received row | [n] the first slot that row fills
+__global__ void phd_resample_end_free_kernel(const int* __restrict__ parent, const phd_pose* __restrict__ pose_src,
+                                             const int* __restrict__ plan, int n, const unsigned char* __restrict__ recv, size_t stride,
+                                             float* __restrict__ guests, int* __restrict__ counts_g, float* __restrict__ cn_g, int goff,
+                                             phd_pose* __restrict__ pose_dst, int cap, float* __restrict__ logw_fill, float nlw,
+                                             int* __restrict__ parent_next, int cn_len)
+{
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int lp = plan[j];
+    if (lp >= 0) {
+        if (tid < 6) ((float*)&pose_dst[j])[tid] = ((const float*)&pose_src[lp])[tid];
+        if (tid == 7) { if (parent_next) parent_next[j] = parent ? parent[lp] : lp; if (logw_fill) logw_fill[j] = nlw; }
+        return;
+    }
+    const float* o = (const float*)(recv + (size_t)plan[n + j] * stride);
+    const int f0 = plan[2 * n + j];
+    if (tid < 6) ((float*)&pose_dst[j])[tid] = o[tid];
+    if (tid == 7) { if (parent_next) parent_next[j] = goff + f0; if (logw_fill) logw_fill[j] = nlw; }
+    if (f0 != j) return;
+    const int cnt = ((const int*)o)[6];
+    copy_slab_wave(o + 8, cnt, cap, guests + (size_t)j * 6 * cap, tid, (int)blockDim.x);
+    if (cn_g)
+        for (int i = tid; i < cn_len; i += blockDim.x) cn_g[(size_t)j * cn_len + i] = o[8 + 6 * cap + i];
+    if (tid == 6) counts_g[j] = cnt;
+}
+
 // copy_particles for the maps (src/slamtypes.h:313-333): dst[p] = src[parent[sel[p]]] (maps, counts, poses);
 // sel == NULL: identity; sel[p] < 0: slot is filled by phd_import_kernel instead
 __global__ void phd_gather_maps_kernel(const float* __restrict__ src, const int* __restrict__ counts_src,
@@ -1374,6 +1452,29 @@ hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int
     for (int phase = 0; phase < (world > 1 ? 2 : 1); ++phase)
         hipLaunchKernelGGL(phd_resample_pull_kernel, dim3(n_dst), dim3(256), 0, st, V, idx, off, n_src, rank, phase, dst, counts_dst, pose_dst,
                            cap, logw_fill, nlw, parent_next, cn_dst, cn_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_resample_pull_free(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank,
+                                     float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
+                                     float nlw, int* parent_next, int cn_len, hipStream_t st)
+{
+    if (n_dst <= 0) return hipSuccess;
+    if (world > PHD_MAX_PEERS) return hipErrorInvalidValue;
+    PeerViews V = {};
+    for (int k = 0; k < world; ++k) V.v[k] = views[k];
+    hipLaunchKernelGGL(phd_resample_pull_free_kernel, dim3(n_dst), dim3(64), 0, st, V, idx, off, n_src, rank, guests, counts_g, cn_g, goff,
+                       pose_dst, cap, logw_fill, nlw, parent_next, cn_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_resample_end_free(const int* parent, const phd_pose* pose_src, const int* plan, int n, const void* recv, size_t stride,
+                                    float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
+                                    float nlw, int* parent_next, int cn_len, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(phd_resample_end_free_kernel, dim3(n), dim3(64), 0, st, parent, pose_src, plan, n, (const unsigned char*)recv, stride,
+                       guests, counts_g, cn_g, goff, pose_dst, cap, logw_fill, nlw, parent_next, cn_len);
     return hipGetLastError();
 }
 

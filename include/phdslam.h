@@ -251,6 +251,9 @@ int phd_gm_reduce_dev(phd_filter* f, const float* d_planes, int64_t total, int n
                       phd_gaussian2d* out, int capacity, int32_t* n_out);
 /* rounds (window/assign/compact passes) the last reduction took — diagnostics */
 int phd_debug_gm_rounds(phd_filter* f);
+/* global resamples of this shard that took the copy-free form (phd_global_resample_pull / _end: local parents by indirection,
+ * remote ones parked in guest slabs; PHD_COPY_FREE=0 in the environment at phd_create selects the copying forms) — diagnostics */
+int phd_debug_copy_free_resamples(phd_filter* f);
 
 /* ------------------------------------------------------------------------------------
  * Device-resident variants (inputs already in HBM; used by bench.py and the multi-GPU host)

@@ -392,3 +392,63 @@ def test_sharded_filter_above_4096_particles_equals_one_filter(shards, exchange)
             assert np.array_equal(p, ref[k][1]) and np.array_equal(lw, ref[k][2]), k
             for a, b in zip(m.get_maps(), ref[k][3]):
                 assert np.array_equal(a, b), k
+
+
+def _copy_free_count(m):
+    return [pkg()._lib.lib().phd_debug_copy_free_resamples(m.shard_handle(k)) for k in range(m.n_shards)]
+
+
+@pytest.mark.parametrize("shards,exchange", [(1, "pull"), (2, "pull"), (4, "pull"), (2, "alltoall"), (4, "alltoall")])
+@pytest.mark.parametrize("filter_type", [0, 1])
+def test_copy_free_resample_of_a_shard_equals_one_filter(shards, exchange, filter_type, monkeypatch):
+    """A shard's global resample moves no local map (round 5): local parents stay by indirection, a remote parent is parked in
+    a guest slab by the first slot it fills and named by the others.  Heavy late weights make most slots of the early shards
+    remote; the CPHD variant's cardinality rows follow the same index.  Must equal a single filter bit for bit step after step
+    (every update reads through the indirection: local slabs, guests), take the copy-free form on every shard on every step
+    that resamples after an update, and equal the copying form (PHD_COPY_FREE=0), which a resample WITHOUT an update in
+    between falls back to (its indirection may still name guests)."""
+    P, S, MM = pkg(), synthetic(), mod()
+    N, steps = 96, 5
+    w = S.make_workload(N, 12, 8, seed=1200 + shards, n_meas_sets=steps)
+    w["logw"] = (w["logw"] + np.linspace(0, 6.0, N).astype(np.float32)).astype(np.float32)
+    kw = dict(n_particles=N, resampleThresh=0.5)
+    if filter_type:
+        kw.update(filterType=1, maxCardinality=63)
+    cfg = P.default_config(**kw)
+    ex = {"alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]
+
+    def run(copy_free):
+        monkeypatch.setenv("PHD_COPY_FREE", "1" if copy_free else "0")
+        out = []
+        with P.PhdFilter(cfg, n_particles=N, map_capacity=96, max_measurements=16) as f, \
+                MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=96, max_measurements=16, exchange=ex) as m:
+            for x in (f, m):
+                x.set_particles(w["poses"], w["logw"])
+                x.set_maps(w["maps"], w["sizes"])
+            n_free = 0
+            for s in range(steps):
+                f.predict((2.0, 0.05), w["noise"][s]); f.update(w["z"][s]); f.resample(w["uniform"][s])
+                m.step((2.0, 0.05), w["noise"][s], w["z"][s], w["uniform"][s], force_resample=True)
+                n_free += 1
+                if s == 2:
+                    # resampleParticles again, nothing in between: the shards' indirection still names guests
+                    f.resample(0.37)
+                    m.resample(0.37)
+                if s != 1:                                   # (one step goes on without the host looking at the maps)
+                    pa, la = f.get_particles()
+                    pb, lb = m.get_particles()
+                    assert np.array_equal(pa, pb) and np.array_equal(la, lb), (copy_free, s)
+                    ma, mb = f.get_maps(), m.get_maps()
+                    for x, y in zip(ma, mb):
+                        assert np.array_equal(x, y), (copy_free, s)
+                    out.append((pb, lb, mb))
+            assert _copy_free_count(m) == [n_free if copy_free else 0] * shards
+            m.state_snapshot()
+            assert m.last_report.status == 0
+        return out
+
+    a, b = run(True), run(False)
+    for (pa, la, ma), (pb, lb, mb) in zip(a, b):
+        assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+        for x, y in zip(ma, mb):
+            assert np.array_equal(x, y)
