@@ -733,6 +733,18 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
     # (the shards run on their own streams: the event-based percentiles of timed_loop do not see them; wall clock only)
     elapsed, _, _, preroll = timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms)
 
+    # the nEff-triggered step (what the SLAM loop runs: src/main.cpp:1281-1296): the decision is taken on the device and the host
+    # only enqueues (PHD_MULTI_HOST_NEFF=1: the round-4 form, nEff read back every step)
+    k_un = max(min(steps, 400), 1)
+    for _ in range(min(20, k_un)):
+        m.step_resident(control, u, force_resample=False)
+    sync()
+    tu = time.perf_counter()
+    for _ in range(k_un):
+        m.step_resident(control, u, force_resample=False)
+    sync()
+    unforced = k_un / (time.perf_counter() - tu)
+
     # per-shard kernel time (HIP events on shard 0's stream around its launches) and the per-phase breakdown (HIP events on
     # shard 0's stream at the phase boundaries, all shards drained after every step): separate passes
     k_ev = min(steps, 50)
@@ -779,6 +791,8 @@ def run_cpp_multi(P, S, torch, cfg_id, steps, warmup, devices, preroll_ms, with_
                       "rccl": m.uses_rccl, "rccl_ranks": n_shards if m.uses_rccl else 0,
                       "value_counts": "filter steps per second (K / wall time with every shard drained)",
                       "multi_gpu_exchange": m.exchange,
+                      "steps_per_s_unforced_resample": unforced,
+                      "unforced_decision": "host (nEff read back)" if os.environ.get("PHD_MULTI_HOST_NEFF") else "device (no host round trip)",
                       "multi_gpu_verified": verified,
                       "multi_gpu_phase_us_shard0": phases,
                       **({} if distinct else {"share_gpu_dry_run": True})},

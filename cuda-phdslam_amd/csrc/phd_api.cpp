@@ -1662,7 +1662,59 @@ extern "C" int phd_peer_view_get(phd_filter* f, phd_peer_view* out)
     return PHD_OK;
 }
 
+static int resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank, bool by_device_decision);
 extern "C" int phd_global_resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank)
+{
+    return resample_pull(f, views, world, rank, false);
+}
+
+// The nEff-triggered step of a shard with NO host round trip: phd_global_resample_launch_auto normalises the gathered raw
+// weights, takes nEff and the reference's decision (src/main.cpp:1286) ON THE DEVICE and leaves either the resampling indices
+// or the identity; phd_global_resample_pull_auto is enqueued whatever the decision was — on "no resample" every slot keeps its
+// own particle (nothing is copied: the copy-free form) and the normalised weights stay.  The host reads the decision from the
+// step report if and when it wants it.
+extern "C" int phd_global_resample_auto_supported(phd_filter* f, int world)
+{
+    return (f && copy_free_ok(f, world > 1)) ? 1 : 0;
+}
+
+extern "C" int phd_global_resample_launch_auto(phd_filter* f, const float* d_all_raw_logw, double uniform)
+{
+    CHECK_F(f);
+    if (!d_all_raw_logw) return fail(PHD_ERR_INVALID_ARG, "phd_global_resample_launch_auto: null weights");
+    if (f->n != f->n_base) return fail(PHD_ERR_UNSUPPORTED, "phd_global_resample_launch_auto: a grown particle set takes the staged calls");
+    WeightArgs w;
+    memset(&w, 0, sizeof(w));
+    w.u0 = uniform;
+    w.logw_in = d_all_raw_logw;
+    w.logw = f->logw_scratch;
+    w.n = ng_cur(f);
+    w.n_new = f->n_global;
+    w.mode = WM_NORMALIZE | WM_RESAMPLE_AUTO | WM_HAD_MEAS;
+    w.resample_thresh = f->cfg.resampleThresh;
+    w.uniforms = f->d_uniforms;
+    w.n_uniforms = 1;
+    w.cdf = f->cdf;
+    w.idx_out = f->idx;
+    w.neff_out = f->neff;
+    w.did_resample = f->did;
+    w.n_weight_norm = f->n_global;
+    t_begin(f, PHD_K_WEIGHTS);
+    HIPCHK(launch_weights_f(f, w));
+    t_end(f);
+    // (this shard's slice of the normalised vector is adopted by the pull that follows — or replaced by -log N)
+    return PHD_OK;
+}
+
+extern "C" int phd_global_resample_pull_auto(phd_filter* f, const phd_peer_view* views, int world, int rank)
+{
+    CHECK_F(f);
+    if (!copy_free_ok(f, world > 1))
+        return fail(PHD_ERR_UNSUPPORTED, "phd_global_resample_pull_auto: the copy-free form is not available (ask phd_global_resample_auto_supported first)");
+    return resample_pull(f, views, world, rank, true);
+}
+
+static int resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank, bool by_device_decision)
 {
     CHECK_F(f);
     if (world < 1 || world > PHD_MAX_PEERS || rank < 0 || rank >= world || f->n_global != f->n_base * world || f->global_offset != rank * f->n_base)
@@ -1677,7 +1729,8 @@ extern "C" int phd_global_resample_pull(phd_filter* f, const phd_peer_view* view
         HIPCHK(launch_resample_pull_free(views, world, f->idx, rank * n_dst, n_src, n_dst, rank, f->maps_g, f->counts_g,
                                          f->cphd ? f->cn_g : nullptr, guest_offset(f), f->pose[pnext], f->cap,
                                          f->frozen ? nullptr : f->logw, (float)(-log((double)f->n_global)),
-                                         f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1], f->cn_len, f->stream));
+                                         f->frozen ? f->parent[2] : f->parent[f->pcur ^ 1], f->cn_len, f->stream,
+                                         by_device_decision ? f->did : nullptr, by_device_decision ? f->logw_scratch + off_cur(f) : nullptr));
         f->copy_free_resamples++;
         if (f->frozen) return PHD_OK;
         f->n = n_dst;

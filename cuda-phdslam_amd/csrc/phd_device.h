@@ -147,7 +147,8 @@ hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int
 // slab counted from the filter's current buffer
 hipError_t launch_resample_pull_free(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank,
                                      float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
-                                     float nlw, int* parent_next, int cn_len, hipStream_t st);
+                                     float nlw, int* parent_next, int cn_len, hipStream_t st, const int* did = nullptr,
+                                     const float* logw_keep = nullptr);
 hipError_t launch_resample_end_free(const int* parent, const phd_pose* pose_src, const int* plan, int n, const void* recv, size_t stride,
                                     float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
                                     float nlw, int* parent_next, int cn_len, hipStream_t st);

@@ -1013,7 +1013,7 @@ __global__ void phd_resample_pull_kernel(PeerViews V, const int* __restrict__ id
 // single filter); the FIRST slot of a remote parent copies it into guest slab j — the only map traffic, and the only reads that
 // cross the link — and the other slots that parent fills name the same guest.  The next update reads through the indirection
 // and writes the other buffer; nothing is flipped here.  Counts and CPHD cardinality rows are laid out the same way.
-// One workgroup of 64 threads per slot (most write two words and leave).  The callers use these forms only while the shard's
+// One wave per slot, four to a workgroup (most write two words and leave).  The callers use these forms only while the shard's
 // indirection is the identity (no resample since the last update): a guest slab named by an older indirection must not be
 // overwritten — the copying forms above take that case.
 // ------------------------------------------------------------------------------------------
@@ -1026,9 +1026,15 @@ __device__ __forceinline__ void copy_slab_wave(const float* __restrict__ a, int 
 __global__ void phd_resample_pull_free_kernel(PeerViews V, const int* __restrict__ idx, int off, int n, int rank,
                                               float* __restrict__ guests, int* __restrict__ counts_g, float* __restrict__ cn_g,
                                               int goff, phd_pose* __restrict__ pose_dst, int cap, float* __restrict__ logw_fill,
-                                              float nlw, int* __restrict__ parent_next, int cn_len)
+                                              float nlw, int* __restrict__ parent_next, int cn_len, const int* __restrict__ did,
+                                              const float* __restrict__ logw_keep, int n_slots)
 {
-    const int j = blockIdx.x, tid = threadIdx.x;
+    // did (optional): the resample decision the weights launch left on the device (nEff trigger).  0: that launch wrote the
+    // identity into idx, every slot "takes" its own particle below and its weight becomes this shard's slice of the normalised
+    // vector (logw_keep) instead of -log N — the host, which enqueues this launch whatever the decision was, need not know it
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), tid = threadIdx.x & 63;   // one WAVE per slot
+    if (j >= n_slots) return;
+    if (did && !did[0]) nlw = logw_keep[j];
     const int g = idx[off + j];
     const int owner = g / n, lp = g - owner * n;
     const phd_peer_view& P = V.v[owner];
@@ -1049,9 +1055,9 @@ __global__ void phd_resample_pull_free_kernel(PeerViews V, const int* __restrict
         return;
     }
     const int cnt = P.counts[s];
-    copy_slab_wave(P.maps + (size_t)s * 6 * cap, cnt, cap, guests + (size_t)j * 6 * cap, tid, (int)blockDim.x);
+    copy_slab_wave(P.maps + (size_t)s * 6 * cap, cnt, cap, guests + (size_t)j * 6 * cap, tid, 64);
     if (cn_g)
-        for (int i = tid; i < cn_len; i += blockDim.x) cn_g[(size_t)j * cn_len + i] = P.cn[(size_t)s * cn_len + i];
+        for (int i = tid; i < cn_len; i += 64) cn_g[(size_t)j * cn_len + i] = P.cn[(size_t)s * cn_len + i];
     if (tid == 6) counts_g[j] = cnt;
     if (tid == 7) { if (parent_next) parent_next[j] = goff + j; if (logw_fill) logw_fill[j] = nlw; }
 }
@@ -1063,7 +1069,8 @@ __global__ void phd_resample_end_free_kernel(const int* __restrict__ parent, con
                                              phd_pose* __restrict__ pose_dst, int cap, float* __restrict__ logw_fill, float nlw,
                                              int* __restrict__ parent_next, int cn_len)
 {
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), tid = threadIdx.x & 63;   // one WAVE per slot
+    if (j >= n) return;
     const int lp = plan[j];
     if (lp >= 0) {
         if (tid < 6) ((float*)&pose_dst[j])[tid] = ((const float*)&pose_src[lp])[tid];
@@ -1076,9 +1083,9 @@ __global__ void phd_resample_end_free_kernel(const int* __restrict__ parent, con
     if (tid == 7) { if (parent_next) parent_next[j] = goff + f0; if (logw_fill) logw_fill[j] = nlw; }
     if (f0 != j) return;
     const int cnt = ((const int*)o)[6];
-    copy_slab_wave(o + 8, cnt, cap, guests + (size_t)j * 6 * cap, tid, (int)blockDim.x);
+    copy_slab_wave(o + 8, cnt, cap, guests + (size_t)j * 6 * cap, tid, 64);
     if (cn_g)
-        for (int i = tid; i < cn_len; i += blockDim.x) cn_g[(size_t)j * cn_len + i] = o[8 + 6 * cap + i];
+        for (int i = tid; i < cn_len; i += 64) cn_g[(size_t)j * cn_len + i] = o[8 + 6 * cap + i];
     if (tid == 6) counts_g[j] = cnt;
 }
 
@@ -1457,14 +1464,14 @@ hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int
 
 hipError_t launch_resample_pull_free(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank,
                                      float* guests, int* counts_g, float* cn_g, int goff, phd_pose* pose_dst, int cap, float* logw_fill,
-                                     float nlw, int* parent_next, int cn_len, hipStream_t st)
+                                     float nlw, int* parent_next, int cn_len, hipStream_t st, const int* did, const float* logw_keep)
 {
     if (n_dst <= 0) return hipSuccess;
     if (world > PHD_MAX_PEERS) return hipErrorInvalidValue;
     PeerViews V = {};
     for (int k = 0; k < world; ++k) V.v[k] = views[k];
-    hipLaunchKernelGGL(phd_resample_pull_free_kernel, dim3(n_dst), dim3(64), 0, st, V, idx, off, n_src, rank, guests, counts_g, cn_g, goff,
-                       pose_dst, cap, logw_fill, nlw, parent_next, cn_len);
+    hipLaunchKernelGGL(phd_resample_pull_free_kernel, dim3((n_dst + 3) / 4), dim3(256), 0, st, V, idx, off, n_src, rank, guests, counts_g, cn_g,
+                       goff, pose_dst, cap, logw_fill, nlw, parent_next, cn_len, did, logw_keep, n_dst);
     return hipGetLastError();
 }
 
@@ -1473,7 +1480,7 @@ hipError_t launch_resample_end_free(const int* parent, const phd_pose* pose_src,
                                     float nlw, int* parent_next, int cn_len, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(phd_resample_end_free_kernel, dim3(n), dim3(64), 0, st, parent, pose_src, plan, n, (const unsigned char*)recv, stride,
+    hipLaunchKernelGGL(phd_resample_end_free_kernel, dim3((n + 3) / 4), dim3(256), 0, st, parent, pose_src, plan, n, (const unsigned char*)recv, stride,
                        guests, counts_g, cn_g, goff, pose_dst, cap, logw_fill, nlw, parent_next, cn_len);
     return hipGetLastError();
 }

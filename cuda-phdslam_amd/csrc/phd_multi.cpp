@@ -709,6 +709,30 @@ static int step_resident_body(phd_multi* m, phd_ackerman_control u, double unifo
     // local step, then the raw weights of all shards on every shard
     PHDCHK(update_stage(m, &u));
     bool resample = force_resample != 0;
+    if (!resample && m->pull && !m->gathered && m->kpred == 1 && !getenv("PHD_MULTI_HOST_NEFF")) {
+        // The nEff trigger with no host round trip: every shard normalises, takes nEff and the decision on the device and
+        // leaves the indices or the identity; the pull is enqueued either way (nothing moves when nothing was resampled: the
+        // copy-free form).  The decision is downloaded only for a caller that asks for it — after everything is enqueued.
+        bool ok = true;
+        for (int k = 0; k < W; ++k) ok = ok && phd_global_resample_auto_supported(m->sh[k].f, W) == 1;
+        if (ok) {
+            for (int k = 0; k < W; ++k) PHDCHK(phd_global_resample_launch_auto(m->sh[k].f, m->sh[k].allw, uniform));
+            PHDCHK(t_mark(m, PHD_MULTI_PHASE_WEIGHTS));
+            std::vector<phd_peer_view> views((size_t)W);
+            for (int k = 0; k < W; ++k) PHDCHK(phd_peer_view_get(m->sh[k].f, &views[k]));
+            for (int k = 0; k < W; ++k) PHDCHK(phd_global_resample_pull_auto(m->sh[k].f, views.data(), W, k));
+            PHDCHK(peer_consumed(m));
+            PHDCHK(t_mark(m, PHD_MULTI_PHASE_IMPORT));
+            m->scratch_current = false;                 // (the host does not know whether the weights were reset)
+            if (did_resample_out) {
+                phd_step_report r;
+                memset(&r, 0, sizeof(r));
+                (void)phd_step_report_get(m->sh[0].f, &r);      // (a status bit is the caller's to find, as on the other paths)
+                *did_resample_out = r.did_resample;
+            }
+            return PHD_OK;
+        }
+    }
     if (!resample) {
         // the reference's trigger: global normalisation (adopted by every shard), nEff read back from shard 0 only
         float neff = 0.f;

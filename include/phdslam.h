@@ -358,6 +358,21 @@ typedef struct {
 } phd_peer_view;
 int phd_peer_view_get(phd_filter* f, phd_peer_view* out);
 int phd_global_resample_pull(phd_filter* f, const phd_peer_view* views, int world, int rank);
+/* Round 5: both forms of the global resample (pull, and _plan/_end) move no LOCAL map while the shard's indirection is the
+ * identity (no resample since its last update): a local parent stays where it is — the slot's indirection names its slab, as
+ * in a single filter — and a remote parent is copied once, by the first slot it fills, into that slot's GUEST slab (the map
+ * buffers of a shard are one allocation [buffer 0 | buffer 1 | guests]; the indirection counts slabs from the current
+ * buffer).  PHD_COPY_FREE=0 in the environment at phd_create keeps the copying forms.
+ *
+ * The nEff-triggered step with no host round trip (the reference reads nEff back, src/main.cpp:1281-1296):
+ * phd_global_resample_launch_auto normalises the gathered un-normalised weights, takes nEff and the decision ON THE DEVICE
+ * and leaves the resampling indices or the identity; phd_global_resample_pull_auto — enqueued whatever the decision was, and
+ * always after the former — completes the step either way (no resample: every slot keeps its particle and adopts its slice of
+ * the normalised weights).  nEff and the decision are in the step report (phd_step_report_get) for a host that wants them.  Available while
+ * phd_global_resample_auto_supported says 1 (the copy-free form applies); otherwise phd_global_normalize + the host's decision. */
+int phd_global_resample_auto_supported(phd_filter* f, int world);
+int phd_global_resample_launch_auto(phd_filter* f, const float* d_all_raw_logw, double uniform);
+int phd_global_resample_pull_auto(phd_filter* f, const phd_peer_view* views, int world, int rank);
 
 /* ------------------------------------------------------------------------------------
  * Bench / steady-state protocol and instrumentation
