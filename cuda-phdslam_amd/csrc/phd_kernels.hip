@@ -293,15 +293,34 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     float wall_local = 0.f; // CPHD: <1, map>
     int n_in = 0, n_out0 = 0; // every thread accumulates the same totals: no broadcast (and no extra barrier) afterwards
     {
+        // (the slab is requested for every slot below its CAPACITY, not below the map's count: the count is itself a load that
+        //  depends on the indirection — parent[p] -> count[src] -> slab — and a lone workgroup per CU pays every link of that
+        //  chain; the slab's address needs only `src`, so its loads now travel beside the count's.  At most cap - n_map unused
+        //  words per plane, inside the slab)
+        //  Built into the 80-register CPHD translation unit only (csrc/Makefile: -DPHD_SLAB_AHEAD): same-visit A/B at 4096 x 256 x 64,
+        //  CPHD 2 640 -> 2 707 steps/s, the 80-register PHD kernel 4 263 -> 4 209 (its register allocation moves), 256 x 64 x 32 +0.3 %.
+#ifdef PHD_SLAB_AHEAD
+        int i0 = 0;
+        do {
+#else
         for (int i0 = 0; i0 < n_map; i0 += PHD_T) {
+#endif
             const int i = i0 + tid;
             int cls = -1, nd_j = 0;
             float w = 0, mx = 0, my = 0, pxx = 0, pxy = 0, pyy = 0;
             EkfTerms t;
             t.pd = 0.f;
+#ifdef PHD_SLAB_AHEAD
+            if (i < cap) {
+                w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
+                pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
+            }
+            if (i < n_map) {
+#else
             if (i < n_map) {
                 w = in[0 * cap + i]; mx = in[1 * cap + i]; my = in[2 * cap + i];
                 pxx = in[3 * cap + i]; pxy = in[4 * cap + i]; pyy = in[5 * cap + i];
+#endif
                 ekf_terms(mx, my, pxx, pxy, pyy, pose, cfg, t);
                 wall_local += w;
                 // computeInRangeKernel, src/phdfilter.cu:1333-1346 (0.8/1.2 are double literals)
@@ -350,7 +369,11 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
             }
             n_in += tot_in; n_out0 += tot_out;
             __syncthreads();
+#ifdef PHD_SLAB_AHEAD
+        } while ((i0 += PHD_T) < n_map);
+#else
         }
+#endif
     }
     STAMP(1);
 
