@@ -17,7 +17,7 @@ def mod():
     return importlib.import_module("cuda-phdslam_amd.multi")
 
 
-def run_single(cfg, w, steps, cap, M, device_rng, force_pattern):
+def run_single(cfg, w, steps, cap, M, device_rng, force_pattern, extra=None):
     P = pkg()
     out = []
     with P.PhdFilter(cfg, n_particles=w["N"], map_capacity=cap, max_measurements=M) as f:
@@ -32,6 +32,8 @@ def run_single(cfg, w, steps, cap, M, device_rng, force_pattern):
                 did = True
             else:
                 did, _ = f.resample_if_needed(w["uniform"][k], had_measurements=True)
+            if extra is not None and extra[k]:
+                f.resample(0.5 * float(w["uniform"][k]))            # resampleParticles again, no update in between
             p, lw = f.get_particles()
             out.append((did, p, lw, f.get_maps()))
         f.status()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised sweep of the C++ multi-device host (libphdslam_multi.so) against a single filter, bit for bit: random shard
 counts (1 = a one-rank RCCL communicator, more = shards sharing this GPU through device copies), both exchange forms, host noise
-or the device generator, forced / nEff-triggered resampling, PHD and CPHD, degenerate and flat weight vectors.
+or the device generator, forced / nEff-triggered resampling, a second resample without an update on some steps, steps the host
+does not inspect, PHD and CPHD, degenerate and flat weight vectors.
 
     python tools/fuzz_multi.py [seconds=120] [first_seed=1000]
 """
@@ -43,9 +44,14 @@ def main():
         w = S.make_workload(N, G, M, seed=seed, n_meas_sets=steps)
         w["logw"] = (w["logw"] + rng.choice([0.0, 3.0, 12.0]) * np.linspace(0, 1.0, N).astype(np.float32)).astype(np.float32)
         force = [bool(x) for x in rng.integers(0, 2, steps)]
+        # a second resample with no update in between on some steps (the shards' copy-free resample falls back to the copying one
+        # there: its indirection still names guest slabs), and steps after which the host does not look at the maps
+        extra = [bool(x) for x in (rng.random(steps) < 0.25)]
+        look = [bool(x) for x in (rng.random(steps) < 0.7)]
+        look[-1] = True
         cap, mm = 2 * G + 4 * M + 32, 16
         try:
-            ref = run_single(cfg, w, steps, cap, mm, device_rng, force)
+            ref = run_single(cfg, w, steps, cap, mm, device_rng, force, extra)
             with MM.MultiFilter(cfg, n_shards=shards, devices=[0] * shards, map_capacity=cap, max_measurements=mm,
                                 exchange={"gathered": MM.EXCHANGE_GATHERED, "alltoall": MM.EXCHANGE_ALLTOALL, "pull": MM.EXCHANGE_PULL}[exchange]) as m:
                 m.seed(77)
@@ -54,9 +60,13 @@ def main():
                 for k in range(steps):
                     did = m.step((2.0, 0.05 - 0.01 * k), None if device_rng else w["noise"][k], w["z"][k], w["uniform"][k],
                                  force_resample=force[k])
+                    if extra[k]:
+                        m.resample(0.5 * float(w["uniform"][k]))
+                    if not look[k]:
+                        continue
                     p, lw = m.get_particles()
                     rdid, rp, rlw, rmaps = ref[k]
-                    assert did == rdid, "resample decision, step %d" % k
+                    assert did == rdid, "resample decision, step %d" % k   # (of the step itself; the extra resample is unconditional)
                     assert np.array_equal(p, rp) and np.array_equal(lw.view(np.uint32), rlw.view(np.uint32)), "particles, step %d" % k
                     for j, (a, b) in enumerate(zip(m.get_maps(), rmaps)):
                         assert a.tobytes() == b.tobytes(), "map of particle %d, step %d" % (j, k)
