@@ -140,6 +140,7 @@ SYMBOLS = {
     "phd_global_resample_gathered": (_i, [_vp, _vp, _d, _i, _i, _i, _vp]),
     "phd_peer_view_get": (_i, [_vp, _vp]),
     "phd_global_resample_pull": (_i, [_vp, _vp, _i, _i]),
+    "phd_set_raw_target": (_i, [_vp, _vp]),
     "phd_global_resample_auto_supported": (_i, [_vp, _i]),
     "phd_global_resample_launch_auto": (_i, [_vp, _vp, _d]),
     "phd_global_resample_pull_auto": (_i, [_vp, _vp, _i, _i]),

@@ -102,7 +102,8 @@ struct phd_filter {
     int pose_cur = 0;
     float* logw = nullptr;
     float* logw_scratch = nullptr;
-    float* logw_raw = nullptr;
+    float* logw_raw = nullptr;      // where a local step leaves the un-normalised weights: logw_raw_own, or the caller's buffer (phd_set_raw_target)
+    float* logw_raw_own = nullptr;
     float* dlogw = nullptr;
     phd_measurement* d_z = nullptr;
     phd_ackerman_noise* d_noise = nullptr;
@@ -309,7 +310,8 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     }
     for (int k = 0; k < 3; ++k) { A(dalloc(&f->parent[k], f->n_max)); A(dalloc(&f->pose[k], f->n_max)); }
     A(dalloc(&f->logw, f->n_max)); A(dalloc(&f->logw_alt, f->n_max)); A(dalloc(&f->logw_scratch, gmax));
-    A(dalloc(&f->logw_raw, f->n_max)); A(dalloc(&f->dlogw, f->n_max));
+    A(dalloc(&f->logw_raw_own, f->n_max)); A(dalloc(&f->dlogw, f->n_max));
+    f->logw_raw = f->logw_raw_own;
     A(dalloc(&f->d_z, f->MM)); A(dalloc(&f->d_noise, f->n_max));
     A(dalloc(&f->d_uniforms, gmax));
     A(dalloc(&f->cdf, gmax));
@@ -380,7 +382,7 @@ extern "C" int phd_destroy(phd_filter* f)
     for (auto& ev : f->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     hipFree(f->maps_arena); hipFree(f->counts_arena); hipFree(f->cn_arena);
     for (int k = 0; k < 3; ++k) { hipFree(f->parent[k]); hipFree(f->pose[k]); }
-    hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw); hipFree(f->dlogw);
+    hipFree(f->logw); hipFree(f->logw_alt); hipFree(f->logw_scratch); hipFree(f->logw_raw_own); hipFree(f->dlogw);
     hipFree(f->d_z); hipFree(f->d_noise); hipFree(f->d_uniforms); hipFree(f->cdf); hipFree(f->idx);
     hipFree(f->report); hipFree(f->state_pose); hipFree(f->state_argmax);
     hipFree(f->d_tmp_int); hipFree(f->ticket); hipFree(f->gw_sync); hipFree(f->gw_part); hipFree(f->d_plan);
@@ -1275,6 +1277,15 @@ extern "C" int phd_cardinality_estimate(phd_filter* f, float* out, int32_t* part
 }
 
 extern "C" int phd_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw; return PHD_OK; }
+// The un-normalised weights of a shard's local step written straight into the caller's buffer (n_max floats; NULL: the filter's own
+// again): with the shard's segment of the all-gather's receive buffer as the target the collective is IN PLACE — on one rank it
+// disappears, on N ranks a 1/N-th of its bytes and the self copy do.
+extern "C" int phd_set_raw_target(phd_filter* f, float* d_raw)
+{
+    CHECK_F(f);
+    f->logw_raw = d_raw ? d_raw : f->logw_raw_own;
+    return PHD_OK;
+}
 extern "C" int phd_raw_logweights_dev(phd_filter* f, float** d) { CHECK_F(f); if (!d) return fail(PHD_ERR_INVALID_ARG, "null"); *d = f->logw_raw; return PHD_OK; }
 
 extern "C" int phd_set_frozen(phd_filter* f, int freeze)

@@ -447,6 +447,10 @@ extern "C" int phd_multi_create(const phd_slam_config* cfg, const phd_multi_opti
             if (e == hipSuccess) e = hipMalloc((void**)&s.d_noise, (size_t)m->n_max * sizeof(phd_ackerman_noise));
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+            // the local step writes its raw weights straight into this shard's segment of its own receive buffer: the all-gather of
+            // the raw weights is in place (no self copy; on one rank nothing is left of it).  Not with the particle shotgun, whose
+            // segments move with the particle count.
+            if (e == hipSuccess && m->kpred == 1 && phd_set_raw_target(s.f, s.allw + (size_t)(&s - &m->sh[0]) * m->n) != PHD_OK) e = hipErrorUnknown;
             if (e != hipSuccess) { rc = fail(PHD_ERR_HIP, std::string("phd_multi_create: ") + hipGetErrorString(e)); break; }
         }
     }

@@ -370,6 +370,10 @@ int phd_global_resample_pull(phd_filter* f, const phd_peer_view* views, int worl
  * always after the former — completes the step either way (no resample: every slot keeps its particle and adopts its slice of
  * the normalised weights).  nEff and the decision are in the step report (phd_step_report_get) for a host that wants them.  Available while
  * phd_global_resample_auto_supported says 1 (the copy-free form applies); otherwise phd_global_normalize + the host's decision. */
+/* the buffer phd_step_local_dev / phd_update_local_dev leave the un-normalised log-weights in (phd_raw_logweights_dev returns it): the
+ * caller's (n_max floats) instead of the filter's own — e.g. this shard's segment of the all-gather's receive buffer, which makes the
+ * collective in place.  NULL: the filter's own again. */
+int phd_set_raw_target(phd_filter* f, float* d_raw);
 int phd_global_resample_auto_supported(phd_filter* f, int world);
 int phd_global_resample_launch_auto(phd_filter* f, const float* d_all_raw_logw, double uniform);
 int phd_global_resample_pull_auto(phd_filter* f, const phd_peer_view* views, int world, int rank);
