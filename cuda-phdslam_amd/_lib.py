@@ -111,6 +111,7 @@ SYMBOLS = {
     "phd_gm_reduce_dev": (_i, [_vp, _vp, C.c_int64, _i, _f, _vp, _i, _vp]),
     "phd_debug_gm_rounds": (_i, [_vp]),
     "phd_debug_copy_free_resamples": (_i, [_vp]),
+    "phd_debug_update_instantiation": (_i, [_vp]),
     "phd_predict_ackerman_dev": (_i, [_vp, Control, _vp]),
     "phd_update_dev": (_i, [_vp, _vp, _i]),
     "phd_logweights_dev": (_i, [_vp, C.POINTER(_vp)]),

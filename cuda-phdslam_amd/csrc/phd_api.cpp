@@ -79,6 +79,8 @@ struct phd_filter {
     bool own_stream = false;
     size_t lds_bytes = 0;
     bool three_per_cu = false;     // the build of the update kernel this filter runs (80 registers, three workgroups per CU): decided at create
+    int last_update_fn = -1;       // the instantiation the last update launch ran (phd_debug_update_instantiation)
+    bool any_layout = false;       // PHD_LAYOUT=0 at create: never the instantiations with this filter's LDS layout compiled in (A/B, tests)
 
     // the map buffers are ONE allocation — [buffer 0 | buffer 1 | guests], n_max slabs each; the guests only on a shard — so
     // that the indirection, which counts slabs from the start of the CURRENT buffer, can name a slab of either buffer or a
@@ -281,6 +283,7 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     }
     // the build this filter runs, for its whole life (PHD_UPDATE_BUILD=2 / 3 overrides: the tests compare the two builds bit for bit)
     f->three_per_cu = update_takes_three_per_cu(f->cphd, f->spill_cap != 0, f->lds_bytes, f->n_base);
+    if (const char* e = getenv("PHD_LAYOUT")) f->any_layout = e[0] == '0';
     if (const char* e = getenv("PHD_UPDATE_BUILD")) {
         if (e[0] == '2') f->three_per_cu = false;
         else if (e[0] == '3' && !f->spill_cap && 3 * (f->lds_bytes + 1024) <= 160 * 1024) f->three_per_cu = true;
@@ -842,7 +845,8 @@ static int do_update_merge(phd_filter* f, const phd_measurement* d_z, int M, con
 #endif
     }
     t_begin(f, PHD_K_UPDATE_MERGE);
-    HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream, f->three_per_cu));
+    HIPCHK(launch_update_merge(a, f->n, f->lds_bytes, f->stream, f->three_per_cu, f->any_layout));
+    f->last_update_fn = update_instantiation(a, f->n, f->three_per_cu, f->any_layout);
     HIPCHK(launch_merge_spill(a, f->n, f->stream));   // (a no-op without a spill list) particles whose survivors outgrew LDS
     t_end(f);
     f->last_M = M;
@@ -938,7 +942,7 @@ extern "C" int phd_update_residency(phd_filter* f, int32_t* workgroups_per_cu_ou
     a.cphd = f->cphd ? 1 : 0;
     a.spill_rec = f->spill_rec;
     a.fuse_weights = can_fuse(f) ? 1 : 0;
-    if (workgroups_per_cu_out) *workgroups_per_cu_out = update_workgroups_per_cu(a, f->lds_bytes, f->three_per_cu);
+    if (workgroups_per_cu_out) *workgroups_per_cu_out = update_workgroups_per_cu(a, f->lds_bytes, f->three_per_cu, f->any_layout);
     if (lds_bytes_out) *lds_bytes_out = f->lds_bytes;
     return PHD_OK;
 }
@@ -1227,6 +1231,7 @@ extern "C" int phd_expected_map(phd_filter* f, phd_gaussian2d* out, int capacity
 
 extern "C" int phd_debug_gm_rounds(phd_filter* f) { return f ? f->gm_rounds : 0; }
 extern "C" int phd_debug_copy_free_resamples(phd_filter* f) { return f ? f->copy_free_resamples : 0; }
+extern "C" int phd_debug_update_instantiation(phd_filter* f) { return f ? f->last_update_fn : -1; }
 
 // ---------------------------------------------------------------------------------------------
 // CPHD variant: the per-particle cardinality distributions (SynthSLAM::cardinalities, src/slamtypes.h:296)

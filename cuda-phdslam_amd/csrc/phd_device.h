@@ -137,8 +137,10 @@ size_t weights_grid_lds_bytes(int n);      // LDS it needs (block ends of the CD
 
 // three_per_cu: the filter's build, decided once at phd_create by update_takes_three_per_cu() (the 80-register instantiations)
 bool update_takes_three_per_cu(bool cphd, bool spill, size_t lds_bytes, int n_base);
-hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st, bool three_per_cu);
-int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_per_cu);   // what the runtime says a CU holds (-1: query failed)
+// any_layout: never the instantiations with a compiled-in LDS layout (phd_kernels.hip, LAYOUT), whatever the filter's layout is
+hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st, bool three_per_cu, bool any_layout = false);
+int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_per_cu, bool any_layout = false);
+int update_instantiation(const UpdateArgs& a, int n_particles, bool three_per_cu, bool any_layout);   // index into the launcher's table (diagnostics)   // what the runtime says a CU holds (-1: query failed)
 #define PHD_MAX_PEERS 16        // shards whose memory one pull kernel can read (phd_global_resample_pull)
 hipError_t launch_resample_pull(const phd_peer_view* views, int world, const int* idx, int off, int n_src, int n_dst, int rank, float* dst,
                                 int* counts_dst, phd_pose* pose_dst, int cap, float* logw_fill, float nlw, int* parent_next,

@@ -125,13 +125,28 @@ __device__ __forceinline__ void handoff_ticket(unsigned* ticket)
 // grid N + W; phd_weights.h) - an instantiation of its own, so that every other one keeps, textually, the code it had: the routine
 // inlined beside the single tail workgroup cost the 80-register CPHD build 3.3 % (27 more spilled scalars from a changed branch
 // condition alone) and raised the headline build's spills from 451 to 537 VGPRs.
-template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL, int MINW = PHD_MIN_WAVES, bool GRIDT = false>
+// LAYOUT: the filter's LDS layout (survivor capacity, map capacity, measurement capacity) as COMPILE-TIME constants (round 5): with
+// the layout known every LDS array is an immediate offset in its ds_* instruction instead of one of ~35 scalar registers — the
+// kernel keeps ~100 scalars alive and spills the excess into vector-register lanes (v_writelane / v_readlane: vector instructions)
+// — and an index shifted once serves all planes.  0 = from the arguments (any filter); 1 = BASELINE.json's 256-Gaussian
+// configurations (configs[2], [3], [4]: 1024 / 512 / 64), 2 = configs[1] (512 / 128 / 32).  Same library, same visit, PHD_LAYOUT=0
+// against the default: 4096 x 256 x 64 4 260 -> 4 270 steps/s, CPHD 2 714 -> 2 816 (+3.8 %), 16 384 x 256 x 64 1 232 -> 1 285
+// (+4.3 %), 256 x 64 x 32 61.7 k -> 62.9 k (+1.9 %).  (A third layout, for bench.py's dense-scan rider - 2048 / 768 / 256 with a
+// spill list - measured nothing, 150.0 against 150.2 steps/s, and was not kept.)  The launcher picks the instantiation by the
+// filter's layout; the LAYOUT = 0 instantiations keep, textually, the code they had.
+template <int LAYOUT> struct FixedLayout { static constexpr int S = 0, C = 0, MM = 0; };
+template <> struct FixedLayout<1> { static constexpr int S = 1024, C = 512, MM = 64; };
+template <> struct FixedLayout<2> { static constexpr int S = 512, C = 128, MM = 32; };
+#define PHD_A_SCAP (LAYOUT ? FixedLayout<LAYOUT>::S : A.S_cap)
+#define PHD_A_CAP (LAYOUT ? FixedLayout<LAYOUT>::C : A.cap)
+#define PHD_A_MM (LAYOUT ? FixedLayout<LAYOUT>::MM : A.MM)
+template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL, int MINW = PHD_MIN_WAVES, bool GRIDT = false, int LAYOUT = 0>
 __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    Lds L = lds_carve((lds_u8)lds_raw, A.S_cap, A.cap, A.MM);
+    Lds L = lds_carve((lds_u8)lds_raw, PHD_A_SCAP, PHD_A_CAP, PHD_A_MM);
     // CPHD instantiation: its arrays follow the common layout
-    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(A.S_cap, A.cap, A.MM).total, (lds_u8)lds_raw, A.S_cap, A.cn_len, A.MM) : CphdLds();
+    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(PHD_A_SCAP, PHD_A_CAP, PHD_A_MM).total, (lds_u8)lds_raw, PHD_A_SCAP, A.cn_len, PHD_A_MM) : CphdLds();
     if (CPHD) L.zpart = Q.zscr;   // the block parks rows of cn_len doubles where pass 1 leaves its partial sums: a scratch of its own
 
     const int tid = threadIdx.x;
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     }
     const int p = blockIdx.x;
     const DevConfig& cfg = A.cfg;
-    const int cap = A.cap, S_cap = A.S_cap, M = A.M;
+    const int cap = PHD_A_CAP, S_cap = PHD_A_SCAP, M = A.M;
     const int src = A.parent[p];
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
     const unsigned rows_stride = FUSEW ? 0u : A.out_stride; // rows mode belongs to the multi-GPU step (never the fused tail)
@@ -400,12 +415,12 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
                            : safe_log(cfg.minFeatureWeight) + safe_log(cfg.clutterDensity + cfg.birthWeight) - 1e-3f;
     // ---- pass 1: normalisers (phd_pass1.h) -----------------------------------------------------------
     const Pass1Grid p1g = pass1_grid(M);
-    pass1_normalisers(L, n_in, M, A.MM, tid, sparse2, c0m);
+    pass1_normalisers(L, n_in, M, PHD_A_MM, tid, sparse2, c0m);
 #ifdef PHD_DUP_PASS1   // (tools/ab_bench.sh: the sweep run twice - its marginal cost; the candidate list restarted, the sums rewritten)
     __syncthreads();
     if (tid == 0) L.ctr[CTR_NCAND] = 0;
     __syncthreads();
-    pass1_normalisers(L, n_in, M, A.MM, tid, sparse2, c0m);
+    pass1_normalisers(L, n_in, M, PHD_A_MM, tid, sparse2, c0m);
 #endif
     if (STAMPS && tid == 0) st[23] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
@@ -419,8 +434,8 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         const float pdw = block_sum(pdw_local, L.red, tid);
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
-        cphd_block(L, Q, cfg, M, A.MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
-                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * A.MM * A.MM, w_all, pdw, tid,
+        cphd_block(L, Q, cfg, M, PHD_A_MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
+                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * PHD_A_MM * PHD_A_MM, w_all, pdw, tid,
                    STAMPS ? cq : nullptr, S_cap, STAMPS ? st : nullptr);
         const float r1 = Q.scal[CQ_R1];
         // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
@@ -713,6 +728,9 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 }
 
 // ------------------------------------------------------------------------------------------
+#undef PHD_A_SCAP
+#undef PHD_A_CAP
+#undef PHD_A_MM
 // Four translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
 // three-workgroups-per-CU ones (PHD, CPHD) are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU — the
 // kernel template above, one of these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
@@ -720,16 +738,23 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 // ------------------------------------------------------------------------------------------
 #if defined(PHD_CPHD_W6_TU)
 // <STAMPS, FUSEW, CPHD, -, 6>: the same three for the CPHD filter
-extern const void* const k_update_cphd_w6_fns[3] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
+// [3], [4]: the staged and the fused step with the layout of BASELINE.json's 256-Gaussian configurations compiled in (LAYOUT = 1)
+extern const void* const k_update_cphd_w6_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<true, false, true, false, 6>,
-                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6>};
+                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6>,
+                                                    (const void*)phd_update_merge_kernel<false, false, true, false, 6, false, 1>,
+                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6, false, 1>};
 #elif defined(PHD_W6_TU)
 // <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
 // + the fused step with the block-form tail (more than 4096 particles)
-extern const void* const k_update_w6_fns[4] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
+// [4], [5], [6]: the staged step, the fused step and the fused step with the block-form tail with LAYOUT = 1 compiled in
+extern const void* const k_update_w6_fns[7] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6>,
-                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>};
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>,
+                                               (const void*)phd_update_merge_kernel<false, false, false, false, 6, false, 1>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 1>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 1>};
 #elif defined(PHD_CPHD_TU)
 // <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
 extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
@@ -739,8 +764,8 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
                                                  (const void*)phd_update_merge_kernel<false, true, true, true>};
 #else
 extern const void* const k_update_cphd_fns[5];
-extern const void* const k_update_w6_fns[4];
-extern const void* const k_update_cphd_w6_fns[3];
+extern const void* const k_update_w6_fns[7];
+extern const void* const k_update_cphd_w6_fns[5];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
@@ -1162,7 +1187,8 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-static const void* const k_update_fns[18] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
+#define PHD_N_UPDATE_FNS_DECL 25
+static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
                                              k_update_cphd_fns[0], k_update_cphd_fns[1], k_update_cphd_fns[2],
@@ -1173,8 +1199,14 @@ static const void* const k_update_fns[18] = {(const void*)phd_update_merge_kerne
                                              k_update_cphd_w6_fns[0], k_update_cphd_w6_fns[1], k_update_cphd_w6_fns[2],
                                              k_update_w6_fns[3],
                                              // [17] the same block-form tail on the two-per-CU build (a layout that admits two workgroups per CU)
-                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, true>};
-#define PHD_N_UPDATE_FNS 18
+                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, true>,
+                                             // [18..24] compiled-in layouts (the kernel template's LAYOUT): of [10], [12], [16] (three per CU, PHD), of [13],
+                                             // [15] (three per CU, CPHD) with LAYOUT = 1, of [0], [2] (two per CU, PHD) with LAYOUT = 2
+                                             k_update_w6_fns[4], k_update_w6_fns[5], k_update_w6_fns[6],
+                                             k_update_cphd_w6_fns[3], k_update_cphd_w6_fns[4],
+                                             (const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
+                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>};
+#define PHD_N_UPDATE_FNS 25
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1256,7 +1288,7 @@ bool update_takes_three_per_cu(bool cphd, bool spill, size_t lds_bytes, int n_ba
     return three_granted(cphd ? 13 : 10, lds_bytes);
 }
 
-static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0)
+static int update_fn_index_any_layout(const UpdateArgs& a, bool three, int n_particles)
 {
     const bool sp = a.spill_rec != nullptr && !a.stamps;           // (the diagnostic instantiation has no spill variant)
     const bool fused = a.fuse_weights && !a.stamps;
@@ -1265,8 +1297,27 @@ static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0)
     if (three && !sp) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }
+// ... and, where the filter's layout is one of the compiled-in ones, the instantiation that has it as constants (any_layout: never
+// — a filter created with PHD_LAYOUT=0 in the environment: A/B, and the test that compares the two bit for bit)
+static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0, bool any_layout = false)
+{
+    const int fn = update_fn_index_any_layout(a, three, n_particles);
+    if (any_layout) return fn;
+    if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM) {
+        switch (fn) { case 10: return 18; case 12: return 19; case 16: return 20; case 13: return 21; case 15: return 22; default: break; }
+    }
+    if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM) {
+        switch (fn) { case 0: return 23; case 2: return 24; default: break; }
+    }
+    return fn;
+}
 
-hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st, bool three_per_cu)
+int update_instantiation(const UpdateArgs& a, int n_particles, bool three_per_cu, bool any_layout)
+{
+    return update_fn_index(a, three_per_cu, n_particles, any_layout);
+}
+
+hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_bytes, hipStream_t st, bool three_per_cu, bool any_layout)
 {
     // function attributes are per device: set once for every device this process launches on (thread-safe: filters on
     // different devices may be driven by different host threads)
@@ -1285,7 +1336,7 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
         if (e != hipSuccess) return e;
     }
     const bool fused = a.fuse_weights && !a.stamps;
-    const int fn = update_fn_index(a, three_per_cu, n_particles);
+    const int fn = update_fn_index(a, three_per_cu, n_particles, any_layout);
     // + the weights workgroup(s) of the fused step: one up to 4096 particles, the block form's above
     const dim3 grid(n_particles + (fused ? (n_particles > PHD_GRID_WEIGHTS_MIN ? grid_weights_workgroups(n_particles) : 1) : 0)), b(PHD_T);
     UpdateArgs args = a;
@@ -1294,10 +1345,10 @@ hipError_t launch_update_merge(const UpdateArgs& a, int n_particles, size_t lds_
 }
 
 // workgroups of the update kernel a CU holds at a time for this filter (the runtime's own count: LDS, registers, waves)
-int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_per_cu)
+int update_workgroups_per_cu(const UpdateArgs& a, size_t lds_bytes, bool three_per_cu, bool any_layout)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_update_fns[update_fn_index(a, three_per_cu)], PHD_T, lds_bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_update_fns[update_fn_index(a, three_per_cu, 0, any_layout)], PHD_T, lds_bytes) != hipSuccess) return -1;
     return n;
 }
 

@@ -272,6 +272,50 @@ def test_two_and_three_per_cu_builds_agree_at_the_headline_layout(ft, monkeypatc
         assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), ft
 
 
+@pytest.mark.parametrize("ft,layout,N", [(0, 1, 768), (1, 1, 768), (0, 2, 300), (0, 1, 4500)])
+def test_compiled_in_layouts_agree_with_the_general_instantiations(ft, layout, N, monkeypatch):
+    """Round 5: filters with the LDS layout of BASELINE.json's configurations run instantiations of the update kernel that have
+    the layout as compile-time constants (every LDS array an immediate offset; phd_kernels.hip, LAYOUT): layout 1 = 1024 survivor
+    slots / map capacity 512 / 64 measurements (three per CU: PHD, CPHD, and the fused step with the block-form tail above 4096
+    particles), layout 2 = 512 / 128 / 32 (two per CU).  A filter created with PHD_LAYOUT=0 in the environment keeps the
+    general instantiations: the staged step (maps, log-weight increments, survivor lists) and the fused single-launch step (maps,
+    poses, normalised weights after the resample) of the two agree bit for bit."""
+    P, S = pkg(), synthetic()
+    import torch
+    G, M = (256, 64) if layout == 1 else (64, 32)
+    w = S.make_workload(N, G, M, seed=0x5EED0003 + layout, clustered=True)
+    cfg = P.default_config(filterType=ft, maxCardinality=255)
+    dev = torch.device("cuda:0")
+    dz = torch.from_numpy(w["z"][0].view(np.uint8).copy()).to(dev)
+    dn = torch.from_numpy(w["noise"][0].copy()).to(dev)
+    picks = (0, 5, N // 2, N - 1)
+    out = []
+    for general in ("1", "0"):
+        monkeypatch.setenv("PHD_LAYOUT", general)
+        with make_filter(cfg, w, cap=2 * G, mm=M) as f, make_filter(cfg, w, cap=2 * G, mm=M) as g:
+            f.debug(True)
+            f.predict((2.0, 0.05), w["noise"][0])
+            f.update(w["z"][0])
+            st = f.status()
+            staged = (f.get_maps(), f.weight_increments(), [f.survivors(p) for p in picks])
+            torch.cuda.synchronize()
+            g.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, w["uniform"][0], force_resample=True)
+            g.sync()
+            pg, lg = g.get_particles()
+            which = (P._lib.lib().phd_debug_update_instantiation(f._h), P._lib.lib().phd_debug_update_instantiation(g._h))
+            assert all(k >= 18 for k in which) if general == "1" else all(0 <= k < 18 for k in which), (general, which)
+            out.append((staged, (g.get_maps(), pg, lg), st))
+    (sa, fa, sta), (sb, fb, stb) = out
+    assert sta["max_survivors"] == stb["max_survivors"] and sta["max_map"] == stb["max_map"]
+    for p in range(N):
+        assert np.array_equal(sa[0][p].view(np.uint8), sb[0][p].view(np.uint8)), (ft, layout, p)
+        assert np.array_equal(fa[0][p].view(np.uint8), fb[0][p].view(np.uint8)), (ft, layout, "fused", p)
+    assert np.array_equal(sa[1].view(np.uint32), sb[1].view(np.uint32))
+    assert np.array_equal(fa[1], fb[1]) and np.array_equal(fa[2].view(np.uint32), fb[2].view(np.uint32))
+    for (xa, ia), (xb, ib) in zip(sa[2], sb[2]):
+        assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), (ft, layout)
+
+
 def test_update_max_measurements_and_full_map():
     """M = 256 (the reference's cap) and a map that fills its slab"""
     P, S = pkg(), synthetic()
