@@ -56,9 +56,9 @@
 #include "phd_predict.h"
 #include "phd_cphd.h"
 #include "phd_weights.h"
-// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU / -DPHD_W6H_TU compile the kernel template and one table of
+// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU / -DPHD_W6H_TU / -DPHD_L2_TU compile the kernel template and one table of
 //  instantiations each)
-#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU) || defined(PHD_CPHD_W6_TU) || defined(PHD_W6H_TU)
+#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU) || defined(PHD_CPHD_W6_TU) || defined(PHD_W6H_TU) || defined(PHD_L2_TU)
 #define PHD_PART_TU 1
 #endif
 #ifndef PHD_PART_TU
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #undef PHD_A_SCAP
 #undef PHD_A_CAP
 #undef PHD_A_MM
-// Five translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
+// Six translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
 // three-workgroups-per-CU ones (PHD, CPHD) are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU — the
 // kernel template above, one of these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
 // (csrc/Makefile, KFLAGS_CPHD: measured, currently the same).
@@ -755,6 +755,10 @@ extern const void* const k_update_w6_fns[6] = {(const void*)phd_update_merge_ker
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>,
                                                (const void*)phd_update_merge_kernel<false, false, false, false, 6, false, 1>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 1>};
+#elif defined(PHD_L2_TU)
+// the staged and the fused step, two per CU, with the layout of BASELINE.json configs[1] compiled in (csrc/Makefile: KFLAGS_L2)
+extern const void* const k_update_l2_fns[2] = {(const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>};
 #elif defined(PHD_W6H_TU)
 // the headline instantiation alone (csrc/Makefile: KFLAGS_W6H)
 extern const void* const k_update_w6h_fns[1] = {(const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 1>};
@@ -769,6 +773,7 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
 extern const void* const k_update_cphd_fns[5];
 extern const void* const k_update_w6_fns[6];
 extern const void* const k_update_w6h_fns[1];
+extern const void* const k_update_l2_fns[2];
 extern const void* const k_update_cphd_w6_fns[5];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
@@ -1208,8 +1213,7 @@ static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd
                                              // [15] (three per CU, CPHD) with LAYOUT = 1, of [0], [2] (two per CU, PHD) with LAYOUT = 2
                                              k_update_w6_fns[4], k_update_w6h_fns[0], k_update_w6_fns[5],
                                              k_update_cphd_w6_fns[3], k_update_cphd_w6_fns[4],
-                                             (const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
-                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>};
+                                             k_update_l2_fns[0], k_update_l2_fns[1]};
 #define PHD_N_UPDATE_FNS 25
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of

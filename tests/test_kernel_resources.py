@@ -38,7 +38,7 @@ def compiled(tmp_path_factory):
         pytest.skip("hipcc not available")
     cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
     jobs = []
-    for target in ("print-kflags", "print-kflags-cphd", "print-kflags-w6", "print-kflags-cphd-w6", "print-kflags-w6h"):
+    for target in ("print-kflags", "print-kflags-cphd", "print-kflags-w6", "print-kflags-cphd-w6", "print-kflags-w6h", "print-kflags-l2"):
         d = tmp_path_factory.mktemp("isa")
         cmd = [cc] + kernel_flags(target) + ["--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj", "-c",
                                              os.path.join(SRC, "phd_kernels.hip"), "-o", str(d / "k.o")]
