@@ -56,9 +56,9 @@
 #include "phd_predict.h"
 #include "phd_cphd.h"
 #include "phd_weights.h"
-// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU / -DPHD_W6H_TU / -DPHD_L2_TU compile the kernel template and one table of
+// (partial translation units: -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU compile the kernel template and one table of
 //  instantiations each)
-#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU) || defined(PHD_CPHD_W6_TU) || defined(PHD_W6H_TU) || defined(PHD_L2_TU)
+#if defined(PHD_CPHD_TU) || defined(PHD_W6_TU) || defined(PHD_CPHD_W6_TU)
 #define PHD_PART_TU 1
 #endif
 #ifndef PHD_PART_TU
@@ -132,8 +132,12 @@ __device__ __forceinline__ void handoff_ticket(unsigned* ticket)
 // configurations (configs[2], [3], [4]: 1024 / 512 / 64), 2 = configs[1] (512 / 128 / 32).  Same library, same visit, PHD_LAYOUT=0
 // against the default: 4096 x 256 x 64 4 260 -> 4 270 steps/s, CPHD 2 714 -> 2 816 (+3.8 %), 16 384 x 256 x 64 1 232 -> 1 285
 // (+4.3 %), 256 x 64 x 32 61.7 k -> 62.9 k (+1.9 %).  (A third layout, for bench.py's dense-scan rider - 2048 / 768 / 256 with a
-// spill list - measured nothing, 150.0 against 150.2 steps/s, and was not kept.)  The launcher picks the instantiation by the
-// filter's layout; the LAYOUT = 0 instantiations keep, textually, the code they had.
+// spill list - measured nothing, 150.0 against 150.2 steps/s, and was not kept.)  These instantiations also take the MEASUREMENT
+// COUNT as a constant — a full scan, M = the measurement capacity, which is what those configurations are: on top of the layout,
+// same visit, 4 342 -> 4 468 steps/s at the headline (+2.9 %), CPHD 2 808 -> 3 001 (+6.9 %: the block's tile count and sweep lengths
+// fold), 16 384 particles 1 283 -> 1 328, 256 x 64 x 32 64.1 k -> 66.2 k.  The launcher picks the instantiation per LAUNCH by the
+// filter's layout and the scan's length (a shorter scan runs the general one); the LAYOUT = 0 instantiations keep, textually, the
+// code they had.
 template <int LAYOUT> struct FixedLayout { static constexpr int S = 0, C = 0, MM = 0; };
 template <> struct FixedLayout<1> { static constexpr int S = 1024, C = 512, MM = 64; };
 template <> struct FixedLayout<2> { static constexpr int S = 512, C = 128, MM = 32; };
@@ -230,7 +234,9 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     }
     const int p = blockIdx.x;
     const DevConfig& cfg = A.cfg;
-    const int cap = PHD_A_CAP, S_cap = PHD_A_SCAP, M = A.M;
+    // (LAYOUT != 0: a FULL scan — as many measurements as the filter holds, what BASELINE.json's configurations are — so that the
+    //  measurement count is a constant too: the grids of pass 1 and pass 2, the CPHD block's tile count and sweep lengths fold)
+    const int cap = PHD_A_CAP, S_cap = PHD_A_SCAP, M = LAYOUT ? PHD_A_MM : A.M;
     const int src = A.parent[p];
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
     const unsigned rows_stride = FUSEW ? 0u : A.out_stride; // rows mode belongs to the multi-GPU step (never the fused tail)
@@ -312,8 +318,9 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         //  depends on the indirection — parent[p] -> count[src] -> slab — and a lone workgroup per CU pays every link of that
         //  chain; the slab's address needs only `src`, so its loads now travel beside the count's.  At most cap - n_map unused
         //  words per plane, inside the slab)
-        //  Built into the 80-register CPHD translation unit only (csrc/Makefile: -DPHD_SLAB_AHEAD): same-visit A/B at 4096 x 256 x 64,
-        //  CPHD 2 640 -> 2 707 steps/s, the 80-register PHD kernel 4 263 -> 4 209 (its register allocation moves), 256 x 64 x 32 +0.3 %.
+        //  -DPHD_SLAB_AHEAD; built into no part at present (csrc/Makefile): same-visit A/B at 4096 x 256 x 64 while the kernels took their
+        //  layout from the arguments: CPHD 2 640 -> 2 707 steps/s, the 80-register PHD kernel 4 263 -> 4 209 (its register allocation
+        //  moves), 256 x 64 x 32 +0.3 %; with the layout and the scan's length compiled in: CPHD -1.3 %, the headline -0.5 %.
 #ifdef PHD_SLAB_AHEAD
         int i0 = 0;
         do {
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #undef PHD_A_SCAP
 #undef PHD_A_CAP
 #undef PHD_A_MM
-// Six translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
+// Four translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
 // three-workgroups-per-CU ones (PHD, CPHD) are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU — the
 // kernel template above, one of these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
 // (csrc/Makefile, KFLAGS_CPHD: measured, currently the same).
@@ -747,21 +754,14 @@ extern const void* const k_update_cphd_w6_fns[5] = {(const void*)phd_update_merg
 #elif defined(PHD_W6_TU)
 // <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
 // + the fused step with the block-form tail (more than 4096 particles)
-// [4], [5]: the staged step and the fused step with the block-form tail with LAYOUT = 1 compiled in (the fused step with LAYOUT = 1
-// — the headline — is a part of its own, PHD_W6H_TU)
-extern const void* const k_update_w6_fns[6] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
+// [4], [5], [6]: the staged step, the fused step (the headline) and the fused step with the block-form tail with LAYOUT = 1 compiled in
+extern const void* const k_update_w6_fns[7] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>,
                                                (const void*)phd_update_merge_kernel<false, false, false, false, 6, false, 1>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 1>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 1>};
-#elif defined(PHD_L2_TU)
-// the staged and the fused step, two per CU, with the layout of BASELINE.json configs[1] compiled in (csrc/Makefile: KFLAGS_L2)
-extern const void* const k_update_l2_fns[2] = {(const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
-                                               (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>};
-#elif defined(PHD_W6H_TU)
-// the headline instantiation alone (csrc/Makefile: KFLAGS_W6H)
-extern const void* const k_update_w6h_fns[1] = {(const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 1>};
 #elif defined(PHD_CPHD_TU)
 // <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
 extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
@@ -771,9 +771,7 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
                                                  (const void*)phd_update_merge_kernel<false, true, true, true>};
 #else
 extern const void* const k_update_cphd_fns[5];
-extern const void* const k_update_w6_fns[6];
-extern const void* const k_update_w6h_fns[1];
-extern const void* const k_update_l2_fns[2];
+extern const void* const k_update_w6_fns[7];
 extern const void* const k_update_cphd_w6_fns[5];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
@@ -1211,9 +1209,10 @@ static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd
                                              (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, true>,
                                              // [18..24] compiled-in layouts (the kernel template's LAYOUT): of [10], [12], [16] (three per CU, PHD), of [13],
                                              // [15] (three per CU, CPHD) with LAYOUT = 1, of [0], [2] (two per CU, PHD) with LAYOUT = 2
-                                             k_update_w6_fns[4], k_update_w6h_fns[0], k_update_w6_fns[5],
+                                             k_update_w6_fns[4], k_update_w6_fns[5], k_update_w6_fns[6],
                                              k_update_cphd_w6_fns[3], k_update_cphd_w6_fns[4],
-                                             k_update_l2_fns[0], k_update_l2_fns[1]};
+                                             (const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
+                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>};
 #define PHD_N_UPDATE_FNS 25
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
@@ -1305,16 +1304,16 @@ static int update_fn_index_any_layout(const UpdateArgs& a, bool three, int n_par
     if (three && !sp) return (a.cphd ? 13 : 10) + (a.stamps ? 1 : fused ? 2 : 0);
     return a.stamps ? (a.cphd ? 4 : 1) : a.cphd ? (fused ? (sp ? 9 : 5) : (sp ? 8 : 3)) : (fused ? (sp ? 7 : 2) : (sp ? 6 : 0));
 }
-// ... and, where the filter's layout is one of the compiled-in ones, the instantiation that has it as constants (any_layout: never
+// ... and, where the filter's layout is one of the compiled-in ones and the scan is full, the instantiation that has both as constants (any_layout: never
 // — a filter created with PHD_LAYOUT=0 in the environment: A/B, and the test that compares the two bit for bit)
 static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0, bool any_layout = false)
 {
     const int fn = update_fn_index_any_layout(a, three, n_particles);
     if (any_layout) return fn;
-    if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM) {
+    if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM && a.M == FixedLayout<1>::MM) {
         switch (fn) { case 10: return 18; case 12: return 19; case 16: return 20; case 13: return 21; case 15: return 22; default: break; }
     }
-    if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM) {
+    if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM && a.M == FixedLayout<2>::MM) {
         switch (fn) { case 0: return 23; case 2: return 24; default: break; }
     }
     return fn;

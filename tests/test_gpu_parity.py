@@ -275,7 +275,8 @@ def test_two_and_three_per_cu_builds_agree_at_the_headline_layout(ft, monkeypatc
 @pytest.mark.parametrize("ft,layout,N", [(0, 1, 768), (1, 1, 768), (0, 2, 300), (0, 1, 4500)])
 def test_compiled_in_layouts_agree_with_the_general_instantiations(ft, layout, N, monkeypatch):
     """Round 5: filters with the LDS layout of BASELINE.json's configurations run instantiations of the update kernel that have
-    the layout as compile-time constants (every LDS array an immediate offset; phd_kernels.hip, LAYOUT): layout 1 = 1024 survivor
+    the layout — and the scan's length: a full scan — as compile-time constants (every LDS array an immediate offset, the
+    measurement count folded; phd_kernels.hip, LAYOUT): layout 1 = 1024 survivor
     slots / map capacity 512 / 64 measurements (three per CU: PHD, CPHD, and the fused step with the block-form tail above 4096
     particles), layout 2 = 512 / 128 / 32 (two per CU).  A filter created with PHD_LAYOUT=0 in the environment keeps the
     general instantiations: the staged step (maps, log-weight increments, survivor lists) and the fused single-launch step (maps,
@@ -304,12 +305,24 @@ def test_compiled_in_layouts_agree_with_the_general_instantiations(ft, layout, N
             pg, lg = g.get_particles()
             which = (P._lib.lib().phd_debug_update_instantiation(f._h), P._lib.lib().phd_debug_update_instantiation(g._h))
             assert all(k >= 18 for k in which) if general == "1" else all(0 <= k < 18 for k in which), (general, which)
-            out.append((staged, (g.get_maps(), pg, lg), st))
-    (sa, fa, sta), (sb, fb, stb) = out
+            # a SHORTER scan on the same filter: the compiled-in instantiations assume a full one, the launcher must take the general
+            # instantiation for this launch (and the step after it is a full scan again)
+            f.predict((2.0, 0.05), w["noise"][0])
+            f.update(w["z"][0][:M - 3])
+            assert 0 <= P._lib.lib().phd_debug_update_instantiation(f._h) < 18
+            short = (f.get_maps(), f.weight_increments())
+            f.predict((2.0, 0.05), w["noise"][0])
+            f.update(w["z"][0])
+            assert (P._lib.lib().phd_debug_update_instantiation(f._h) >= 18) == (general == "1")
+            out.append((staged, (g.get_maps(), pg, lg), st, short, f.get_maps()))
+    (sa, fa, sta, sha, la), (sb, fb, stb, shb, lb) = out
     assert sta["max_survivors"] == stb["max_survivors"] and sta["max_map"] == stb["max_map"]
+    assert np.array_equal(sha[1].view(np.uint32), shb[1].view(np.uint32))
     for p in range(N):
         assert np.array_equal(sa[0][p].view(np.uint8), sb[0][p].view(np.uint8)), (ft, layout, p)
         assert np.array_equal(fa[0][p].view(np.uint8), fb[0][p].view(np.uint8)), (ft, layout, "fused", p)
+        assert np.array_equal(sha[0][p].view(np.uint8), shb[0][p].view(np.uint8)), (ft, layout, "short scan", p)
+        assert np.array_equal(la[p].view(np.uint8), lb[p].view(np.uint8)), (ft, layout, "third step", p)
     assert np.array_equal(sa[1].view(np.uint32), sb[1].view(np.uint32))
     assert np.array_equal(fa[1], fb[1]) and np.array_equal(fa[2].view(np.uint32), fb[2].view(np.uint32))
     for (xa, ia), (xb, ib) in zip(sa[2], sb[2]):
