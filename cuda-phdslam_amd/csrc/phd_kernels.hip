@@ -138,19 +138,22 @@ __device__ __forceinline__ void handoff_ticket(unsigned* ticket)
 // fold), 16 384 particles 1 283 -> 1 328, 256 x 64 x 32 64.1 k -> 66.2 k.  The launcher picks the instantiation per LAUNCH by the
 // filter's layout and the scan's length (a shorter scan runs the general one); the LAYOUT = 0 instantiations keep, textually, the
 // code they had.
-template <int LAYOUT> struct FixedLayout { static constexpr int S = 0, C = 0, MM = 0; };
-template <> struct FixedLayout<1> { static constexpr int S = 1024, C = 512, MM = 64; };
-template <> struct FixedLayout<2> { static constexpr int S = 512, C = 128, MM = 32; };
+template <int LAYOUT> struct FixedLayout { static constexpr int S = 0, C = 0, MM = 0, CN = 0; };
+template <> struct FixedLayout<1> { static constexpr int S = 1024, C = 512, MM = 64, CN = 256; };
+template <> struct FixedLayout<2> { static constexpr int S = 512, C = 128, MM = 32, CN = 256; };
 #define PHD_A_SCAP (LAYOUT ? FixedLayout<LAYOUT>::S : A.S_cap)
 #define PHD_A_CAP (LAYOUT ? FixedLayout<LAYOUT>::C : A.cap)
 #define PHD_A_MM (LAYOUT ? FixedLayout<LAYOUT>::MM : A.MM)
+// (CPHD: the length of the cardinality rows — max_cardinality + 1 = 256 in BASELINE.json configs[4] — a constant too: 3 040 -> 3 127
+//  steps/s on top of the full scan; before the scan's length was a constant the same change measured -0.7 %)
+#define PHD_A_CNLEN (LAYOUT ? FixedLayout<LAYOUT>::CN : A.cn_len)
 template <bool STAMPS, bool FUSEW, bool CPHD, bool SPILL, int MINW = PHD_MIN_WAVES, bool GRIDT = false, int LAYOUT = 0>
 __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L = lds_carve((lds_u8)lds_raw, PHD_A_SCAP, PHD_A_CAP, PHD_A_MM);
     // CPHD instantiation: its arrays follow the common layout
-    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(PHD_A_SCAP, PHD_A_CAP, PHD_A_MM).total, (lds_u8)lds_raw, PHD_A_SCAP, A.cn_len, PHD_A_MM) : CphdLds();
+    const CphdLds Q = CPHD ? cphd_carve((lds_u8)lds_raw + lds_offsets(PHD_A_SCAP, PHD_A_CAP, PHD_A_MM).total, (lds_u8)lds_raw, PHD_A_SCAP, PHD_A_CNLEN, PHD_A_MM) : CphdLds();
     if (CPHD) L.zpart = Q.zscr;   // the block parks rows of cn_len doubles where pass 1 leaves its partial sums: a scratch of its own
 
     const int tid = threadIdx.x;
@@ -441,8 +444,8 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
         const float pdw = block_sum(pdw_local, L.red, tid);
         const float w_all = block_sum(wall_local, L.red, tid);
         __syncthreads();
-        cphd_block(L, Q, cfg, M, PHD_A_MM, A.cn_len, A.lfact, A.lfact_len, A.cn_in + (size_t)src * A.cn_len,
-                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)A.cn_len), A.cphd_scratch + (size_t)p * PHD_A_MM * PHD_A_MM, w_all, pdw, tid,
+        cphd_block(L, Q, cfg, M, PHD_A_MM, PHD_A_CNLEN, A.lfact, A.lfact_len, A.cn_in + (size_t)src * PHD_A_CNLEN,
+                   A.cn_out + (size_t)p * (rows_stride ? rows_stride : (unsigned)PHD_A_CNLEN), A.cphd_scratch + (size_t)p * PHD_A_MM * PHD_A_MM, w_all, pdw, tid,
                    STAMPS ? cq : nullptr, S_cap, STAMPS ? st : nullptr);
         const float r1 = Q.scal[CQ_R1];
         // births (weight bw (lambda/kappa) <Y1[Z\m],p>/<Y0,p>)
@@ -738,6 +741,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #undef PHD_A_SCAP
 #undef PHD_A_CAP
 #undef PHD_A_MM
+#undef PHD_A_CNLEN
 // Four translation units from this one file (csrc/Makefile): the CPHD instantiations of the update kernel and the
 // three-workgroups-per-CU ones (PHD, CPHD) are compiled on their own with -DPHD_CPHD_TU / -DPHD_W6_TU / -DPHD_CPHD_W6_TU — the
 // kernel template above, one of these tables and nothing else — so that the parts build side by side and the CPHD part can take compile flags of its own
@@ -1311,7 +1315,12 @@ static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0,
     const int fn = update_fn_index_any_layout(a, three, n_particles);
     if (any_layout) return fn;
     if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM && a.M == FixedLayout<1>::MM) {
-        switch (fn) { case 10: return 18; case 12: return 19; case 16: return 20; case 13: return 21; case 15: return 22; default: break; }
+        switch (fn) {
+        case 10: return 18; case 12: return 19; case 16: return 20;
+        case 13: if (a.cn_len == FixedLayout<1>::CN) return 21; break;       // (CPHD: the cardinality rows' length is compiled in as well)
+        case 15: if (a.cn_len == FixedLayout<1>::CN) return 22; break;
+        default: break;
+        }
     }
     if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM && a.M == FixedLayout<2>::MM) {
         switch (fn) { case 0: return 23; case 2: return 24; default: break; }
