@@ -696,7 +696,9 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     // ---- merge ----------------------------------------------------------------------------------------
     const int n_update = n_in * (M + 1) + M;
     const bool packed = (n_update + n_map <= 0xFFFF) && (S_cap <= 0x10000);
-    if (cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
+    // (the PHD instantiations with a compiled-in layout also assume the Mahalanobis merge metric — the reference's default, and a
+    //  per-filter constant: the Hellinger copy of the merge is not in them; +0.7 % at the headline, nothing for CPHD, which keeps both)
+    if ((LAYOUT && !CPHD) || cfg.distanceMetric == 0) merge_in_lds<false, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
     else merge_in_lds<true, STAMPS>(L, S_cap, n_surv, cfg, out, cap, tid, st, n_update, packed, bm);
     PHD_TRACE_AT(5);
     int k_out = L.ctr[CTR_KOUT];
@@ -1316,14 +1318,14 @@ static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0,
     if (any_layout) return fn;
     if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM && a.M == FixedLayout<1>::MM) {
         switch (fn) {
-        case 10: return 18; case 12: return 19; case 16: return 20;
+        case 10: case 12: case 16: if (a.cfg.distanceMetric == 0) return fn == 10 ? 18 : fn == 12 ? 19 : 20; break;   // (PHD: the Mahalanobis merge only)
         case 13: if (a.cn_len == FixedLayout<1>::CN) return 21; break;       // (CPHD: the cardinality rows' length is compiled in as well)
         case 15: if (a.cn_len == FixedLayout<1>::CN) return 22; break;
         default: break;
         }
     }
     if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM && a.M == FixedLayout<2>::MM) {
-        switch (fn) { case 0: return 23; case 2: return 24; default: break; }
+        if (a.cfg.distanceMetric == 0) switch (fn) { case 0: return 23; case 2: return 24; default: break; }
     }
     return fn;
 }

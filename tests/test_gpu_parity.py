@@ -327,6 +327,14 @@ def test_compiled_in_layouts_agree_with_the_general_instantiations(ft, layout, N
     assert np.array_equal(fa[1], fb[1]) and np.array_equal(fa[2].view(np.uint32), fb[2].view(np.uint32))
     for (xa, ia), (xb, ib) in zip(sa[2], sb[2]):
         assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), (ft, layout)
+    if ft == 0:
+        # the PHD fast path has only the Mahalanobis merge in it: a filter of the same layout with the Hellinger metric runs the general one
+        monkeypatch.setenv("PHD_LAYOUT", "1")
+        with make_filter(P.default_config(distanceMetric=1), w, cap=2 * G, mm=M) as h:
+            h.predict((2.0, 0.05), w["noise"][0])
+            h.update(w["z"][0])
+            h.status()
+            assert 0 <= P._lib.lib().phd_debug_update_instantiation(h._h) < 18
 
 
 def test_update_max_measurements_and_full_map():
