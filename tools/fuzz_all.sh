@@ -12,5 +12,6 @@ run python tools/fuzz_multi.py $t 1
 run python tools/fuzz_resample.py 40 1
 run python tools/fuzz_gm_reduce.py 40 1
 run python tools/fuzz_cphd.py $t 1
+run python tools/fuzz_layout.py $t 1
 run python tools/determinism_check.py
 cat $out
