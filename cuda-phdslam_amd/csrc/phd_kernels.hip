@@ -752,22 +752,24 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #if defined(PHD_CPHD_W6_TU)
 // <STAMPS, FUSEW, CPHD, -, 6>: the same three for the CPHD filter
 // [3], [4]: the staged and the fused step with the layout of BASELINE.json's 256-Gaussian configurations compiled in (LAYOUT = 1)
-extern const void* const k_update_cphd_w6_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
+extern const void* const k_update_cphd_w6_fns[6] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<true, false, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<false, true, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<false, false, true, false, 6, false, 1>,
-                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6, false, 1>};
+                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6, false, 1>,
+                                                    (const void*)phd_update_merge_kernel<true, false, true, false, 6, false, 1>};   // [5]: the diagnostic one
 #elif defined(PHD_W6_TU)
 // <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
 // + the fused step with the block-form tail (more than 4096 particles)
 // [4], [5], [6]: the staged step, the fused step (the headline) and the fused step with the block-form tail with LAYOUT = 1 compiled in
-extern const void* const k_update_w6_fns[7] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
+extern const void* const k_update_w6_fns[8] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>,
                                                (const void*)phd_update_merge_kernel<false, false, false, false, 6, false, 1>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 1>,
-                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 1>};
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 1>,
+                                               (const void*)phd_update_merge_kernel<true, false, false, false, 6, false, 1>};   // [7]: the diagnostic one
 #elif defined(PHD_CPHD_TU)
 // <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
 extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
@@ -777,8 +779,8 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
                                                  (const void*)phd_update_merge_kernel<false, true, true, true>};
 #else
 extern const void* const k_update_cphd_fns[5];
-extern const void* const k_update_w6_fns[7];
-extern const void* const k_update_cphd_w6_fns[5];
+extern const void* const k_update_w6_fns[8];
+extern const void* const k_update_cphd_w6_fns[6];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
@@ -1200,7 +1202,7 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-#define PHD_N_UPDATE_FNS_DECL 25
+#define PHD_N_UPDATE_FNS_DECL 27
 static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
@@ -1218,8 +1220,10 @@ static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd
                                              k_update_w6_fns[4], k_update_w6_fns[5], k_update_w6_fns[6],
                                              k_update_cphd_w6_fns[3], k_update_cphd_w6_fns[4],
                                              (const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
-                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>};
-#define PHD_N_UPDATE_FNS 25
+                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>,
+                                             // [25], [26]: the diagnostic instantiations (phase stamps) of the three-per-CU fast path, PHD and CPHD
+                                             k_update_w6_fns[7], k_update_cphd_w6_fns[5]};
+#define PHD_N_UPDATE_FNS 27
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1319,6 +1323,8 @@ static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0,
     if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM && a.M == FixedLayout<1>::MM) {
         switch (fn) {
         case 10: case 12: case 16: if (a.cfg.distanceMetric == 0) return fn == 10 ? 18 : fn == 12 ? 19 : 20; break;   // (PHD: the Mahalanobis merge only)
+        case 11: if (a.cfg.distanceMetric == 0) return 25; break;
+        case 14: if (a.cn_len == FixedLayout<1>::CN) return 26; break;
         case 13: if (a.cn_len == FixedLayout<1>::CN) return 21; break;       // (CPHD: the cardinality rows' length is compiled in as well)
         case 15: if (a.cn_len == FixedLayout<1>::CN) return 22; break;
         default: break;

@@ -255,7 +255,7 @@ int phd_debug_gm_rounds(phd_filter* f);
  * remote ones parked in guest slabs; PHD_COPY_FREE=0 in the environment at phd_create selects the copying forms) — diagnostics */
 int phd_debug_copy_free_resamples(phd_filter* f);
 /* which instantiation of the update kernel the last update launch of this filter ran: the index into the launcher's table
- * (csrc/phd_kernels.hip: 0..17 take the LDS layout and the scan's length from the arguments, 18..24 have the layout of a
+ * (csrc/phd_kernels.hip: 0..17 take the LDS layout and the scan's length from the arguments, 18..26 have the layout of a
  * BASELINE.json configuration and a full scan compiled in — picked per launch; PHD_LAYOUT=0 in the environment at phd_create keeps a
  * filter on the former) — diagnostics; -1 before any launch */
 int phd_debug_update_instantiation(phd_filter* f);
