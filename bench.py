@@ -289,6 +289,11 @@ def timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms, agree=None):
     return elapsed, gpu_region_ms, [pct(0.1), pct(0.5), pct(0.9)], preroll
 
 
+def _instantiation(P, f):
+    k = int(P._lib.lib().phd_debug_update_instantiation(f._h))
+    return {"index": k, "fast_path": k >= 18}
+
+
 def make_filter(P, torch, cfg_id, n_local, G, M, n_global, offset, dev, local_rank, map_capacity=0, survivor_capacity=0):
     cfg = P.default_config(n_particles=n_global)
     if cfg_id == 5:                                           # BASELINE.json configs[4]: the CPHD variant
@@ -396,6 +401,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
 
     elapsed, gpu_region_ms, pcts, preroll = timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms)
     st = f.status()
+    inst = _instantiation(P, f)                       # (of the timed steps: the stamped pass below runs the diagnostic instantiation)
 
     # kernel durations from HIP events on the filter's stream (separate pass: events perturb the timed loop)
     k_ev = min(steps, 100)
@@ -478,6 +484,11 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
                    "one_launch_per_step": bool(one_launch_per_step),
                    "max_survivors": st["max_survivors"], "max_map": st["max_map"],
                    "update_residency": f.residency(),
+                   # which instantiation of the update kernel the steps ran (csrc/phd_kernels.hip: below 18 the LDS layout and the
+                   # scan's length come from the arguments; from 18 the configuration's layout, a full scan and — PHD — the
+                   # Mahalanobis merge metric / — CPHD — the cardinality length are compiled in: the fast path, picked per launch,
+                   # bit for bit the general one; PHD_LAYOUT=0 in the environment turns it off)
+                   "update_kernel_instantiation": inst,
                    "steps_per_s_unforced_resample": unforced},
         "stages_us_per_workgroup": stages,
         "roofline": roof,
