@@ -36,3 +36,59 @@ def test_bench_gpus_n_without_a_launcher_refuses_missing_devices():
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+
+
+def test_line_is_compact():
+    """The driver's record of a bench run is the LAST stdout line, and it keeps a bounded tail of stdout: round 5's line had grown to
+    21.7 KB (riders, notes, thread scans) and BENCH_r05.json.parsed was null.  bench.py now prints compact_line(record) and writes
+    the record itself to profiles/bench_last.json.  Here: round 5's full 21.7 KB record (the canned input) through that same
+    function -> <= 4096 bytes, json round trip, every key of the contract present and non-null where the record had it."""
+    import json
+    bench = importlib.import_module("bench")
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_invocation.json")))
+    assert len(json.dumps(full)) > 20000                      # the canned record is the one that broke the driver's parser
+    full["value_general"] = 4300.123456789
+    full["config"]["update_kernel_instantiation"] = {"index": 20, "fast_path": True}   # (the key the last commit of round 5 added)
+    for k, r in enumerate(full["secondary"]):
+        r["rider"] = "cfg%d_a_rider_with_a_long_label" % k
+    text = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(text) <= bench.LINE_LIMIT == 4096, len(text)
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "value_general", "riders"):
+        assert key in line, key
+    assert line["value"] == float("%.6g" % full["value"]) and line["unit"] == "steps/s" and line["vs_baseline"] is None
+    assert len(line["config"]["workload"]) <= 120 and "model" not in line["config"]
+    assert (line["config"]["N"], line["config"]["G"], line["config"]["M"]) == (4096, 256, 64)
+    assert line["config"]["instantiation"] == 20 and line["config"]["fast_path"] is True
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_us", "library_build"):
+        assert line["roofline"].get(key) is not None, key
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert line["cpu_baseline"].get(key) is not None, key
+    assert len(line["cpu_baseline"]["sample"]) <= 120
+    assert len(line["riders_steps_per_s"]) == len(full["secondary"])
+    # no string of the line is longer than what the driver keeps of any string
+    def strings(x):
+        if isinstance(x, str):
+            yield x
+        elif isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from strings(v)
+    assert max(len(t) for t in strings(line)) <= 120
+
+
+def test_emit_prints_the_compact_line_last_and_writes_the_record(tmp_path, capsys, monkeypatch):
+    import json
+    bench = importlib.import_module("bench")
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_invocation.json")))
+    rec = tmp_path / "bench_last.json"
+    monkeypatch.setattr(bench, "RECORD_PATH", str(rec))
+    bench.emit(full)
+    out = capsys.readouterr().out.strip().splitlines()
+    line = json.loads(out[-1])
+    assert len(out[-1]) <= 4096 and line["value"] == float("%.6g" % full["value"])
+    assert json.load(open(rec))["secondary"] == full["secondary"]        # nothing of the record is lost

@@ -7,6 +7,8 @@ tag=${1:-r05}
 P=$GRAFT_REPO_ROOT/tools/probes/valu_issue_probe
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
+# the probe is built here from its source (the binary is not tracked: tools/probes/.gitignore)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $P $GRAFT_REPO_ROOT/tools/probes/valu_issue_probe.hip || exit 1
 $P --json $O/valu_probe_plain_$tag.json > $O/valu_probe_plain_$tag.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
