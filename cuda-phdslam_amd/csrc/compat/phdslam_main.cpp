@@ -8,6 +8,9 @@
 //
 //   phdslam <config.cfg> [synth] [--out DIR] [--seed S] [--capacity C] [--steps K] [--log7] [--device-noise] [--devices N [--shards S]]
 //
+// environment: PHD_DRIVER_SYNC=1 the step-synchronous loop (run_synth's own structure) instead of the pipelined one;
+// PHD_DRIVER_PROFILE=1 per-phase times of the synchronous loop; PHD_DRIVER_SYNC_LOG=1 logs written in line.
+//
 // --devices N: ONE filter sharded over N GPUs of this process (include/phdslam_multi.h: one shard and one stream per
 // device, RCCL all-gather of the log-weights, global resample, particle migration over xGMI).  --shards S > N puts several
 // shards on a device (exchange by device copies; for boxes with fewer GPUs than shards).  Same files in, same logs out.
@@ -313,7 +316,137 @@ int main(int argc, char** argv)
     double step_t[5] = {0, 0, 0, 0, 0};
     FILE* prof_file = prof ? fopen((out_dir + "/loopProfile.log").c_str(), "w") : nullptr;
 #define PROF_MARK(k) do { if (prof) { const double t_ = now(); acc_t[k] += t_ - tp; step_t[k] = t_ - tp; tp = t_; } } while (0)
-    for (int n = 0; n < nSteps; ++n) {
+    // ---- the pipelined loop (round 6): the plain configuration — one predicted particle per prior particle, MAP map, PHD filter —
+    // runs WITHOUT a host synchronisation inside the step.  run_synth's step is predict -> update -> recoverSlamState -> log ->
+    // nEff test -> resample (src/main.cpp:1244-1297), with the host waiting for the device three times; here the host only
+    // enqueues: the control noise of step n + 1 and its resampling uniform are drawn by a helper thread (the SAME random stream in
+    // the SAME order: noise of the step, then its uniform — the draws do not depend on the filter's state), the state of step n is
+    // captured on the device between its update and its resample (the order of the log's contents, :1271-1297), the resample is
+    // decided on the device from the same nEff float, and the log of step n is handed to the writers while step n + 1 runs.
+    // Same files, character for character (tests/test_gpu_driver.py compares the two loops); PHD_DRIVER_SYNC=1 runs the loop below.
+    const bool pipelined = !config.followTrajectory && kshot == 1 && !config.savePrediction && !(config.mapEstimate & 2) &&
+                           config.filterType != 1 && !prof && getenv("PHD_DRIVER_SYNC") == nullptr;
+    if (pipelined) {
+        const int n_part = phd_n_particles(f);
+        const int sub = config.subdividePredict > 0 ? config.subdividePredict : 1;
+        const size_t slot_entries = (size_t)n_part * sub;
+        phd_ackerman_noise* ring[3] = {nullptr, nullptr, nullptr};
+        for (auto& r : ring) { r = (phd_ackerman_noise*)phd_host_alloc(slot_entries * sizeof(phd_ackerman_noise)); if (!r) die("phd_host_alloc"); }
+        std::vector<double> uniforms((size_t)nSteps > 0 ? nSteps : 1);
+        std::mutex mu;
+        std::condition_variable cv;
+        int produced = 0, retired = -1;                      // steps whose draws are ready; last step whose snapshot was waited for
+        bool stop = false;
+        std::thread producer([&]() {
+            for (int m = 0; m < nSteps; ++m) {
+                {   // slot m % 3 is free once step m - 3 has been retired (its upload is behind the device by then)
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || retired >= m - 3; });
+                    if (stop) return;
+                }
+                if (m > 0 && !device_noise) {
+                    phd_ackerman_noise* nz = ring[m % 3];
+                    for (size_t i = 0; i < slot_entries; ++i) {                              // phdfilter.cu:1147-1152
+                        nz[i].n_alpha = (float)(config.stdAlpha * randn());
+                        nz[i].n_encoder = (float)(config.stdEncoder * randn());
+                    }
+                }
+                uniforms[m] = randu01();
+                { std::lock_guard<std::mutex> lk(mu); produced = m + 1; }
+                cv.notify_all();
+            }
+        });
+        struct Pending { int M; bool resample_enqueued; double elapsed; };
+        std::vector<Pending> pend((size_t)nSteps > 0 ? nSteps : 1);
+        bool failed_nan = false;
+        // retire step k: wait for its download, hand its log to the writers, print its line
+        auto retire = [&](int k) -> bool {
+            phd_snapshot_view v;
+            const int rc = phd_snapshot_wait(f, k & 1, &v);
+            if (rc == PHD_ERR_NAN) { printf("nan weights detected! exiting...\n"); failed_nan = true; return false; }      // :1307-1311
+            if (rc != PHD_OK) die("phd_snapshot_wait");
+            const int n_cur = v.n_particles;
+            const int did = pend[k].resample_enqueued ? v.report.did_resample : 0;
+            LogJob j;
+            j.step = k; j.n_map = v.n_map; j.n_cur = n_cur; j.did = did != 0; j.expected = *v.expected;
+            j.map.assign(v.map, v.map + v.n_map);
+            j.logw.assign(v.log_weights, v.log_weights + n_cur);
+            j.poses.assign(v.poses, v.poses + n_cur);
+            if (log7) {
+                j.ridx.resize((size_t)n_cur);
+                if (did && v.resample_idx) std::copy(v.resample_idx, v.resample_idx + n_cur, j.ridx.begin());
+                else for (int i = 0; i < n_cur; ++i) j.ridx[i] = i;                                               // :1292-1296
+            }
+            if (sync_log) {
+                CHK(write_job(j));
+            } else {
+                std::unique_lock<std::mutex> lk(log_mu);
+                log_cv.wait(lk, [&] { return (int)log_q.size() + log_inflight < 8; });
+                if (log_err) { lk.unlock(); finish_logs(); die("state log"); }
+                log_q.push_back(std::move(j));
+                lk.unlock();
+                log_cv.notify_all();
+            }
+            if (FILE* tf = fopen(timefile.c_str(), "a")) { fprintf(tf, "%g\n", pend[k].elapsed); fclose(tf); }      // :1300-1305
+            printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", k, nSteps, pend[k].M, n_cur, v.n_map, did,
+                   pend[k].elapsed);
+            { std::lock_guard<std::mutex> lk(mu); retired = k; }
+            cv.notify_all();
+            return true;
+        };
+        int enqueued = 0;
+        for (int n = 0; n < nSteps; ++n) {
+            timeval t0, t1;
+            gettimeofday(&t0, nullptr);
+            const phd_measurement* Z = nullptr;
+            int M = 0;
+            if (has_timestamps) {                                                                // :1189-1229
+                if (z_idx >= n_mt || c_idx >= n_ct) { printf("no more timestamps\n"); break; }
+                const bool meas_first = mtimes[z_idx] < ctimes[c_idx], both = mtimes[z_idx] == ctimes[c_idx];
+                last_time = current_time;
+                current_time = ctimes[c_idx];      // (sic) the reference takes the control's time stamp in all three branches
+                config.dt = current_time - last_time;
+                setDeviceConfig(config);
+                CHK(phd_set_config(f, &config));
+                if (meas_first) { Z = meas.data() + moff[z_idx]; M = sizes[z_idx]; z_idx++; }
+                else if (both) { current_control = controls[c_idx++]; Z = meas.data() + moff[z_idx]; M = sizes[z_idx]; z_idx++; }
+                else current_control = controls[c_idx++];
+            } else {                                                                             // :1231-1237 lock-step
+                Z = meas.data() + moff[n]; M = sizes[n];
+                if (n > 0) {
+                    if ((size_t)(n - 1) >= n_ctrl) { fprintf(stderr, "not enough controls\n"); break; }
+                    current_control = controls[n - 1];
+                }
+            }
+            {   // this step's draws
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return produced > n; });
+            }
+            if (n > 0)                                                                           // no motion at step 0 (:1244)
+                for (int s = 0; s < sub; ++s)
+                    CHK(phd_predict_ackerman(f, current_control, device_noise ? nullptr : ring[n % 3] + (size_t)s * n_part));
+            if (M > 0) CHK(phd_update(f, Z, M));                                                 // :1260-1272
+            CHK(phd_snapshot_capture(f, n & 1));                                                 // the log's contents: before the resample
+            // nEff test and resampling (:1281-1297), decided on the device: nEff <= resample_threshold and the step had a scan
+            if (M > 0) CHK(phd_resample_if_needed(f, uniforms[n], 1, nullptr, nullptr));
+            CHK(phd_snapshot_send(f, n & 1, log7 && M > 0));
+            pend[n].M = M;
+            pend[n].resample_enqueued = M > 0;
+            enqueued = n + 1;
+            bool ok = true;
+            if (n > 0) ok = retire(n - 1);
+            gettimeofday(&t1, nullptr);
+            pend[n].elapsed = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_usec - t0.tv_usec) / 1000.0;
+            if (!ok) break;
+        }
+        if (!failed_nan && enqueued > 0) retire(enqueued - 1);
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        producer.join();
+        phd_sync(f);
+        for (auto& r : ring) phd_host_free(r);
+    }
+    for (int n = 0; n < (pipelined ? 0 : nSteps); ++n) {
         timeval t0, t1;
         gettimeofday(&t0, nullptr);
         if (prof) { tp = now(); for (double& v : step_t) v = 0; }   // a phase this step does not reach reads 0, not the last step's value

@@ -162,6 +162,16 @@ struct phd_filter {
     GmWorkspace* gm = nullptr; // expected-map / gm_reduce workspace, created on first use
     int gm_rounds = 0;
 
+    // pipelined state snapshot (phd_snapshot_capture / _send / _wait): two staging blocks on the device, their pinned mirrors, a
+    // second stream for the downloads
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t snap_ready[2] = {nullptr, nullptr}, snap_done[2] = {nullptr, nullptr};
+    float* snap_dev[2] = {nullptr, nullptr};
+    float* snap_host[2] = {nullptr, nullptr};
+    int snap_state[2] = {0, 0};    // 0 idle, 1 captured, 2 sent
+    int snap_n[2] = {0, 0};
+    bool snap_idx[2] = {false, false};
+
     bool frozen = false;
     uint64_t seed = 0x5EED, counter = 0;
     const phd_pose* pose_for_update = nullptr; // set by a frozen predict
@@ -395,6 +405,13 @@ extern "C" int phd_destroy(phd_filter* f)
     hipFree(f->dbg_surv); hipFree(f->dbg_u); hipFree(f->dbg_n); hipFree(f->dbg_nin); hipFree(f->stamps);
     hipFree(f->spill_rec); hipFree(f->spill_meta); hipFree(f->spill_out); hipFree(f->spill_acc); hipFree(f->spill_tmp);
     gm_workspace_destroy(f->gm);
+    if (f->copy_stream) { hipStreamSynchronize(f->copy_stream); hipStreamDestroy(f->copy_stream); }
+    for (int k = 0; k < 2; ++k) {
+        if (f->snap_ready[k]) hipEventDestroy(f->snap_ready[k]);
+        if (f->snap_done[k]) hipEventDestroy(f->snap_done[k]);
+        hipFree(f->snap_dev[k]);
+        if (f->snap_host[k]) hipHostFree(f->snap_host[k]);
+    }
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     delete f;
     return PHD_OK;
@@ -1132,6 +1149,107 @@ extern "C" int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gau
     *n_map_out = nm;
     if (particle_out) *particle_out = am;
     if (nm > capacity) return fail(PHD_ERR_CAPACITY, "phd_state_snapshot: map larger than the output buffer");
+    return PHD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same snapshot WITHOUT the host synchronisation, for a driver loop that keeps the device busy (include/phdslam.h).
+// run_synth logs between the update and the resample (src/main.cpp:1271-1297): that ORDER of contents is kept — the block is
+// captured on the filter's stream after the update, the report (nEff, the resample decision) is added after the resample launch —
+// but the host no longer waits: a second stream downloads the block while the filter's stream runs the next step.
+// ---------------------------------------------------------------------------------------------
+static size_t snap_words(const phd_filter* f) { return (size_t)PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)8 * f->n_max; }
+
+static int ensure_snapshot(phd_filter* f)
+{
+    if (f->copy_stream) return PHD_OK;
+    HIPCHK(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipEventCreateWithFlags(&f->snap_ready[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&f->snap_done[k], hipEventDisableTiming));
+        HIPCHK(dalloc(&f->snap_dev[k], snap_words(f)));
+        HIPCHK(hipHostMalloc((void**)&f->snap_host[k], snap_words(f) * 4, hipHostMallocDefault));
+    }
+    return PHD_OK;
+}
+
+extern "C" void* phd_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(PHD_ERR_HIP, "phd_host_alloc: hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+
+extern "C" void phd_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int phd_snapshot_capture(phd_filter* f, int slot)
+{
+    CHECK_F(f);
+    if (slot < 0 || slot > 1) return fail(PHD_ERR_INVALID_ARG, "phd_snapshot_capture: slot must be 0 or 1");
+    if (f->snap_state[slot] != 0) return fail(PHD_ERR_INVALID_ARG, "phd_snapshot_capture: the slot holds a snapshot that was not waited for");
+    int rc = ensure_snapshot(f);
+    if (rc) return rc;
+    rc = ensure_concat(f, (size_t)f->cap);
+    if (rc) return rc;
+    // the same two kernels as phd_state_snapshot (so: the same bits), then one pack into the slot's staging block
+    HIPCHK(launch_state(f->pose[f->pose_cur], f->logw, f->n, f->state_pose, f->state_argmax, f->stream));
+    HIPCHK(launch_unpack_one(f->maps[f->cur], f->parent[f->pcur], f->counts[f->cur], f->state_argmax, f->d_concat, f->cap,
+                             f->d_tmp_int, f->stream));
+    HIPCHK(launch_snapshot_pack(f->state_pose, f->state_argmax, f->d_tmp_int, f->d_concat, f->pose[f->pose_cur], f->logw, f->n,
+                                f->n_max, f->cap, f->snap_dev[slot], f->stream));
+    f->snap_state[slot] = 1;
+    f->snap_n[slot] = f->n;
+    return PHD_OK;
+}
+
+extern "C" int phd_snapshot_send(phd_filter* f, int slot, int want_resample_idx)
+{
+    CHECK_F(f);
+    if (slot < 0 || slot > 1 || f->snap_state[slot] != 1) return fail(PHD_ERR_INVALID_ARG, "phd_snapshot_send: no captured snapshot in this slot");
+    // the report as it stands NOW on the filter's stream (after the resample launch: nEff of the pre-resample weights and the
+    // decision), and — for the 7-line log — the parent indices of the resample
+    HIPCHK(hipMemcpyAsync(f->snap_dev[slot] + 16, f->report, 8 * 4, hipMemcpyDeviceToDevice, f->stream));
+    size_t words = (size_t)PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)7 * f->n_max;
+    f->snap_idx[slot] = want_resample_idx != 0;
+    if (want_resample_idx) {
+        HIPCHK(hipMemcpyAsync(f->snap_dev[slot] + words, f->idx, (size_t)f->n * 4, hipMemcpyDeviceToDevice, f->stream));
+        words += (size_t)f->n;
+    }
+    HIPCHK(hipEventRecord(f->snap_ready[slot], f->stream));
+    HIPCHK(hipStreamWaitEvent(f->copy_stream, f->snap_ready[slot], 0));
+    HIPCHK(hipMemcpyAsync(f->snap_host[slot], f->snap_dev[slot], words * 4, hipMemcpyDeviceToHost, f->copy_stream));
+    HIPCHK(hipEventRecord(f->snap_done[slot], f->copy_stream));
+    f->snap_state[slot] = 2;
+    return PHD_OK;
+}
+
+extern "C" int phd_snapshot_wait(phd_filter* f, int slot, phd_snapshot_view* out)
+{
+    CHECK_F(f);
+    if (!out) return fail(PHD_ERR_INVALID_ARG, "phd_snapshot_wait: null output");
+    if (slot < 0 || slot > 1 || f->snap_state[slot] != 2) return fail(PHD_ERR_INVALID_ARG, "phd_snapshot_wait: nothing was sent from this slot");
+    HIPCHK(hipEventSynchronize(f->snap_done[slot]));
+    f->snap_state[slot] = 0;
+    const float* h = f->snap_host[slot];
+    memset(out, 0, sizeof(*out));
+    out->expected = (const phd_pose*)h;
+    out->particle = ((const int32_t*)h)[6];
+    out->n_map = ((const int32_t*)h)[7];
+    out->n_particles = ((const int32_t*)h)[8];
+    out->map = (const phd_gaussian2d*)(h + PHD_SNAP_HEADER_WORDS);
+    out->poses = (const phd_pose*)(h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap);
+    out->log_weights = h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)6 * f->n_max;
+    out->resample_idx = f->snap_idx[slot] ? (const int32_t*)(out->log_weights + f->n_max) : nullptr;
+    unsigned raw[8];
+    memcpy(raw, h + 16, sizeof(raw));
+    int rc = interpret_report(f, raw, &out->report);
+    if (rc) return rc;
+    if (out->report.neff != out->report.neff) return fail(PHD_ERR_NAN, "nan weights detected");   // src/main.cpp:1307-1311
+    if (out->particle < 0) return fail(PHD_ERR_NAN, "no finite particle weight");
+    if (out->n_map > f->cap) return fail(PHD_ERR_CAPACITY, "phd_snapshot_wait: map larger than the map capacity");
     return PHD_OK;
 }
 

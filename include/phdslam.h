@@ -448,6 +448,32 @@ int phd_set_particle_count(phd_filter* f, int n);
 int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gaussian2d* map_out, int capacity, int32_t* n_map_out,
                        int32_t* particle_out, phd_pose* poses_out, float* log_weights_out, phd_step_report* report_out /* optional */);
 
+/* The same snapshot WITHOUT the host synchronisation, for a driver loop that keeps the device busy (replaces the blocking part of
+ * recoverSlamState + the nEff read-back of run_synth, src/main.cpp:1274-1297; the reference logs between the update and the
+ * resample - that ORDER of contents is kept, the host's wait is not).  Two slots:
+ *   phd_snapshot_capture(f, slot)   after the step's update, BEFORE its resample: enqueues the state extraction and one pack of
+ *                                   (expected pose, arg-max particle's map, every pose and log-weight) into the slot's device block;
+ *   phd_snapshot_send(f, slot, idx) after the resample was enqueued: adds the step report (nEff of the pre-resample weights, the
+ *                                   resample decision; idx != 0: the resample's parent indices too) and starts ONE download on a
+ *                                   second stream - the filter's stream is free for the next step;
+ *   phd_snapshot_wait(f, slot, &v)  blocks until that download is complete; v points INTO the slot's pinned block, valid until the
+ *                                   slot is captured again.  Returns what phd_state_snapshot returns (PHD_ERR_NAN, PHD_ERR_CAPACITY ...).
+ * phd_host_alloc / phd_host_free: page-locked host memory, so that phd_predict_ackerman's noise upload is asynchronous too. */
+typedef struct {
+    const phd_pose* expected;
+    const phd_gaussian2d* map;
+    const phd_pose* poses;
+    const float* log_weights;
+    const int32_t* resample_idx;   /* NULL unless asked for in phd_snapshot_send */
+    int32_t n_map, particle, n_particles;
+    phd_step_report report;
+} phd_snapshot_view;
+int phd_snapshot_capture(phd_filter* f, int slot);
+int phd_snapshot_send(phd_filter* f, int slot, int want_resample_idx);
+int phd_snapshot_wait(phd_filter* f, int slot, phd_snapshot_view* out);
+void* phd_host_alloc(size_t bytes);
+void phd_host_free(void* p);
+
 /* ------------------------------------------------------------------------------------
  * Host-side boundary helpers (no device needed): config file, data files, log writer
  * ---------------------------------------------------------------------------------- */

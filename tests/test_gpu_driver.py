@@ -322,3 +322,37 @@ def test_driver_sharded_equals_single_device(tmp_path, extra, common):
         if "resampled=1" in line_a:
             resampled += 1
     assert resampled >= 1 or common      # (the device generator's stream happens not to trigger a resample within these six steps)
+
+
+@pytest.mark.parametrize("extra", [[], ["--log7"], ["--device-noise"]], ids=["log5", "log7", "device_noise"])
+def test_pipelined_loop_writes_the_files_of_the_synchronous_loop(tmp_path, extra):
+    """Round 6: the driver's default loop no longer waits for the device inside a step (noise drawn ahead by a helper thread in the
+    same order from the same stream, state captured on the device between update and resample, resample decided on the device,
+    the log of step n written while step n + 1 runs).  Every state_estimate file must be byte for byte what the step-synchronous
+    loop (PHD_DRIVER_SYNC=1: run_synth's own structure, src/main.cpp:1178-1312) writes — resampled steps included."""
+    d = str(tmp_path)
+    cfg_path = write_dataset(d, n_steps=12, n_particles=300, seed=11)
+    outs = {}
+    for mode in ("pipelined", "sync"):
+        out = os.path.join(d, "out_" + mode); os.makedirs(out)
+        env = dict(os.environ)
+        env.pop("PHD_DRIVER_PROFILE", None)
+        if mode == "sync":
+            env["PHD_DRIVER_SYNC"] = "1"
+        else:
+            env.pop("PHD_DRIVER_SYNC", None)
+        r = subprocess.run([os.path.join(PKG, "bin", "phdslam"), cfg_path, "synth", "--out", out, "--seed", "21", "--capacity", "256"] + extra,
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[mode] = (out, r.stdout)
+    names = sorted(n for n in os.listdir(outs["sync"][0]) if n.startswith("state_estimate"))
+    assert len(names) == 12 and names == sorted(n for n in os.listdir(outs["pipelined"][0]) if n.startswith("state_estimate"))
+    for nm in names:
+        a = open(os.path.join(outs["sync"][0], nm), "rb").read()
+        b = open(os.path.join(outs["pipelined"][0], nm), "rb").read()
+        assert a == b, nm
+    # the per-step lines (M, particle count, map size, resample decision) agree too, and some step resampled
+    strip = lambda t: [ln.rsplit(" ", 2)[0] for ln in t.splitlines() if ln.startswith("****** Time Step")]
+    assert strip(outs["sync"][1]) == strip(outs["pipelined"][1]) and len(strip(outs["sync"][1])) == 12
+    assert any("resampled=1" in ln for ln in strip(outs["pipelined"][1]))
+    assert len(open(os.path.join(outs["pipelined"][0], "loopTime.log")).read().split()) == 12
