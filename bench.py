@@ -501,7 +501,9 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
         "ms_per_step_gpu_p10_p50_p90": pcts,
         "preroll_steps": preroll,
         "value_general": value_general,
-        "config": {"workload_short": ("configs[%d]: %d particles x %d Gaussians x %d meas/step%s, Ackerman, forced resample, one launch/step"
+        "config": {"workload_short": ("diagnostic (--particles): %d particles of configs[%d]'s workload x %d Gaussians x %d meas/step" % (N, cfg_id - 1, G, M))
+                                     if c.get("particles_override") else
+                                     ("configs[%d]: %d particles x %d Gaussians x %d meas/step%s, Ackerman, forced resample, one launch/step"
                                       % (cfg_id - 1, N, G, M, ", CPHD" if cfg_id == 5 else "")) if cfg_id <= 5 else
                                      ("dense scan %d x %d x %d (not a BASELINE config), spill-merge path" % (N, G, M)),
                    "instantiation_general": inst_general,
@@ -947,6 +949,9 @@ def main():
                     help="soft budget of the headline's cpu_baseline leg: bounds the thread scan; the 5 + 2 full timed steps always run (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
     ap.add_argument("--preroll-ms", type=float, default=PREROLL_MS)
+    ap.add_argument("--particles", type=int, default=0,
+                    help="override the particle count of the chosen configuration (a shard's share of configs[3]: 2048 / 4096 / 8192) — a "
+                         "diagnostic workload, labelled in config.workload; not a BASELINE.json configuration")
     ap.add_argument("--bare", action="store_true",
                     help="profiling runs (rocprofv3): headline loop only — no riders, no stamped/unforced/copy passes, no CPU leg")
     args = ap.parse_args()
@@ -957,6 +962,9 @@ def main():
     S = importlib.import_module("cuda-phdslam_amd.synthetic")
     D = importlib.import_module("cuda-phdslam_amd.dist")
 
+    if args.particles > 0:
+        for cid in ([args.config] if args.config else [3, 4]):
+            S.CONFIGS[cid] = dict(S.CONFIGS[cid], N=args.particles, particles_override=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -71,6 +71,13 @@ class StepReport(C.Structure):
                 ("did_resample", C.c_int32)]
 
 
+class SnapshotView(C.Structure):
+    """phd_snapshot_view: pointers into the slot's pinned block (valid until the slot is captured again)"""
+    _fields_ = [("expected", C.c_void_p), ("map", C.c_void_p), ("poses", C.c_void_p), ("log_weights", C.c_void_p),
+                ("resample_idx", C.c_void_p), ("n_map", C.c_int32), ("particle", C.c_int32), ("n_particles", C.c_int32),
+                ("report", StepReport)]
+
+
 class Control(C.Structure):
     _fields_ = [("alpha", C.c_float), ("v_encoder", C.c_float)]
 
@@ -132,6 +139,11 @@ SYMBOLS = {
     "phd_global_resample_launch_normalized": (_i, [_vp, _vp, _d, _vp]),
     "phd_global_resample_plan": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "phd_state_snapshot": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "phd_snapshot_capture": (_i, [_vp, _i]),
+    "phd_snapshot_send": (_i, [_vp, _i, _i]),
+    "phd_snapshot_wait": (_i, [_vp, _i, _vp]),
+    "phd_host_alloc": (_vp, [C.c_size_t]),
+    "phd_host_free": (None, [_vp]),
     "phd_step_report_get": (_i, [_vp, _vp]),
     "phd_set_particle_count": (_i, [_vp, _i]),
     "phd_export_shard_dev": (_i, [_vp, _vp, _vp]),

@@ -325,7 +325,7 @@ int main(int argc, char** argv)
     // decided on the device from the same nEff float, and the log of step n is handed to the writers while step n + 1 runs.
     // Same files, character for character (tests/test_gpu_driver.py compares the two loops); PHD_DRIVER_SYNC=1 runs the loop below.
     const bool pipelined = !config.followTrajectory && kshot == 1 && !config.savePrediction && !(config.mapEstimate & 2) &&
-                           config.filterType != 1 && !prof && getenv("PHD_DRIVER_SYNC") == nullptr;
+                           config.filterType != 1 && getenv("PHD_DRIVER_SYNC") == nullptr;
     if (pipelined) {
         const int n_part = phd_n_particles(f);
         const int sub = config.subdividePredict > 0 ? config.subdividePredict : 1;
@@ -356,13 +356,16 @@ int main(int argc, char** argv)
                 cv.notify_all();
             }
         });
-        struct Pending { int M; bool resample_enqueued; double elapsed; };
+        struct Pending { int M; bool resample_enqueued; double elapsed; int inst; };
         std::vector<Pending> pend((size_t)nSteps > 0 ? nSteps : 1);
         bool failed_nan = false;
+        int last_n_map = 0, last_did = 0;
+        if (prof_file) fprintf(prof_file, "# pipelined: wait_for_draws enqueue_step wait_for_device log_hand_off time_file+print\n");
         // retire step k: wait for its download, hand its log to the writers, print its line
         auto retire = [&](int k) -> bool {
             phd_snapshot_view v;
             const int rc = phd_snapshot_wait(f, k & 1, &v);
+            PROF_MARK(2);                                                                        // waiting for the device (step k's download)
             if (rc == PHD_ERR_NAN) { printf("nan weights detected! exiting...\n"); failed_nan = true; return false; }      // :1307-1311
             if (rc != PHD_OK) die("phd_snapshot_wait");
             const int n_cur = v.n_particles;
@@ -387,9 +390,11 @@ int main(int argc, char** argv)
                 lk.unlock();
                 log_cv.notify_all();
             }
+            PROF_MARK(3);                                                                        // log hand-off
+            last_n_map = v.n_map; last_did = did;
             if (FILE* tf = fopen(timefile.c_str(), "a")) { fprintf(tf, "%g\n", pend[k].elapsed); fclose(tf); }      // :1300-1305
-            printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", k, nSteps, pend[k].M, n_cur, v.n_map, did,
-                   pend[k].elapsed);
+            printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d inst=%d %.3f ms\n", k, nSteps, pend[k].M, n_cur, v.n_map, did,
+                   pend[k].inst, pend[k].elapsed);
             { std::lock_guard<std::mutex> lk(mu); retired = k; }
             cv.notify_all();
             return true;
@@ -418,23 +423,30 @@ int main(int argc, char** argv)
                     current_control = controls[n - 1];
                 }
             }
+            if (prof) { tp = now(); for (double& v : step_t) v = 0; }
             {   // this step's draws
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return produced > n; });
             }
+            PROF_MARK(0);                                                                        // waiting for the helper thread's draws
             if (n > 0)                                                                           // no motion at step 0 (:1244)
                 for (int s = 0; s < sub; ++s)
                     CHK(phd_predict_ackerman(f, current_control, device_noise ? nullptr : ring[n % 3] + (size_t)s * n_part));
             if (M > 0) CHK(phd_update(f, Z, M));                                                 // :1260-1272
+            pend[n].inst = M > 0 ? phd_debug_update_instantiation(f) : -1;
             CHK(phd_snapshot_capture(f, n & 1));                                                 // the log's contents: before the resample
             // nEff test and resampling (:1281-1297), decided on the device: nEff <= resample_threshold and the step had a scan
             if (M > 0) CHK(phd_resample_if_needed(f, uniforms[n], 1, nullptr, nullptr));
             CHK(phd_snapshot_send(f, n & 1, log7 && M > 0));
+            PROF_MARK(1);                                                                        // enqueueing the whole step
             pend[n].M = M;
             pend[n].resample_enqueued = M > 0;
             enqueued = n + 1;
             bool ok = true;
             if (n > 0) ok = retire(n - 1);
+            PROF_MARK(4);                                                                        // (retire() marks 2 and 3 inside)
+            if (prof_file && n > 0) fprintf(prof_file, "%d %d %d %d %.4f %.4f %.4f %.4f %.4f\n", n, M, last_n_map, last_did, step_t[0], step_t[1],
+                                            step_t[2], step_t[3], step_t[4]);
             gettimeofday(&t1, nullptr);
             pend[n].elapsed = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_usec - t0.tv_usec) / 1000.0;
             if (!ok) break;
@@ -600,12 +612,18 @@ int main(int argc, char** argv)
         gettimeofday(&t1, nullptr);
         double elapsed = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_usec - t0.tv_usec) / 1000.0;
         if (FILE* tf = fopen(timefile.c_str(), "a")) { fprintf(tf, "%g\n", elapsed); fclose(tf); } // :1300-1305
-        printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d %.3f ms\n", n, nSteps, M, n_cur, n_map, did, elapsed);
+        // (inst: which instantiation of the update kernel the step's scan ran, csrc/phd_kernels.hip; -1: no scan this step)
+        printf("****** Time Step [%d/%d] ****** M=%d particles=%d map=%d resampled=%d inst=%d %.3f ms\n", n, nSteps, M, n_cur, n_map, did,
+               M > 0 ? phd_debug_update_instantiation(f) : -1, elapsed);
         if (prof_file) fprintf(prof_file, "%d %d %d %d %.4f %.4f %.4f %.4f %.4f\n", n, M, n_map, (int)did, step_t[0], step_t[1], step_t[2],
                                step_t[3], step_t[4]);
     }
     if (prof_file) fclose(prof_file);
-    if (prof && nSteps > 0)
+    if (prof && nSteps > 0 && pipelined)
+        printf("loop profile, pipelined loop (host ms per step): waiting for the helper thread's draws %.3f, enqueueing the step %.3f, waiting for the device "
+               "(the previous step's download) %.3f, log hand-off %.3f, time file + progress line %.3f\n",
+               acc_t[0] / nSteps, acc_t[1] / nSteps, acc_t[2] / nSteps, acc_t[3] / nSteps, acc_t[4] / nSteps);
+    else if (prof && nSteps > 0)
         printf("loop profile (ms per step): inputs+predict %.3f, update %.3f, state extraction %.3f, resample %.3f, log writing %.3f\n",
                acc_t[0] / nSteps, acc_t[1] / nSteps, acc_t[2] / nSteps, acc_t[3] / nSteps, acc_t[4] / nSteps);
     finish_logs();

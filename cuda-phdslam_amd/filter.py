@@ -182,6 +182,27 @@ class PhdFilter:
         self.last_report = rep
         return e[0], out[:n.value].copy(), who.value, poses, lw
 
+    # the same snapshot without the host synchronisation (include/phdslam.h: phd_snapshot_capture / _send / _wait)
+    def snapshot_capture(self, slot):
+        check(lib().phd_snapshot_capture(self._h, int(slot)), "phd_snapshot_capture")
+
+    def snapshot_send(self, slot, want_resample_idx=False):
+        check(lib().phd_snapshot_send(self._h, int(slot), 1 if want_resample_idx else 0), "phd_snapshot_send")
+
+    def snapshot_wait(self, slot):
+        """-> (expected pose, arg-max particle's map, its index, poses, log-weights, resample indices or None, report): copies
+        of the slot's pinned block"""
+        v = L.SnapshotView()
+        check(lib().phd_snapshot_wait(self._h, int(slot), C.byref(v)), "phd_snapshot_wait")
+        n = v.n_particles
+
+        def arr(addr, dtype, count):
+            return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype, count=count).copy()
+        idx = arr(v.resample_idx, np.int32, n) if v.resample_idx else None
+        self.last_report = v.report
+        return (arr(v.expected, POSE, 1)[0], arr(v.map, GAUSSIAN, v.n_map), v.particle, arr(v.poses, POSE, n),
+                arr(v.log_weights, np.float32, n), idx, v.report)
+
     def step_report(self):
         """status word, high-water marks, nEff and resample decision of the last weights routine: one download"""
         rep = L.StepReport()

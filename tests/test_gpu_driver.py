@@ -356,3 +356,40 @@ def test_pipelined_loop_writes_the_files_of_the_synchronous_loop(tmp_path, extra
     assert strip(outs["sync"][1]) == strip(outs["pipelined"][1]) and len(strip(outs["sync"][1])) == 12
     assert any("resampled=1" in ln for ln in strip(outs["pipelined"][1]))
     assert len(open(os.path.join(outs["pipelined"][0], "loopTime.log")).read().split()) == 12
+
+
+def test_snapshot_slots_equal_the_blocking_snapshot():
+    """phd_snapshot_capture / _send / _wait (the pipelined loop's state extraction) against phd_state_snapshot on the same filter:
+    the captured block holds the state BETWEEN the update and the resample although it is read after the resample and after the
+    next step was enqueued; report and resample indices ride along."""
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    N, G, M = 600, 24, 10
+    w = S.make_workload(N, G, M, seed=77, n_meas_sets=3, clustered=True)
+    cfg = P.default_config(n_particles=N, resampleThresh=2.0)           # nEff / N <= 2: every step with a scan resamples
+    ref = []
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=128, max_measurements=M) as f:
+        f.set_particles(w["poses"], w["logw"]); f.set_maps(w["maps"], w["sizes"])
+        for s in range(3):
+            f.predict((2.0, 0.05), w["noise"][s]); f.update(w["z"][s])
+            ref.append(f.state_snapshot())
+            did, idx = f.resample_if_needed(w["uniform"][s], had_measurements=True)
+            assert did
+            ref[-1] = ref[-1] + (idx,)
+    with P.PhdFilter(cfg, n_particles=N, map_capacity=128, max_measurements=M) as f:
+        f.set_particles(w["poses"], w["logw"]); f.set_maps(w["maps"], w["sizes"])
+        got = []
+        for s in range(3):
+            f.predict((2.0, 0.05), w["noise"][s]); f.update(w["z"][s])
+            f.snapshot_capture(s & 1)
+            P._lib.check(P._lib.lib().phd_resample_if_needed(f._h, float(w["uniform"][s]), 1, None, None), "phd_resample_if_needed")
+            f.snapshot_send(s & 1, want_resample_idx=True)
+            if s > 0:
+                got.append(f.snapshot_wait((s - 1) & 1))                # read one step late, as the driver does
+        got.append(f.snapshot_wait(2 & 1))
+    for s in range(3):
+        e, m, who, poses, lw, idx = ref[s]
+        e2, m2, who2, poses2, lw2, idx2, rep = got[s]
+        assert e.tobytes() == e2.tobytes() and who == who2 and m.tobytes() == m2.tobytes(), s
+        assert poses.tobytes() == poses2.tobytes() and lw.tobytes() == lw2.tobytes(), s
+        assert rep.did_resample == 1 and np.array_equal(idx, idx2) and rep.neff > 0, s

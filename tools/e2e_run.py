@@ -25,7 +25,7 @@ def main():
     from e2e_utils import load
     P = importlib.import_module("cuda-phdslam_amd")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    d = sys.argv[2] if len(sys.argv) > 2 else tempfile.mkdtemp(prefix="phd_e2e_")
+    d = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] not in ("", "-") else tempfile.mkdtemp(prefix="phd_e2e_")
     os.makedirs(d, exist_ok=True)
     data = load()
     with open(os.path.join(d, "measurements.txt"), "w") as f:
@@ -59,10 +59,22 @@ def main():
         if line.startswith("loop profile"):               # PHD_DRIVER_PROFILE=1
             print(line)
     t = np.loadtxt(os.path.join(out, "loopTime.log"))
+    # which instantiation of the update kernel the bundled scans ran (csrc/phd_kernels.hip: below 18 the layout and the scan's length
+    # come from the arguments; from 18 they are compiled in — only a scan as long as the filter's measurement capacity gets there)
+    inst = [int(m.group(1)) for m in re.finditer(r"inst=(-?\d+)", r.stdout)]
+    ms = [int(m.group(1)) for m in re.finditer(r" M=(\d+) ", r.stdout)]
+    if inst:
+        hist = {k: inst.count(k) for k in sorted(set(inst))}
+        print("update-kernel instantiation over the %d steps: %s (fast path = index >= 18: %d steps); measurements per step min %d, median %d, max %d"
+              % (len(inst), hist, sum(v for k, v in hist.items() if k >= 18), min(ms), int(np.median(ms)), max(ms)))
     pf = os.path.join(out, "loopProfile.log")
     if os.path.exists(pf):                                    # PHD_DRIVER_PROFILE=1: which phase do the slow steps spend their time in?
         q = np.loadtxt(pf)
         names = ["inputs+predict", "update (synchronised for the profile)", "state extraction", "resample", "log hand-off"]
+        first = open(pf).readline()
+        if first.startswith("# pipelined"):               # the pipelined loop: what the HOST does per iteration
+            names = ["wait for the helper thread's draws", "enqueue the step (7 calls)", "wait for the device (previous step)", "log hand-off",
+                     "time file + progress line"]
         ph = q[:, 4:9]
         tot = ph.sum(1)
         slow = tot >= np.percentile(tot, 90)
