@@ -507,6 +507,36 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
     LDS_T(v4f)* const sG = sP + 72;
     LDS_T(float)* const sPf = (LDS_T(float)*)sP;
     LDS_T(float)* const sQf = (LDS_T(float)*)sQ;
+#ifdef PHD_PRICE_WAVE_PASS
+    // PRICING EXPERIMENT (round 6; tools/ab_bench.sh): what ONE pass of a wave-local sequential greedy costs
+    // inside this kernel, at its residency, beside its other workgroups — the seed is the first unmerged lane of the wave's
+    // 64-survivor block (the block is in weight order), its record reaches the scalar registers through v_readlane, every
+    // unmerged lane takes the exact decision against it, a ballot retires the members, the members store an assignment word.
+    // The block stays in REGISTERS (the cheapest form: a component of more than 64 members would re-read LDS every pass), no
+    // barrier, no LDS read inside a pass.  PHD_PRICE_WAVE_PASS passes per wave; the stores land in assignment words that the
+    // rounds below overwrite, so the results are unchanged.
+    {
+        const int pi = wave * 64 + lane;
+        const bool pvalid = pi < S;
+        const v4f pa = gA[pvalid ? pi : 0], pb = gB[pvalid ? pi : 0];
+        const u64 all = __ballot(pvalid);
+        u64 unmerged = all;
+        int pcnt = 0;
+        if (all)
+        for (int k = 0; k < PHD_PRICE_WAVE_PASS; ++k) {
+            if (!unmerged) unmerged = all;                       // (re-armed: every pass does the work of a live component)
+            const int sd = __builtin_ctzll(unmerged);
+            const float smx = lane_f(pa.x, sd), smy = lane_f(pa.y, sd), sxx = lane_f(pb.x, sd), sxy = lane_f(pb.y, sd), syy = lane_f(pb.z, sd);
+            const bool mine = (unmerged >> lane) & 1ull;
+            const bool cl = mine && is_close<HELLINGER>(smx, smy, sxx, sxy, syy, pa.x, pa.y, pb.x, pb.y, pb.z, T);
+            const u64 mm = __ballot(cl) | (1ull << sd);
+            if (cl) asg[4 * pi + 3] = pcnt | ((wave * 64 + sd) << 16);
+            unmerged &= ~mm;
+            ++pcnt;
+            asm volatile("" ::: "memory");
+        }
+    }
+#endif
     for (int i = tid; i < S; i += PHD_T) ul_a[i] = (u16)i;
     int n_u = S;
     int kbase = 0;                                             // seeds of the rounds so far = clusters opened
