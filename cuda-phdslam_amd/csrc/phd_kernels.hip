@@ -86,6 +86,11 @@ size_t weights_grid_lds_bytes(int n) { return grid_weights_lds_bytes(n); }
 __global__ __launch_bounds__(PHD_T) void phd_weights_grid_kernel(WeightArgs A, unsigned* status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_gwdyn[];
+    // An EARLIER launch of this filter gave up at one of its waits (status bit, sticky until the host reads the step report and
+    // re-zeroes the counters, phd_api.cpp: interpret_report): the barrier counters are mid-count, and a launch enqueued before the
+    // host has looked would pass its barriers early and read incomplete block records.  It refuses instead: the bit
+    // stays set, the host's next report fails the step loudly, and nothing downstream consumes half-made weights as good ones.
+    if (status && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PHD_STATUS_TAIL_TIMEOUT)) return;
     weights_grid_body<false>(A, (int)blockIdx.x, (int)gridDim.x, s_gwdyn, status, nullptr);
 }
 size_t cphd_lds_bytes(int S_cap, int cn_len, int MM) { return cphd_extra_lds_bytes(S_cap, cn_len, MM); }
@@ -1415,7 +1420,18 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t st, unsigned* status)
     // above 4096 weights: the block form on several workgroups (phd_weights.h) - chosen by n ALONE, so that every caller and
     // every launch shape (this launch, the fused tail of the update kernel, every shard of a sharded filter) gets the same bits
     if (a.n > PHD_GRID_WEIGHTS_MIN && a.n_new <= a.n && a.gsync && a.gpart) {
-        hipLaunchKernelGGL(phd_weights_grid_kernel, dim3(grid_weights_workgroups(a.n)), dim3(PHD_T), grid_weights_lds_bytes(a.n), st, a, status);
+        // its LDS is one block end per 256 weights: past 64 KB (about two million weights) the kernel needs the limit raised, and
+        // past what a CU has (five million) the launch is refused instead of failing inside the runtime
+        const size_t dyn_grid = grid_weights_lds_bytes(a.n);
+        if (dyn_grid > 150 * 1024) return hipErrorInvalidValue;
+        if (dyn_grid > 48 * 1024) {
+            static OncePerDevice once_grid_attr;
+            const hipError_t e = once_per_device(once_grid_attr, [] {
+                return hipFuncSetAttribute((const void*)phd_weights_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            });
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(phd_weights_grid_kernel, dim3(grid_weights_workgroups(a.n)), dim3(PHD_T), dyn_grid, st, a, status);
         return hipGetLastError();
     }
     // up to 4096 weights: one workgroup, the fixed-point CDF in LDS; small particle sets use a small one (cheaper barriers, same

@@ -185,6 +185,35 @@ int main() {
         assert w >= 48 * 256 and t < 160 * 1024, line            # merge_small's 256 clusters always fit
 
 
+# spill moves (v_readlane / v_writelane of a parked scalar) at loop depth >= 2, per instantiation, as observed with the compiler named
+# in PINNED_WITH when the pins were recorded (`python tests/test_kernel_resources.py` prints both)
+PINNED_WITH = "HIP version: 7.2.26015-fc0010cf6a, AMD clang version 22.0.0git (roc-7.2.0)"
+RECORDED_DEEP = {'ILb0ELb0ELb0ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb0ELb1ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb1ELb0ELi4ELb0ELi0E': 0,
+                 'ILb0ELb0ELb0ELb1ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb0ELb1ELi4ELb0ELi0E': 3, 'ILb0ELb0ELb1ELb1ELi4ELb0ELi0E': 5, 'ILb0ELb1ELb1ELb1ELi4ELb0ELi0E': 31,
+                 'ILb0ELb1ELb0ELb0ELi4ELb1ELi0E': 0, 'ILb0ELb0ELb0ELb0ELi4ELb0ELi2E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi2E': 0}
+OBSERVED_DEEP = {}
+
+
+def hipcc_version():
+    cc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    if not cc:
+        return "hipcc not available"
+    t = subprocess.run([cc, "--version"], capture_output=True, text=True, timeout=120).stdout
+    hv = re.search(r"HIP version: (\S+)", t)
+    cv = re.search(r"clang version (\S+) .*?(roc-[\d.]+)", t)
+    return "HIP version: %s, AMD clang version %s (%s)" % (hv.group(1) if hv else "?", cv.group(1) if cv else "?", cv.group(2) if cv else "?")
+
+
+def test_pins_name_the_compiler_they_were_recorded_with(capsys):
+    """the static pins of this file (instruction counts, spill counts) are properties of ONE compiler: the test prints the
+    compiler in use beside the one the pins were recorded with, so a toolchain re-roll is visible in the test log (VERDICT r5
+    item 7; the GPU box's HIP runtime version is in the bench line, `hip_runtime_version`)"""
+    now = hipcc_version()
+    with capsys.disabled():
+        print("\n[kernel resources] pins recorded with: %s | compiling with: %s%s" % (PINNED_WITH, now, "" if now == PINNED_WITH else "  <-- DIFFERENT COMPILER: re-record the pins"))
+    assert now != "hipcc not available" or True
+
+
 def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
     """The update kernel keeps ~100 scalar values alive across its phases (35 LDS pointers, 30 kernel-argument pointers,
     the configuration), more than the 102 SGPRs of a wave: the compiler parks the excess in lanes of a spare VGPR
@@ -243,6 +272,11 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
         # in the 1 332 instructions of the octet loop, round 5).  No spill STORE inside an inner loop, and the reloads at
         # most 1 % of the loop they sit in.)
         with_spill_list = "ELb1ELi" in tag[12:21]          # the SPILL flag is the fourth
+        OBSERVED_DEEP[tag] = deep
+        # the count observed when the pins were recorded (+ 2: allocator noise) — the global ceilings below admit a move of a few
+        # dozen scalars, which once cost 3.3 % at configs[4]: the next register-cliff move fails HERE, per instantiation
+        if tag in RECORDED_DEEP:
+            assert deep <= RECORDED_DEEP[tag] + 2, "spill moves at loop depth >= 2 of %s: %d, recorded %d (%s)" % (tag, deep, RECORDED_DEEP[tag], by_depth)
         if with_spill_list:
             assert deep <= 40, (tag, by_depth)
             for name, (loads, stores, instrs) in per_loop2.items():
@@ -369,3 +403,9 @@ if __name__ == "__main__":                                            # re-recor
     print("RECORDED =", static_profile(*_c[1:]))
     print("RECORDED_GENERAL =", static_profile(_c[1], _c[2], HEADLINE_GENERAL))
     print("RECORDED_CPHD =", cphd_profile(_c[0], _c[1]))
+    try:
+        test_sgpr_spills_stay_out_of_the_inner_loops(_c)
+    except AssertionError as e:                                       # (a moved pin: print the new observations anyway)
+        print("spill guard failed:", e)
+    print("PINNED_WITH = %r" % hipcc_version())
+    print("RECORDED_DEEP =", OBSERVED_DEEP)
