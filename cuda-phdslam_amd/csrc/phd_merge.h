@@ -455,6 +455,178 @@ __device__ __forceinline__ void merge_small(const Lds& L, int S_cap, int S, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// merge_tail: ONE-SHOT finish of the rounds (round 6).
+//
+// The rounds resolve 64 candidate seeds at a time, four barriers each, and their LAST rounds are nearly empty: at
+// 4096 x 256 x 64 the list of unmerged survivors reads ~880, ~300, ~150, ~55, (~5) at the start of the 4.25 rounds
+// (tools/round_tail.py), so rounds 3, 4 and 5 pay their fixed cost — window matrix, seed resolution by one wave, seed records,
+// ordered compaction, four barriers — for one or two busy waves.  Once at most PHD_TAIL_N survivors are listed the rest of the
+// greedy merge is finished in one shot with merge_small's structure on the listed survivors (in list order = weight order):
+//   rows     row_k = {l < k : close(k, l)} for ALL pairs of listed survivors: far-pair filter in sign-bit form (the rounds' own:
+//            E_k + E_l - 2 m_k.m_l < 0, gA.z) — lane = position k of a 64-row block, a unit = 16 columns whose terms reach the
+//            scalar registers through v_readlane — then the exact decision on the listed pairs, one pair per thread;
+//   seeds    s_k = not exists l < k : close(k, l) and s_l, by one wave, 64 positions at a time (earlier blocks are final);
+//   members  every position joins the first seed of its row; cluster index = kbase + seeds before its owner.
+// Exactly the decisions the rounds would take (the same greedy, the same exact test), five barriers instead of ~2.3 rounds x 4.
+// LDS: the bytes behind the two round lists up to the end of the update's small arrays are dead by now (window, seed records,
+// matrix parts, measurement arrays): rows [N][4] u64 | tA, tB [N] float4 (the listed survivors' records by position) | seed
+// masks | candidate pairs.  tail_cap = the N this filter's layout has room for (0: never).
+// ------------------------------------------------------------------------------------------
+#ifndef PHD_TAIL_N
+#define PHD_TAIL_N 192
+#endif
+// rows [N][N / 64] u64 | tA, tB [N] float4 | seed masks | eight wave-private pair lists of 64 entries
+__host__ __device__ constexpr int merge_tail_bytes(int N) { return N * (N / 64) * 8 + 2 * N * 16 + 64 + PHD_NW * 64 * 4; }
+
+template <bool HELLINGER, bool STAMPS>
+__device__ __forceinline__ int merge_tail(const Lds& L, lds_u16 cur, int n, int cap_n, int kbase, float T, int tid)
+{
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = cap_n >> 6;                                          // 64-bit words per row (3 or 2)
+    LDS_T(u64)* const rows = (LDS_T(u64)*)L.rwin;                       // [cap_n][rw]: row_k = {l < k : close(k, l)}
+    LDS_T(u32)* const rows32 = (LDS_T(u32)*)rows;
+    LDS_T(v4f)* const tA = (LDS_T(v4f)*)(rows + rw * cap_n);            // [cap_n] (mean x, mean y, E, weight)
+    LDS_T(v4f)* const tB = tA + cap_n;                                  // [cap_n] (cov xx, xy, yy, -)
+    LDS_T(u64)* const sseed = (LDS_T(u64)*)(tB + cap_n);                // [4] (+ 4 spare)
+    lds_u32 wlist = (lds_u32)(sseed + 8) + wave * 64;                   // this wave's waiting pairs (k << 16 | l)
+    LDS_T(v4f)* const gA = L.gA;
+    LDS_T(v4f)* const gB = L.gB;
+    // ---- stage the listed survivors by position, clear the rows
+    for (int k = tid; k < n; k += PHD_T) {
+        const int i = cur[k];
+        tA[k] = gA[i];
+        tB[k] = gB[i];
+    }
+    for (int t = tid; t < n * rw; t += PHD_T) rows[t] = 0ull;
+    __syncthreads();
+    // ---- closeness rows: units of 64 positions x 16 columns, only units with a column below the block's last row.
+    //      The filter marks candidate pairs; the wave collects its units' marked pairs in a wave-private list (in order, no
+    //      barrier) and takes the exact decisions ONE PAIR PER LANE when the next unit's pairs would not fit (and at the
+    //      end): a pair that is close sets its bit in the cleared row with an LDS atomic OR (a word's bits come from several waves).
+    const int nb = (n + 63) >> 6, ncu = (n + 15) >> 4;
+    int n_units = 0;
+    for (int b = 0; b < nb; ++b) n_units += (4 * b + 4 < ncu) ? 4 * b + 4 : ncu;
+    int waiting = 0;                                                 // (uniform)
+    for (int u0 = wave; u0 < n_units; u0 += PHD_NW) {
+        int b = 0, cu = u0;
+        for (;;) { const int c = (4 * b + 4 < ncu) ? 4 * b + 4 : ncu; if (cu < c) break; cu -= c; ++b; }
+        const int lbase = 16 * cu;
+        const int k = 64 * b + lane;
+        const bool kvalid = k < n;
+        const v4f ka = tA[kvalid ? k : n - 1];
+        const v4f ca = tA[(lbase + (lane & 15)) < n ? lbase + (lane & 15) : n - 1];   // lane j < 16: column lbase + j
+        const float cE = ca.z, c2x = -2.f * ca.x, c2y = -2.f * ca.y;
+        const v2f kE2 = (v2f){ka.z, ka.z}, kx2 = (v2f){ka.x, ka.x}, ky2 = (v2f){ka.y, ka.y};
+        u32 cand = 0;
+#pragma unroll
+        for (int c = 14; c >= 0; c -= 2) {                       // descending: v_alignbit shifts the mask left
+            v2f t = (v2f){lane_f(cE, c), lane_f(cE, c + 1)} + kE2;
+            t = __builtin_elementwise_fma((v2f){lane_f(c2x, c), lane_f(c2x, c + 1)}, kx2, t);
+            t = __builtin_elementwise_fma((v2f){lane_f(c2y, c), lane_f(c2y, c + 1)}, ky2, t);
+            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(t.y), 31);
+            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(t.x), 31);
+        }
+        // only earlier positions count (l < k), and only rows of listed survivors
+        const int nlt = k - lbase;
+        cand &= (!kvalid || nlt <= 0) ? 0u : (nlt >= 16 ? 0xFFFFu : ((1u << nlt) - 1u));
+        if (__ballot(cand != 0u) == 0ull) continue;              // uniform
+        const int np = __popc(cand);
+        const int incl = (int)wave_incl_scan((u32)np);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (waiting + tot > 64 && waiting) {                     // uniform: decide what is waiting first
+            if (lane < waiting) {
+                const u32 pr = wlist[lane];
+                const int pk = (int)(pr >> 16), pl = (int)(pr & 0xFFFFu);
+                const v4f qa = tA[pk], qb = tB[pk], la = tA[pl], lb = tB[pl];
+                if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, qa.x, qa.y, qb.x, qb.y, qb.z, T))
+                    __hip_atomic_fetch_or(rows32 + pk * 2 * rw + (pl >> 5), 1u << (pl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            waiting = 0;
+        }
+        if (tot <= 64) {
+            int pos = waiting + incl - np;
+            while (cand) {
+                const int j = __builtin_ctz(cand);
+                cand &= cand - 1;
+                wlist[pos++] = ((u32)k << 16) | (u32)(lbase + j);
+            }
+            waiting += tot;
+        } else {
+            // more than 64 marked pairs in one unit (the Hellinger metric has no cheap filter): per lane on its marked columns
+            u32 bits = 0;
+            if (cand) {
+                const v4f kb = tB[k];
+                while (cand) {
+                    const int j = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    const v4f la = tA[lbase + j], lb = tB[lbase + j];
+                    if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, ka.x, ka.y, kb.x, kb.y, kb.z, T)) bits |= 1u << j;
+                }
+                if (bits) __hip_atomic_fetch_or(rows32 + k * 2 * rw + (lbase >> 5), bits << (lbase & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    if (waiting) {
+        if (lane < waiting) {
+            const u32 pr = wlist[lane];
+            const int pk = (int)(pr >> 16), pl = (int)(pr & 0xFFFFu);
+            const v4f qa = tA[pk], qb = tB[pk], la = tA[pl], lb = tB[pl];
+            if (is_close<HELLINGER>(la.x, la.y, lb.x, lb.y, lb.z, qa.x, qa.y, qb.x, qb.y, qb.z, T))
+                __hip_atomic_fetch_or(rows32 + pk * 2 * rw + (pl >> 5), 1u << (pl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    // ---- seeds: one wave, block by block (merge_small's resolution): earlier blocks are final, inside a block the ballot fixed point
+    if (wave == 0) {
+        u64 sd[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b < nb) {
+                const int k = 64 * b + lane;
+                const bool kvalid = k < n;
+                const int kk = kvalid ? k : n - 1;
+                const u64 r0 = rows[kk * rw + 0], r1 = (b >= 1) ? rows[kk * rw + 1] : 0ull, r2 = (b >= 2) ? rows[kk * rw + 2] : 0ull;
+                bool blocked = false;
+                if (b > 0) blocked = blocked || ((r0 & sd[0]) != 0ull);
+                if (b > 1) blocked = blocked || ((r1 & sd[1]) != 0ull);
+                const u64 row = (b == 0) ? r0 : (b == 1) ? r1 : r2;   // within the block
+                const u64 live = __ballot(kvalid && !blocked);
+                u64 seeds = live;
+                for (int it = 0; it < 65; ++it) {
+                    const u64 blk = __ballot((row & seeds) != 0ull);
+                    const u64 nx = live & ~blk;
+                    if (nx == seeds) break;
+                    seeds = nx;
+                }
+                sd[b] = seeds;
+            }
+        }
+        if (lane < 3) sseed[lane] = (lane == 0) ? sd[0] : (lane == 1) ? sd[1] : sd[2];
+    }
+    __syncthreads();
+    // ---- membership: every position joins the first seed of its row (a seed joins itself); the assignment word of the
+    //      survivor: cluster index (seeds of the rounds + seeds before its owner) | its seed's survivor index
+    const u64 s0 = sseed[0], s1 = sseed[1], s2 = sseed[2];
+    if (tid < n) {
+        const int k = tid, kbk = k >> 6;              // (words beyond the position's own block are zero: cleared, never set)
+        const u64 sw = (kbk == 0) ? s0 : (kbk == 1) ? s1 : s2;
+        int o = k;
+        if (!((sw >> (k & 63)) & 1ull)) {
+            const u64 m0 = rows[k * rw + 0] & s0, m1 = (kbk >= 1) ? (rows[k * rw + 1] & s1) : 0ull, m2 = (kbk >= 2) ? (rows[k * rw + 2] & s2) : 0ull;
+            o = m0 ? __builtin_ctzll(m0) : m1 ? 64 + __builtin_ctzll(m1) : 128 + __builtin_ctzll(m2);
+        }
+        const u64 below = (o & 63) ? (~0ull >> (64 - (o & 63))) : 0ull;
+        int c = 0;                                    // seeds before the owner
+        c += (o >= 64) ? __popcll(s0) : __popcll(s0 & below);
+        if (o >= 64) c += (o >= 128) ? __popcll(s1) : __popcll(s1 & below);
+        if (o >= 128) c += __popcll(s2 & below);
+        ((LDS_T(int)*)gB)[4 * cur[k] + 3] = (kbase + c) | ((int)cur[o] << 16);
+    }
+    __syncthreads();                                  // the moment sums' accumulators overwrite the lists and these arrays
+    return __popcll(s0) + __popcll(s1) + __popcll(s2);
+}
+
+// ------------------------------------------------------------------------------------------
 // the greedy merge on the survivors held in LDS; writes the merged map to the output slab.
 // Returns (in ctr[CTR_KOUT]) the number of merged Gaussians.
 // ------------------------------------------------------------------------------------------
@@ -552,7 +724,24 @@ __device__ __forceinline__ void merge_in_lds(const Lds& L, int S_cap, int n_surv
         wB[tid] = gB[i];
     }
     __syncthreads();
+    // the one-shot finish (merge_tail above): what this filter's layout has room for behind the round lists
+    int tail_cap = 0;
+#ifndef PHD_NO_TAIL
+    {
+        static_assert(PHD_TAIL_N == 192 || PHD_TAIL_N == 128, "merge_tail holds rows of two or three 64-bit words");
+        const int room = (int)((LDS_T(unsigned char)*)L.out_idx - (LDS_T(unsigned char)*)L.rwin);
+        tail_cap = room >= merge_tail_bytes(PHD_TAIL_N) ? PHD_TAIL_N : room >= merge_tail_bytes(128) ? 128 : 0;
+    }
+#endif
     while (n_u > 0) {
+        if (n_u <= tail_cap && n_u > 64) {                      // (uniform; a list of at most 64 is one more window round: cheaper)
+            u64 tt0 = 0;
+            if (STAMPS && tid == 0) tt0 = __builtin_amdgcn_s_memrealtime();
+            kbase += merge_tail<HELLINGER, STAMPS>(L, cur, n_u, tail_cap, kbase, T, tid);
+            if (STAMPS && tid == 0) st[31] += __builtin_amdgcn_s_memrealtime() - tt0;
+            n_u = 0;
+            break;
+        }
         u64 tq0 = 0, tq1 = 0, tq2 = 0;
         if (STAMPS && tid == 0) tq0 = __builtin_amdgcn_s_memrealtime();
         const int nwin = n_u < 64 ? n_u : 64;

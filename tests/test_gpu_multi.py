@@ -133,14 +133,21 @@ def test_bench_gpus_2_unlaunched_runs_the_cpp_host():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PHD_BENCH_SHARE_GPU="1")
+    import tempfile
+    rec = os.path.join(tempfile.mkdtemp(prefix="phd_bench_"), "bench_last.json")
+    env = dict(os.environ, PHD_BENCH_SHARE_GPU="1", PHD_BENCH_RECORD=rec)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--preroll-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "steps/s"
+    # the last stdout line is the compact record (round 6); the riders, phases and the first-contact verdict are in the record file
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) <= 4096 and line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["unit"] == "steps/s"
+    assert line["config"]["n_shards"] == 2 and line["config"]["N"] == 16384 and len(line["riders_steps_per_s"]) == 1
+    d = json.load(open(rec))
+    assert d["value"] == pytest.approx(line["value"], rel=1e-5)
     c = d["config"]
     assert c["cpp_multi_host"] and c["n_shards"] == 2 and c["particles_total"] == 16384 and c["share_gpu_dry_run"]
     # the first-contact check: before timing, the sharded filter equalled a single filter bit for bit on these devices

@@ -214,10 +214,16 @@ def test_bench_gpus_k_unlaunched(k):
         env.pop(v, None)
     if SHARE and NDEV < k:
         env["PHD_BENCH_SHARE_GPU"] = "1"
+    import tempfile
+    rec = os.path.join(tempfile.mkdtemp(prefix="phd_bench_"), "bench_last.json")
+    env["PHD_BENCH_RECORD"] = rec
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(k), "--steps", "5", "--warmup", "2"], env=env,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)                                   # the compact record; the full one is in the record file
+    assert len(last) <= 4096 and line["n_gpus"] == k and line["value"] > 0 and line["config"]["n_shards"] == k
+    d = json.load(open(rec))
     c = d["config"]
     assert d["n_gpus"] == k and d["value"] > 0 and c["cpp_multi_host"]
     assert (c["rccl_ranks"] == k and not c.get("share_gpu_dry_run")) or SHARE

@@ -183,6 +183,28 @@ def test_update_clustered_merge_stress():
     assert st["max_survivors"] > 400
 
 
+@pytest.mark.parametrize("G,M,cap,mm,metric,sep,clustered", [
+    (256, 64, 512, 64, 0, None, True),      # the headline layout: the one-shot finish takes over at <= 192 listed survivors
+    (200, 30, 400, 32, 0, None, True),      # 1024 survivor slots but 32 measurements: room for the 128-survivor form only
+    (300, 64, 1024, 64, 0, None, True),     # 2048 survivor slots
+    (300, 40, 640, 64, 0, 3.0, False),      # a small merge distance: many clusters, little merging — the finish lists most survivors' pairs as far
+    (160, 12, 320, 64, 1, 0.6, True),       # Hellinger: no cheap filter — every pair of a unit is a candidate (> 64 per unit: the per-lane exact loop)
+])
+def test_merge_one_shot_finish_paths(G, M, cap, mm, metric, sep, clustered):
+    """Round 6: once at most 192 (or 128: layouts with less room behind the round lists) unmerged survivors are listed, the rounds'
+    remaining work is finished in one shot (csrc/phd_merge.h: merge_tail — all-pairs rows, exact decisions from wave-private
+    pair lists, seeds block by block, membership).  The same greedy, so the merge stage must stay bit for bit `o_merge` of the
+    device's survivors — on every layout that picks another form of it, with both metrics."""
+    P, S = pkg(), synthetic()
+    w = S.make_workload(4, G, M, seed=0x7A11 + G + M, clustered=clustered)
+    kw = dict(distanceMetric=metric)
+    if sep is not None:
+        kw["minSeparation"] = sep
+    st = check_update_against_oracle(P.default_config(**kw), w, w["z"][0], cap=cap, mm=mm, min_structural=0.0,
+                                     structural_maps=(metric == 0))
+    assert st["max_survivors"] > 256, st          # (the round-based merge, not merge_small)
+
+
 def test_more_clusters_than_one_sweep_of_the_moment_sums():
     """The accumulators of the exact moment sums share LDS with everything that is dead after the rounds: room for 384
     clusters at 1024 survivor slots / map capacity 512 (csrc/phd_lds_layout.h).  A map of 470 landmarks with a merge distance

@@ -189,9 +189,10 @@ int main() {
 # in PINNED_WITH when the pins were recorded (`python tests/test_kernel_resources.py` prints both)
 PINNED_WITH = "HIP version: 7.2.26015-fc0010cf6a, AMD clang version 22.0.0git (roc-7.2.0)"
 RECORDED_DEEP = {'ILb0ELb0ELb0ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb0ELb1ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb1ELb0ELi4ELb0ELi0E': 0,
-                 'ILb0ELb0ELb0ELb1ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb0ELb1ELi4ELb0ELi0E': 3, 'ILb0ELb0ELb1ELb1ELi4ELb0ELi0E': 5, 'ILb0ELb1ELb1ELb1ELi4ELb0ELi0E': 31,
-                 'ILb0ELb1ELb0ELb0ELi4ELb1ELi0E': 0, 'ILb0ELb0ELb0ELb0ELi4ELb0ELi2E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi2E': 0}
+                 'ILb0ELb0ELb0ELb1ELi4ELb0ELi0E': 6, 'ILb0ELb1ELb0ELb1ELi4ELb0ELi0E': 4, 'ILb0ELb0ELb1ELb1ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb1ELb1ELi4ELb0ELi0E': 0,
+                 'ILb0ELb1ELb0ELb0ELi4ELb1ELi0E': 0, 'ILb0ELb0ELb0ELb0ELi4ELb0ELi2E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi2E': 0}   # (round 6, with merge_tail)
 OBSERVED_DEEP = {}
+RECORDING = False                                     # python tests/test_kernel_resources.py: observe, do not hold
 
 
 def hipcc_version():
@@ -275,7 +276,7 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
         OBSERVED_DEEP[tag] = deep
         # the count observed when the pins were recorded (+ 2: allocator noise) — the global ceilings below admit a move of a few
         # dozen scalars, which once cost 3.3 % at configs[4]: the next register-cliff move fails HERE, per instantiation
-        if tag in RECORDED_DEEP:
+        if tag in RECORDED_DEEP and not RECORDING:
             assert deep <= RECORDED_DEEP[tag] + 2, "spill moves at loop depth >= 2 of %s: %d, recorded %d (%s)" % (tag, deep, RECORDED_DEEP[tag], by_depth)
         if with_spill_list:
             assert deep <= 40, (tag, by_depth)
@@ -307,9 +308,9 @@ def test_sgpr_spills_stay_out_of_the_inner_loops(compiled):
 HEADLINE = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb0ELb0ELi6ELb0ELi1EEEvNS_10UpdateArgsE"    # the fused step, three per CU, the bench layout compiled in
 # (round 5: the block-form tail of launches above 4096 particles has an instantiation of its own, and so have the LDS layouts of the
 #  bench configurations; HEADLINE_GENERAL — any layout, from the arguments — is round 4's code + the pass-1 cuts)
-RECORDED = {"code_bytes": 106608, "instructions": 20039, "valu": 11533}      # (no Hellinger copy of the merge in it)
+RECORDED = {"code_bytes": 111560, "instructions": 20955, "valu": 12088}      # (no Hellinger copy of the merge in it)
 HEADLINE_GENERAL = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb0ELb0ELi6ELb0ELi0EEEvNS_10UpdateArgsE"
-RECORDED_GENERAL = {"code_bytes": 169232, "instructions": 32150, "valu": 18151}
+RECORDED_GENERAL = {"code_bytes": 180384, "instructions": 34232, "valu": 19440}
 
 
 def static_profile(asm, sizes, name=None):
@@ -344,7 +345,7 @@ def test_headline_kernel_code_size_and_instruction_counts(compiled):
 # steps/s).  Its static profile and its spill counts are held to recorded values, so the next such move shows up HERE, with the numbers, and
 # not in a bench three weeks later.  Re-record after a deliberate change of the CPHD path: python tests/test_kernel_resources.py
 CPHD_HEADLINE = "_ZN3phd23phd_update_merge_kernelILb0ELb1ELb1ELb0ELi6ELb0ELi1EEEvNS_10UpdateArgsE"      # (the bench layout compiled in)
-RECORDED_CPHD = {"instructions": 33804, "valu": 19576, "sgpr_spill": 37, "vgpr_spill": 443}      # (the general instantiation: 44 663 / 25 979 / 82 / 459)
+RECORDED_CPHD = {"instructions": 35782, "valu": 20911, "sgpr_spill": 42, "vgpr_spill": 312}      # (the general instantiation: 44 663 / 25 979 / 82 / 459)
 
 
 def cphd_profile(text, asm):
@@ -400,6 +401,7 @@ if __name__ == "__main__":                                            # re-recor
             import pathlib
             return pathlib.Path(tempfile.mkdtemp(prefix=name))
     _c = compiled.__wrapped__(_F())
+    RECORDING = True
     print("RECORDED =", static_profile(*_c[1:]))
     print("RECORDED_GENERAL =", static_profile(_c[1], _c[2], HEADLINE_GENERAL))
     print("RECORDED_CPHD =", cphd_profile(_c[0], _c[1]))

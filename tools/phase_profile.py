@@ -56,6 +56,9 @@ for cid in [int(a) for a in sys.argv[1:]] or [2, 3]:
             continue
         print("   rounds: %.1f per particle; matrix %.2f us, resolve %.2f us, assign %.2f us (sums over rounds)" %
               (r[:, 3].mean(), r[:, 0].mean() * 0.01, r[:, 1].mean() * 0.01, r[:, 2].mean() * 0.01))
+        if st[:, 31].any():
+            print("   one-shot finish of the rounds (merge_tail, inside 'merge rounds'): %.2f us per particle; %.0f %% of the particles took it"
+                  % (st[:, 31].mean() * 0.01, 100.0 * (st[:, 31] > 0).mean()))
         if st[:, 28].any():
             c = st[:, 25:29].astype(np.float64).mean(axis=0)
             print("   assign statistics per particle: %.0f (survivor, round) tests; filter-positive seeds per test %.2f; exact decisions per "
