@@ -930,8 +930,14 @@ def emit(full):
             fh.write("\n")
     except OSError as e:                                      # a read-only tree must not cost the line
         print("bench.py: could not write %s: %s" % (RECORD_PATH, e), file=sys.stderr)
-    text = json.dumps(compact_line(full), separators=(",", ":"))
-    assert len(text) <= LINE_LIMIT, "bench.py: the result line is %d bytes (limit %d)" % (len(text), LINE_LIMIT)
+    line = compact_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    # never lose the line to its own size: drop what is optional until it fits (cannot happen with today's keys: 1.3 KB)
+    for drop in ("riders_steps_per_s", "roofline_valu", "hip_runtime_version"):
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
     sys.stdout.flush()
     print(text, flush=True)
 
