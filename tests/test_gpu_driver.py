@@ -393,3 +393,32 @@ def test_snapshot_slots_equal_the_blocking_snapshot():
         assert e.tobytes() == e2.tobytes() and who == who2 and m.tobytes() == m2.tobytes(), s
         assert poses.tobytes() == poses2.tobytes() and lw.tobytes() == lw2.tobytes(), s
         assert rep.did_resample == 1 and np.array_equal(idx, idx2) and rep.neff > 0, s
+
+
+def test_snapshot_slots_refuse_misuse():
+    """the slot protocol of the pipelined snapshot fails loudly: a slot is captured, then sent, then waited for — anything else is
+    PHD_ERR_INVALID_ARG with a message, never a silent overwrite of a block that is still being downloaded"""
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    w = S.make_workload(64, 8, 4, seed=3)
+    with P.PhdFilter(P.default_config(n_particles=64), n_particles=64, map_capacity=32, max_measurements=8) as f:
+        f.set_particles(w["poses"], w["logw"]); f.set_maps(w["maps"], w["sizes"])
+        f.update(w["z"][0])
+        for bad in (lambda: f.snapshot_send(0), lambda: f.snapshot_wait(0), lambda: f.snapshot_capture(2)):
+            with pytest.raises(P._lib.PhdError):
+                bad()
+        f.snapshot_capture(0)
+        with pytest.raises(P._lib.PhdError):
+            f.snapshot_capture(0)                              # captured, not yet waited for
+        with pytest.raises(P._lib.PhdError):
+            f.snapshot_wait(0)                                 # captured, not yet sent
+        f.snapshot_send(0)
+        with pytest.raises(P._lib.PhdError):
+            f.snapshot_send(0)
+        e, m, who, poses, lw, idx, rep = f.snapshot_wait(0)
+        assert idx is None and len(poses) == 64 and rep.status == 0
+        e2, m2, who2, poses2, lw2 = f.state_snapshot()
+        assert e.tobytes() == e2.tobytes() and m.tobytes() == m2.tobytes() and lw.tobytes() == lw2.tobytes()
+        f.snapshot_capture(0)                                  # the slot is free again
+        f.snapshot_send(0)
+        f.snapshot_wait(0)
