@@ -95,7 +95,7 @@ def test_cphd_update_matches_oracle(N, G, M, nmax, seed, min_structural=0.5):
             r = compare_particle_with_oracle(maps[p], surv, sidx, ref, ocfg, M, dlw=dlw[p], what="particle %d" % p,
                                              tail_bit_exact=False, dlogw_tol=cphd_dlogw_tol(ref["dlogw"], M))
             n_struct += bool(r["structural"])
-        assert n_struct >= int(min_structural * N) // 1 if min_structural < 0.5 else n_struct >= N // 2
+        assert n_struct >= (N // 2 if min_structural >= 0.5 else int(min_structural * N))
 
 
 def test_cphd_with_poisson_prior_is_the_phd_filter():
