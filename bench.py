@@ -392,6 +392,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
     d_noise = torch.from_numpy(w["noise"][0].copy()).to(dev)
     control = (2.0, 0.05)
     u = float(np.random.default_rng(0x5EED0000 + cfg_id).random())
+    M_scan = min(c.get("meas_override", M), M)               # (--meas: a scan shorter than the filter's measurement capacity)
 
     def build(any_layout):
         old = os.environ.get("PHD_LAYOUT")
@@ -411,7 +412,7 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
         f_.set_frozen(True)  # steady state: no step commits, every iteration restarts from the same snapshot
 
         def step_():
-            f_.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M, u, force_resample=True)
+            f_.step_dev(control, d_noise.data_ptr(), d_z.data_ptr(), M_scan, u, force_resample=True)
 
         def sync_():
             f_.sync()
@@ -501,8 +502,8 @@ def run_single(P, S, torch, cfg_id, steps, warmup, cpu_seconds, dev, local_rank,
         "ms_per_step_gpu_p10_p50_p90": pcts,
         "preroll_steps": preroll,
         "value_general": value_general,
-        "config": {"workload_short": ("diagnostic (--particles): %d particles of configs[%d]'s workload x %d Gaussians x %d meas/step" % (N, cfg_id - 1, G, M))
-                                     if c.get("particles_override") else
+        "config": {"workload_short": ("diagnostic (--particles / --meas): %d particles of configs[%d]'s workload x %d Gaussians x %d of %d meas/step" % (N, cfg_id - 1, G, M_scan, M))
+                                     if (c.get("particles_override") or c.get("meas_override")) else
                                      ("configs[%d]: %d particles x %d Gaussians x %d meas/step%s, Ackerman, forced resample, one launch/step"
                                       % (cfg_id - 1, N, G, M, ", CPHD" if cfg_id == 5 else "")) if cfg_id <= 5 else
                                      ("dense scan %d x %d x %d (not a BASELINE config), spill-merge path" % (N, G, M)),
@@ -958,6 +959,9 @@ def main():
     ap.add_argument("--particles", type=int, default=0,
                     help="override the particle count of the chosen configuration (a shard's share of configs[3]: 2048 / 4096 / 8192) — a "
                          "diagnostic workload, labelled in config.workload; not a BASELINE.json configuration")
+    ap.add_argument("--meas", type=int, default=0,
+                    help="diagnostic: scans of this many measurements (the first ones of the generated scan) on a filter that holds the "
+                         "configuration's measurement capacity - a RAGGED scan, what real data presents; labelled in config.workload")
     ap.add_argument("--bare", action="store_true",
                     help="profiling runs (rocprofv3): headline loop only — no riders, no stamped/unforced/copy passes, no CPU leg")
     args = ap.parse_args()
@@ -971,6 +975,9 @@ def main():
     if args.particles > 0:
         for cid in ([args.config] if args.config else [3, 4]):
             S.CONFIGS[cid] = dict(S.CONFIGS[cid], N=args.particles, particles_override=True)
+    if args.meas > 0:
+        for cid in ([args.config] if args.config else [3]):
+            S.CONFIGS[cid] = dict(S.CONFIGS[cid], meas_override=args.meas)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -103,6 +103,7 @@ SYMBOLS = {
     "phd_get_map": (_i, [_vp, _i, _vp, _i, _vp]),
     "phd_predict_ackerman": (_i, [_vp, Control, _vp]),
     "phd_update": (_i, [_vp, _vp, _i]),
+    "phd_predict_update": (_i, [_vp, Control, _vp, _vp, _i]),
     "phd_neff": (_i, [_vp, _vp]),
     "phd_resample": (_i, [_vp, _vp, _i, _vp]),
     "phd_resample_if_needed": (_i, [_vp, _d, _i, _vp, _vp]),

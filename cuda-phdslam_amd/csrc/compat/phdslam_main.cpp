@@ -429,10 +429,15 @@ int main(int argc, char** argv)
                 cv.wait(lk, [&] { return produced > n; });
             }
             PROF_MARK(0);                                                                        // waiting for the helper thread's draws
-            if (n > 0)                                                                           // no motion at step 0 (:1244)
-                for (int s = 0; s < sub; ++s)
+            // predict (no motion at step 0, :1244) and update (:1260-1272): the step's last predict and its update are ONE launch
+            // (phd_predict_update: the same results as the two calls)
+            if (n > 0) {
+                for (int s = 0; s + 1 < sub; ++s)
                     CHK(phd_predict_ackerman(f, current_control, device_noise ? nullptr : ring[n % 3] + (size_t)s * n_part));
-            if (M > 0) CHK(phd_update(f, Z, M));                                                 // :1260-1272
+                CHK(phd_predict_update(f, current_control, device_noise ? nullptr : ring[n % 3] + (size_t)(sub - 1) * n_part, Z, M));
+            } else if (M > 0) {
+                CHK(phd_update(f, Z, M));
+            }
             pend[n].inst = M > 0 ? phd_debug_update_instantiation(f) : -1;
             CHK(phd_snapshot_capture(f, n & 1));                                                 // the log's contents: before the resample
             // nEff test and resampling (:1281-1297), decided on the device: nEff <= resample_threshold and the step had a scan

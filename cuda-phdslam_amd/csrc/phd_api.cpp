@@ -988,6 +988,26 @@ extern "C" int phd_update(phd_filter* f, const phd_measurement* z, int n_meas)
     return phd_update_dev(f, f->d_z, M);
 }
 
+// phdPredict + phdUpdateSynth of one step in ONE launch (the vehicle predict fused in front of the update kernel, the weight
+// normalisation as its tail): the same results as phd_predict_ackerman followed by phd_update — the staged calls are what it
+// falls back to where the fused launch does not apply (no scan, the particle shotgun, filters that cannot fuse).
+extern "C" int phd_predict_update(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* noise, const phd_measurement* z, int n_meas)
+{
+    CHECK_F(f);
+    if (n_meas > 0 && !z) return fail(PHD_ERR_INVALID_ARG, "phd_predict_update: null measurements");
+    if (n_meas <= 0 || f->cfg.nPredictParticles > 1 || !can_fuse(f)) {
+        const int rc = phd_predict_ackerman(f, u, noise);
+        if (rc) return rc;
+        return phd_update(f, z, n_meas);
+    }
+    const int M = std::min(n_meas, f->MM);
+    if (noise) HIPCHK(hipMemcpyAsync(f->d_noise, noise, (size_t)f->n * sizeof(phd_ackerman_noise), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_z, z, M * sizeof(phd_measurement), hipMemcpyHostToDevice, f->stream));
+    FusedPredict fp = {u, noise ? f->d_noise : nullptr};
+    FusedWeights fw = {WM_ACCUMULATE | WM_NORMALIZE, 0.0};
+    return do_update_merge(f, f->d_z, M, &fp, &fw);
+}
+
 extern "C" int phd_neff(phd_filter* f, float* neff_out)
 {
     CHECK_F(f);
@@ -1192,14 +1212,10 @@ extern "C" int phd_snapshot_capture(phd_filter* f, int slot)
     if (f->snap_state[slot] != 0) return fail(PHD_ERR_INVALID_ARG, "phd_snapshot_capture: the slot holds a snapshot that was not waited for");
     int rc = ensure_snapshot(f);
     if (rc) return rc;
-    rc = ensure_concat(f, (size_t)f->cap);
-    if (rc) return rc;
-    // the same two kernels as phd_state_snapshot (so: the same bits), then one pack into the slot's staging block
-    HIPCHK(launch_state(f->pose[f->pose_cur], f->logw, f->n, f->state_pose, f->state_argmax, f->stream));
-    HIPCHK(launch_unpack_one(f->maps[f->cur], f->parent[f->pcur], f->counts[f->cur], f->state_argmax, f->d_concat, f->cap,
-                             f->d_tmp_int, f->stream));
-    HIPCHK(launch_snapshot_pack(f->state_pose, f->state_argmax, f->d_tmp_int, f->d_concat, f->pose[f->pose_cur], f->logw, f->n,
-                                f->n_max, f->cap, f->snap_dev[slot], f->stream));
+    // ONE launch: phd_state_snapshot's two kernels restated operation for operation (the same bits) + the copies, straight
+    // into the slot's staging block (phd_snapshot.hip)
+    HIPCHK(launch_snapshot(f->pose[f->pose_cur], f->logw, f->n, f->n_max, f->maps[f->cur], f->parent[f->pcur], f->counts[f->cur], f->cap,
+                           f->snap_dev[slot], f->stream));
     f->snap_state[slot] = 1;
     f->snap_n[slot] = f->n;
     return PHD_OK;

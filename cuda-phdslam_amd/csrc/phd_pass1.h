@@ -226,15 +226,36 @@ __device__ __forceinline__ void pass1_chunks(const Lds& L, const Pass1Grid& g, i
             const v4f fa = L.f_a[jj];
             v2f fc = L.f_c[jj];
             if (j >= n_in) fc.y = -INFINITY;                      // contributes exp(-inf) = 0, never a candidate
+#ifdef PHD_PASS1_RAGGED_R5
             const u32 bits = (fast && vm == (1u << CH) - 1u) ? pass1_octet_packed<CH>(zr, zb, fa, fc, c0m, acc)
                              : fast                          ? pass1_octet<true, CH>(zr, zb, vm, fa, fc, c0m, acc)
                                                              : pass1_octet<false, CH>(zr, zb, vm, fa, fc, c0m, acc);
+#else
+            // A RAGGED chunk — a scan whose length is not a multiple of the chunk (the last chunk of every real scan: 14 ... 44
+            // measurements in the bundled data) or a measurement whose label is rejected — takes the packed form too (round 6): the
+            // slots without a measurement carry a copy of the scan's last one (loaded above), their sums are dropped below and their
+            // candidate bits masked here.  Until round 5 such a chunk ran the one-measurement-at-a-time form, about twice the
+            // instructions, on ONE wave with the other seven waiting at the barrier behind it: +1.0 ... +1.5 % on scans of 27 / 44 / 61
+            // measurements at 4096 x 256.  The packed form takes exp2 of a pre-scaled argument where the one-at-a-time form takes
+            // __expf: the two agree to the rounding of that argument (an ulp of the sum, far inside the parity tolerances), so a
+            // ragged chunk now rounds exactly like a full one — and a chained run (331 steps with resampling) is not bit-identical
+            // to a round-5 build's.
+            const u32 bits = fast ? (pass1_octet_packed<CH>(zr, zb, fa, fc, c0m, acc) & vm)
+                                  : pass1_octet<false, CH>(zr, zb, vm, fa, fc, c0m, acc);
+#endif
             if (sparse2) {
                 pend |= bits << (slot * CH);
                 if (++slot == GPF) { flush(jb - (GPF - 1) * jstep); slot = 0; }   // (uniform)
             }
         }
         if (sparse2 && slot) flush(jb - slot * jstep);
+#ifndef PHD_PASS1_RAGGED_R5
+        if (fast && vm != (1u << CH) - 1u) {                      // (uniform) the slots without a measurement: whatever their copies summed up is dropped
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (!((vm >> q) & 1u)) acc[q] = 0.f;
+        }
+#endif
         float tot;
         int m;
         if (CH == 8) { tot = reduce8_over_wave((float (&)[8])acc, lane); m = c + (lane >> 3) * mstep; }

@@ -133,6 +133,12 @@ class PhdFilter:
             raise ValueError("noise must have n_particles * n_predict_particles entries")
         check(lib().phd_predict_ackerman(self._h, _ctrl(control), ptr(nz)), "phd_predict_ackerman")
 
+    def predict_update(self, control, noise, z):
+        """phdPredict + phdUpdateSynth of one step in ONE launch: the results of predict(control, noise) followed by update(z)"""
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float32).view(NOISE).reshape(-1)
+        z = np.ascontiguousarray(z, MEAS)
+        check(lib().phd_predict_update(self._h, _ctrl(control), ptr(nz), ptr(z), len(z)), "phd_predict_update")
+
     def update(self, z):
         """phdUpdateSynth(particles, Z)"""
         z = np.ascontiguousarray(z, MEAS)

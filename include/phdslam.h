@@ -196,6 +196,12 @@ int phd_predict_ackerman(phd_filter* f, phd_ackerman_control u, const phd_ackerm
  * Asynchronous on the filter's stream. */
 int phd_update(phd_filter* f, const phd_measurement* z, int n_meas);
 
+/* phdPredict + phdUpdateSynth of ONE step in one launch (run_synth's src/main.cpp:1244-1272: the vehicle predict fused in front of
+ * the update kernel, the weight normalisation as its tail): exactly the results of phd_predict_ackerman(f, u, noise) followed by
+ * phd_update(f, z, n_meas) — which is what it runs where the fused launch does not apply (n_meas <= 0: predict only; the particle
+ * shotgun; filters whose weights routine cannot be fused).  Asynchronous on the filter's stream. */
+int phd_predict_update(phd_filter* f, phd_ackerman_control u, const phd_ackerman_noise* noise, const phd_measurement* z, int n_meas);
+
 /* replaces: the nEff test of run_synth (src/main.cpp:1281-1284) */
 int phd_neff(phd_filter* f, float* neff_out);
 

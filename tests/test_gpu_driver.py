@@ -422,3 +422,32 @@ def test_snapshot_slots_refuse_misuse():
         f.snapshot_capture(0)                                  # the slot is free again
         f.snapshot_send(0)
         f.snapshot_wait(0)
+
+
+@pytest.mark.parametrize("ft,N", [(0, 300), (1, 200), (0, 5000)])
+def test_predict_update_in_one_launch_equals_the_two_calls(ft, N):
+    """phd_predict_update (the pipelined loop's step: vehicle predict fused in front of the update kernel, normalisation as its tail)
+    against phd_predict_ackerman + phd_update: particles, weights, maps, the step report — bit for bit, over three chained steps
+    with host noise and with the device generator, PHD and CPHD, below and above the block-form tail's 4096 particles."""
+    P = importlib.import_module("cuda-phdslam_amd")
+    S = importlib.import_module("cuda-phdslam_amd.synthetic")
+    G, M = 24, 10
+    w = S.make_workload(N, G, M, seed=91 + N, n_meas_sets=3, clustered=True)
+    cfg = P.default_config(n_particles=N, filterType=ft, maxCardinality=63)
+    outs = []
+    for fused in (False, True):
+        with P.PhdFilter(cfg, n_particles=N, map_capacity=128, max_measurements=16) as f:
+            f.set_particles(w["poses"], w["logw"]); f.set_maps(w["maps"], w["sizes"]); f.seed(5)
+            for s in range(3):
+                noise = w["noise"][s] if s != 1 else None                       # step 1: the device generator
+                z = w["z"][s] if s != 2 else w["z"][s][:7]                      # step 2: a shorter scan
+                if fused:
+                    f.predict_update((2.0, 0.05), noise, z)
+                else:
+                    f.predict((2.0, 0.05), noise); f.update(z)
+                f.resample_if_needed(w["uniform"][s], had_measurements=True)
+            poses, lw = f.get_particles()
+            rep = f.step_report()
+            outs.append((poses.tobytes(), lw.tobytes(), [m.tobytes() for m in f.get_maps()], rep.neff, rep.did_resample))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert outs[0][3] == outs[1][3] and outs[0][4] == outs[1][4]
