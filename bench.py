@@ -295,7 +295,9 @@ def timed_loop(step, sync, ts, torch, steps, warmup, preroll_ms, agree=None):
 
 def _instantiation(P, f):
     k = int(P._lib.lib().phd_debug_update_instantiation(f._h))
-    return {"index": k, "fast_path": k >= 18}
+    # (csrc/phd_kernels.hip: below 18 the LDS layout and the scan's length come from the arguments; 18 ... 26 both are compiled in — a
+    #  full scan on a filter of a compiled-in layout; 27 ... 35 the layout alone — any other scan on such a filter)
+    return {"index": k, "fast_path": 18 <= k < 27, "layout_compiled_in": k >= 18}
 
 
 def make_filter(P, torch, cfg_id, n_local, G, M, n_global, offset, dev, local_rank, map_capacity=0, survivor_capacity=0):

@@ -146,6 +146,15 @@ __device__ __forceinline__ void handoff_ticket(unsigned* ticket)
 template <int LAYOUT> struct FixedLayout { static constexpr int S = 0, C = 0, MM = 0, CN = 0; };
 template <> struct FixedLayout<1> { static constexpr int S = 1024, C = 512, MM = 64, CN = 256; };
 template <> struct FixedLayout<2> { static constexpr int S = 512, C = 128, MM = 32, CN = 256; };
+// LAYOUT 3 / 4 (round 6): the layouts of 1 / 2 WITHOUT the scan length — the measurement count comes from the arguments.  What a filter
+// of one of these layouts runs on a scan of any other length than its capacity, i.e. on every real scan (the bundled data: 14 ... 44
+// measurements): same visit, 4096 x 256 with scans of 27 / 44 / 61 measurements +3.3 / +3.5 / +2.9 % against the general instantiation,
+// 16 384 particles +5.4 %, 256 x 64 with 13 / 27 measurements +4.3 / +2.8 %, and the CPHD variant **+24.8 / +14.6 / +14.3 %** (its
+// general instantiation carries the cardinality rows' length and every table offset in registers) — profiles/r06_ab_layout_dynm.txt.
+// A full scan keeps the instantiations that have its length too (1 / 2): -3.6 % (PHD), -8.8 % (CPHD) without it.
+template <> struct FixedLayout<3> : FixedLayout<1> {};
+template <> struct FixedLayout<4> : FixedLayout<2> {};
+#define PHD_LAYOUT_FULL_SCAN(L) ((L) == 1 || (L) == 2)
 #define PHD_A_SCAP (LAYOUT ? FixedLayout<LAYOUT>::S : A.S_cap)
 #define PHD_A_CAP (LAYOUT ? FixedLayout<LAYOUT>::C : A.cap)
 #define PHD_A_MM (LAYOUT ? FixedLayout<LAYOUT>::MM : A.MM)
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
     const DevConfig& cfg = A.cfg;
     // (LAYOUT != 0: a FULL scan — as many measurements as the filter holds, what BASELINE.json's configurations are — so that the
     //  measurement count is a constant too: the grids of pass 1 and pass 2, the CPHD block's tile count and sweep lengths fold)
-    const int cap = PHD_A_CAP, S_cap = PHD_A_SCAP, M = LAYOUT ? PHD_A_MM : A.M;
+    const int cap = PHD_A_CAP, S_cap = PHD_A_SCAP, M = PHD_LAYOUT_FULL_SCAN(LAYOUT) ? PHD_A_MM : A.M;
     const int src = A.parent[p];
     const float* __restrict__ in = A.map_in + (size_t)src * 6 * cap;
     const unsigned rows_stride = FUSEW ? 0u : A.out_stride; // rows mode belongs to the multi-GPU step (never the fused tail)
@@ -757,24 +766,33 @@ __global__ __launch_bounds__(PHD_T, MINW) void phd_update_merge_kernel(UpdateArg
 #if defined(PHD_CPHD_W6_TU)
 // <STAMPS, FUSEW, CPHD, -, 6>: the same three for the CPHD filter
 // [3], [4]: the staged and the fused step with the layout of BASELINE.json's 256-Gaussian configurations compiled in (LAYOUT = 1)
-extern const void* const k_update_cphd_w6_fns[6] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
+// [6], [7], [8]: the same three with LAYOUT = 3 (the layout without the scan length: scans shorter than the filter's capacity)
+extern const void* const k_update_cphd_w6_fns[9] = {(const void*)phd_update_merge_kernel<false, false, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<true, false, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<false, true, true, false, 6>,
                                                     (const void*)phd_update_merge_kernel<false, false, true, false, 6, false, 1>,
                                                     (const void*)phd_update_merge_kernel<false, true, true, false, 6, false, 1>,
-                                                    (const void*)phd_update_merge_kernel<true, false, true, false, 6, false, 1>};   // [5]: the diagnostic one
+                                                    (const void*)phd_update_merge_kernel<true, false, true, false, 6, false, 1>,    // [5]: the diagnostic one
+                                                    (const void*)phd_update_merge_kernel<false, false, true, false, 6, false, 3>,
+                                                    (const void*)phd_update_merge_kernel<false, true, true, false, 6, false, 3>,
+                                                    (const void*)phd_update_merge_kernel<true, false, true, false, 6, false, 3>};
 #elif defined(PHD_W6_TU)
 // <STAMPS, FUSEW, -, -, 6>: the staged step, the diagnostic instantiation and the fused step for three workgroups per CU
 // + the fused step with the block-form tail (more than 4096 particles)
 // [4], [5], [6]: the staged step, the fused step (the headline) and the fused step with the block-form tail with LAYOUT = 1 compiled in
-extern const void* const k_update_w6_fns[8] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
+// [8] ... [11]: the same four with LAYOUT = 3 (the layout without the scan length)
+extern const void* const k_update_w6_fns[12] = {(const void*)phd_update_merge_kernel<false, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<true, false, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true>,
                                                (const void*)phd_update_merge_kernel<false, false, false, false, 6, false, 1>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 1>,
                                                (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 1>,
-                                               (const void*)phd_update_merge_kernel<true, false, false, false, 6, false, 1>};   // [7]: the diagnostic one
+                                               (const void*)phd_update_merge_kernel<true, false, false, false, 6, false, 1>,    // [7]: the diagnostic one
+                                               (const void*)phd_update_merge_kernel<false, false, false, false, 6, false, 3>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, false, 3>,
+                                               (const void*)phd_update_merge_kernel<false, true, false, false, 6, true, 3>,
+                                               (const void*)phd_update_merge_kernel<true, false, false, false, 6, false, 3>};
 #elif defined(PHD_CPHD_TU)
 // <STAMPS, FUSEW, CPHD, SPILL>: the staged step, the diagnostic instantiation, the fused step, and the two with a spill list
 extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_kernel<false, false, true, false>,
@@ -784,8 +802,8 @@ extern const void* const k_update_cphd_fns[5] = {(const void*)phd_update_merge_k
                                                  (const void*)phd_update_merge_kernel<false, true, true, true>};
 #else
 extern const void* const k_update_cphd_fns[5];
-extern const void* const k_update_w6_fns[8];
-extern const void* const k_update_cphd_w6_fns[6];
+extern const void* const k_update_w6_fns[12];
+extern const void* const k_update_cphd_w6_fns[9];
 
 __global__ void phd_predict_kernel(const phd_pose* __restrict__ in, phd_pose* __restrict__ out, int n,
                                    phd_ackerman_control u, const phd_ackerman_noise* __restrict__ noise,
@@ -1207,7 +1225,7 @@ __global__ void phd_iota_kernel(int* a, int n)
 // ------------------------------------------------------------------------------------------
 // launchers (called from phd_api.cpp; plain C++ signatures, no <<<>>> outside this file)
 // ------------------------------------------------------------------------------------------
-#define PHD_N_UPDATE_FNS_DECL 27
+#define PHD_N_UPDATE_FNS_DECL 36
 static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd_update_merge_kernel<false, false, false, false>,
                                              (const void*)phd_update_merge_kernel<true, false, false, false>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false>,
@@ -1227,8 +1245,14 @@ static const void* const k_update_fns[PHD_N_UPDATE_FNS_DECL] = {(const void*)phd
                                              (const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 2>,
                                              (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 2>,
                                              // [25], [26]: the diagnostic instantiations (phase stamps) of the three-per-CU fast path, PHD and CPHD
-                                             k_update_w6_fns[7], k_update_cphd_w6_fns[5]};
-#define PHD_N_UPDATE_FNS 27
+                                             k_update_w6_fns[7], k_update_cphd_w6_fns[5],
+                                             // [27..35] the layouts WITHOUT the scan length (LAYOUT = 3 / 4): of [18], [19], [20], [21], [22], [23], [24], [25], [26]
+                                             k_update_w6_fns[8], k_update_w6_fns[9], k_update_w6_fns[10],
+                                             k_update_cphd_w6_fns[6], k_update_cphd_w6_fns[7],
+                                             (const void*)phd_update_merge_kernel<false, false, false, false, PHD_MIN_WAVES, false, 4>,
+                                             (const void*)phd_update_merge_kernel<false, true, false, false, PHD_MIN_WAVES, false, 4>,
+                                             k_update_w6_fns[11], k_update_cphd_w6_fns[8]};
+#define PHD_N_UPDATE_FNS 36
 
 // per-device one-time setup (function attributes are per device).  A mutex-guarded set of device ordinals: no aliasing of
 // ordinals, no race between host threads that create or drive filters on different devices at the same time.
@@ -1325,18 +1349,22 @@ static int update_fn_index(const UpdateArgs& a, bool three, int n_particles = 0,
 {
     const int fn = update_fn_index_any_layout(a, three, n_particles);
     if (any_layout) return fn;
-    if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM && a.M == FixedLayout<1>::MM) {
+    // a filter of a compiled-in layout: the instantiation with the scan's length too when the scan is full (18 ... 26), the one with the
+    // layout alone otherwise (27 ... 35 = 9 further on)
+    if (a.S_cap == FixedLayout<1>::S && a.cap == FixedLayout<1>::C && a.MM == FixedLayout<1>::MM) {
+        const int dyn = (a.M == FixedLayout<1>::MM) ? 0 : 9;
         switch (fn) {
-        case 10: case 12: case 16: if (a.cfg.distanceMetric == 0) return fn == 10 ? 18 : fn == 12 ? 19 : 20; break;   // (PHD: the Mahalanobis merge only)
-        case 11: if (a.cfg.distanceMetric == 0) return 25; break;
-        case 14: if (a.cn_len == FixedLayout<1>::CN) return 26; break;
-        case 13: if (a.cn_len == FixedLayout<1>::CN) return 21; break;       // (CPHD: the cardinality rows' length is compiled in as well)
-        case 15: if (a.cn_len == FixedLayout<1>::CN) return 22; break;
+        case 10: case 12: case 16: if (a.cfg.distanceMetric == 0) return (fn == 10 ? 18 : fn == 12 ? 19 : 20) + dyn; break;   // (PHD: the Mahalanobis merge only)
+        case 11: if (a.cfg.distanceMetric == 0) return 25 + dyn; break;
+        case 14: if (a.cn_len == FixedLayout<1>::CN) return 26 + dyn; break;
+        case 13: if (a.cn_len == FixedLayout<1>::CN) return 21 + dyn; break;       // (CPHD: the cardinality rows' length is compiled in as well)
+        case 15: if (a.cn_len == FixedLayout<1>::CN) return 22 + dyn; break;
         default: break;
         }
     }
-    if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM && a.M == FixedLayout<2>::MM) {
-        if (a.cfg.distanceMetric == 0) switch (fn) { case 0: return 23; case 2: return 24; default: break; }
+    if (a.S_cap == FixedLayout<2>::S && a.cap == FixedLayout<2>::C && a.MM == FixedLayout<2>::MM) {
+        const int dyn = (a.M == FixedLayout<2>::MM) ? 0 : 9;
+        if (a.cfg.distanceMetric == 0) switch (fn) { case 0: return 23 + dyn; case 2: return 24 + dyn; default: break; }
     }
     return fn;
 }

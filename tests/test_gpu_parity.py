@@ -325,19 +325,28 @@ def test_compiled_in_layouts_agree_with_the_general_instantiations(ft, layout, N
             g.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, w["uniform"][0], force_resample=True)
             g.sync()
             pg, lg = g.get_particles()
+            g_maps_full = g.get_maps()
             which = (P._lib.lib().phd_debug_update_instantiation(f._h), P._lib.lib().phd_debug_update_instantiation(g._h))
-            assert all(k >= 18 for k in which) if general == "1" else all(0 <= k < 18 for k in which), (general, which)
-            # a SHORTER scan on the same filter: the compiled-in instantiations assume a full one, the launcher must take the general
-            # instantiation for this launch (and the step after it is a full scan again)
+            assert all(18 <= k < 27 for k in which) if general == "1" else all(0 <= k < 18 for k in which), (general, which)
+            # a SHORTER scan on the same filter (what every real scan is): the instantiations 18 ... 26 have the scan's length compiled in,
+            # so the launcher takes, for this launch, the ones with the layout ALONE (27 ... 35, round 6) — and the step after it is a
+            # full scan again.  Staged update and fused step, both compared with the general instantiations below.
             f.predict((2.0, 0.05), w["noise"][0])
             f.update(w["z"][0][:M - 3])
-            assert 0 <= P._lib.lib().phd_debug_update_instantiation(f._h) < 18
+            k_short = P._lib.lib().phd_debug_update_instantiation(f._h)
+            assert (27 <= k_short < 36) if general == "1" else (0 <= k_short < 18), (general, k_short)
             short = (f.get_maps(), f.weight_increments())
+            g.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M - 5, w["uniform"][0], force_resample=True)
+            g.sync()
+            k_short_fused = P._lib.lib().phd_debug_update_instantiation(g._h)
+            assert (27 <= k_short_fused < 36) if general == "1" else (0 <= k_short_fused < 18), (general, k_short_fused)
+            pg2, lg2 = g.get_particles()
+            short_fused = (g.get_maps(), pg2, lg2)
             f.predict((2.0, 0.05), w["noise"][0])
             f.update(w["z"][0])
-            assert (P._lib.lib().phd_debug_update_instantiation(f._h) >= 18) == (general == "1")
-            out.append((staged, (g.get_maps(), pg, lg), st, short, f.get_maps()))
-    (sa, fa, sta, sha, la), (sb, fb, stb, shb, lb) = out
+            assert (18 <= P._lib.lib().phd_debug_update_instantiation(f._h) < 27) == (general == "1")
+            out.append((staged, (g_maps_full, pg, lg), st, short, f.get_maps(), short_fused))
+    (sa, fa, sta, sha, la, sfa), (sb, fb, stb, shb, lb, sfb) = out
     assert sta["max_survivors"] == stb["max_survivors"] and sta["max_map"] == stb["max_map"]
     assert np.array_equal(sha[1].view(np.uint32), shb[1].view(np.uint32))
     for p in range(N):
@@ -345,8 +354,10 @@ def test_compiled_in_layouts_agree_with_the_general_instantiations(ft, layout, N
         assert np.array_equal(fa[0][p].view(np.uint8), fb[0][p].view(np.uint8)), (ft, layout, "fused", p)
         assert np.array_equal(sha[0][p].view(np.uint8), shb[0][p].view(np.uint8)), (ft, layout, "short scan", p)
         assert np.array_equal(la[p].view(np.uint8), lb[p].view(np.uint8)), (ft, layout, "third step", p)
+        assert np.array_equal(sfa[0][p].view(np.uint8), sfb[0][p].view(np.uint8)), (ft, layout, "short scan, fused step", p)
     assert np.array_equal(sa[1].view(np.uint32), sb[1].view(np.uint32))
     assert np.array_equal(fa[1], fb[1]) and np.array_equal(fa[2].view(np.uint32), fb[2].view(np.uint32))
+    assert np.array_equal(sfa[1], sfb[1]) and np.array_equal(sfa[2].view(np.uint32), sfb[2].view(np.uint32))
     for (xa, ia), (xb, ib) in zip(sa[2], sb[2]):
         assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)) and np.array_equal(ia, ib), (ft, layout)
     if ft == 0:

@@ -70,11 +70,15 @@ def compiled(tmp_path_factory):
 TAGS = ("ILb0ELb0ELb0ELb0ELi4ELb0ELi0E", "ILb0ELb1ELb0ELb0ELi4ELb0ELi0E", "ILb0ELb0ELb1ELb0ELi4ELb0ELi0E", "ILb0ELb1ELb1ELb0ELi4ELb0ELi0E",
         "ILb0ELb0ELb0ELb1ELi4ELb0ELi0E", "ILb0ELb1ELb0ELb1ELi4ELb0ELi0E", "ILb0ELb0ELb1ELb1ELi4ELb0ELi0E", "ILb0ELb1ELb1ELb1ELi4ELb0ELi0E",
         "ILb0ELb1ELb0ELb0ELi4ELb1ELi0E",      # (the fused step with the block-form tail, launches above 4096 particles)
-        "ILb0ELb0ELb0ELb0ELi4ELb0ELi2E", "ILb0ELb1ELb0ELb0ELi4ELb0ELi2E")
+        "ILb0ELb0ELb0ELb0ELi4ELb0ELi2E", "ILb0ELb1ELb0ELb0ELi4ELb0ELi2E",
+        "ILb0ELb0ELb0ELb0ELi4ELb0ELi4E", "ILb0ELb1ELb0ELb0ELi4ELb0ELi4E")       # (Li4: layout 2 without the scan length, round 6)
 TAGS_W6 = ("ILb0ELb0ELb0ELb0ELi6ELb0ELi0E", "ILb0ELb1ELb0ELb0ELi6ELb0ELi0E", "ILb0ELb0ELb1ELb0ELi6ELb0ELi0E", "ILb0ELb1ELb1ELb0ELi6ELb0ELi0E",
            "ILb0ELb1ELb0ELb0ELi6ELb1ELi0E",
            "ILb0ELb0ELb0ELb0ELi6ELb0ELi1E", "ILb0ELb1ELb0ELb0ELi6ELb0ELi1E", "ILb0ELb0ELb1ELb0ELi6ELb0ELi1E", "ILb0ELb1ELb1ELb0ELi6ELb0ELi1E",
-           "ILb0ELb1ELb0ELb0ELi6ELb1ELi1E")
+           "ILb0ELb1ELb0ELb0ELi6ELb1ELi1E",
+           # (Li3: layout 1 without the scan length, round 6 — what a filter of that layout runs on a scan of any other length)
+           "ILb0ELb0ELb0ELb0ELi6ELb0ELi3E", "ILb0ELb1ELb0ELb0ELi6ELb0ELi3E", "ILb0ELb0ELb1ELb0ELi6ELb0ELi3E", "ILb0ELb1ELb1ELb0ELi6ELb0ELi3E",
+           "ILb0ELb1ELb0ELb0ELi6ELb1ELi3E")
 
 
 def test_production_kernels_do_not_spill(compiled):

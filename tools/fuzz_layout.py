@@ -37,6 +37,11 @@ def main():
         N = int(rng.choice([600, 900, 900, 4200, 64] if layout == 1 else [1, 17, 256, 500]))
         G = int(rng.integers(1, cap // 2 + 1))
         clustered = bool(rng.integers(0, 2))
+        # the scan: full (the instantiations with the layout AND the scan's length compiled in) or — half of the cases, round 6 — of any
+        # shorter length (the ones with the layout alone), on a filter whose REQUESTED measurement capacity may be smaller than the
+        # layout's (phd_create rounds it up)
+        m_scan = M if rng.random() < 0.5 else int(rng.integers(1, M + 1))
+        mm_req = M if rng.random() < 0.5 else int(rng.integers(m_scan, M + 1))
         w = S.make_workload(N, G, M, seed=seed, clustered=clustered)
         over = dict(n_particles=N)
         if ft:
@@ -49,22 +54,24 @@ def main():
         try:
             for general in ("1", "0"):
                 os.environ["PHD_LAYOUT"] = general
-                with P.PhdFilter(cfg, n_particles=N, map_capacity=cap, max_measurements=M) as f, \
-                        P.PhdFilter(cfg, n_particles=N, map_capacity=cap, max_measurements=M) as g:
+                with P.PhdFilter(cfg, n_particles=N, map_capacity=cap, max_measurements=mm_req) as f, \
+                        P.PhdFilter(cfg, n_particles=N, map_capacity=cap, max_measurements=mm_req) as g:
                     for x in (f, g):
                         x.set_particles(w["poses"], w["logw"])
                         x.set_maps(w["maps"], w["sizes"])
                     f.predict((2.0, 0.05), w["noise"][0])
-                    f.update(w["z"][0])
+                    f.update(w["z"][0][:m_scan])
                     st = f.status(raise_on_overflow=False)
                     staged = (f.get_maps(), f.weight_increments())
                     torch.cuda.synchronize()
-                    g.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, float(w["uniform"][0]), force_resample=bool(seed & 1))
+                    g.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), m_scan, float(w["uniform"][0]), force_resample=bool(seed & 1))
                     g.sync()
                     pg, lg = g.get_particles()
                     which = (L.phd_debug_update_instantiation(f._h), L.phd_debug_update_instantiation(g._h))
                     if general == "1":
                         fast = all(k >= 18 for k in which)      # (no fast path where the build and the layout do not meet: layout 2 three per CU, layout 1 two per CU)
+                        if fast:
+                            assert all((18 <= k < 27) == (m_scan == M) for k in which), (which, m_scan, M)
                     else:
                         assert all(0 <= k < 18 for k in which), which
                     out.append((staged, (g.get_maps(), pg, lg), st))
@@ -86,7 +93,7 @@ def main():
             n_fast += int(fast)
         except AssertionError as e:
             n_fail += 1
-            print("FAIL seed %d layout=%d ft=%d N=%d G=%d clustered=%s: %s" % (seed, layout, ft, N, G, clustered, str(e)[:200]))
+            print("FAIL seed %d layout=%d ft=%d N=%d G=%d clustered=%s scan %d of %d (requested capacity %d): %s" % (seed, layout, ft, N, G, clustered, m_scan, M, mm_req, str(e)[:200]))
         seed += 1
     os.environ.pop("PHD_LAYOUT", None)
     print("fast-path fuzz: %d cases bit-identical to the general instantiations (%d of them through the fast path), %d failed, %d skipped (capacity), %.0f s, seeds up to %d"
