@@ -272,13 +272,11 @@ extern "C" int phd_create(const phd_slam_config* cfg, const phd_options* opt, ph
     // 512 / 64 measurements and 512 / 128 / 32) — worth +3 % (PHD) to +25 % (CPHD) on real scans.  The layout is a property of the
     // LIBRARY, not of a bench script (round 6): a filter with one of those map capacities and the default survivor
     // capacity gets its measurement capacity rounded UP to the layout's — LDS for a few more measurements; scans are still clamped to
-    // the caller's max_measurements (M_limit).  PHD_LAYOUT=0 keeps the request as it is.
-    {
-        const char* e = getenv("PHD_LAYOUT");
-        if (!(e && e[0] == '0') && o.survivor_capacity <= 0) {
-            if (f->cap == 512 && f->MM < 64) f->MM = 64;
-            else if (f->cap == 128 && f->MM < 32) f->MM = 32;
-        }
+    // the caller's max_measurements (M_limit).  (Whatever PHD_LAYOUT says: that switch picks instantiations, not capacities — the CPHD
+    // block chooses some of its forms by the measurement capacity, and a filter must not change its arithmetic with a debugging switch.)
+    if (o.survivor_capacity <= 0) {
+        if (f->cap == 512 && f->MM < 64) f->MM = 64;
+        else if (f->cap == 128 && f->MM < 32) f->MM = 32;
     }
     f->n_global = o.global_particles > 0 ? o.global_particles : f->n;
     f->global_offset = o.global_offset;

@@ -194,7 +194,8 @@ int main() {
 PINNED_WITH = "HIP version: 7.2.26015-fc0010cf6a, AMD clang version 22.0.0git (roc-7.2.0)"
 RECORDED_DEEP = {'ILb0ELb0ELb0ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb0ELb1ELb0ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb1ELb0ELi4ELb0ELi0E': 0,
                  'ILb0ELb0ELb0ELb1ELi4ELb0ELi0E': 6, 'ILb0ELb1ELb0ELb1ELi4ELb0ELi0E': 3, 'ILb0ELb0ELb1ELb1ELi4ELb0ELi0E': 0, 'ILb0ELb1ELb1ELb1ELi4ELb0ELi0E': 3,
-                 'ILb0ELb1ELb0ELb0ELi4ELb1ELi0E': 0, 'ILb0ELb0ELb0ELb0ELi4ELb0ELi2E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi2E': 0}   # (round 6, with merge_tail)
+                 'ILb0ELb1ELb0ELb0ELi4ELb1ELi0E': 0, 'ILb0ELb0ELb0ELb0ELi4ELb0ELi2E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi2E': 0,
+                 'ILb0ELb0ELb0ELb0ELi4ELb0ELi4E': 0, 'ILb0ELb1ELb0ELb0ELi4ELb0ELi4E': 0}   # (round 6, with merge_tail)
 OBSERVED_DEEP = {}
 RECORDING = False                                     # python tests/test_kernel_resources.py: observe, do not hold
 
