@@ -132,7 +132,9 @@ typedef struct phd_filter phd_filter; /* opaque: owns all device state of one ra
 typedef struct {
     int32_t n_particles;      /* particles held by THIS filter (a rank's shard); 0 = cfg->n_particles */
     int32_t map_capacity;     /* Gaussians per particle slab; 0 = 256                                   */
-    int32_t max_measurements; /* <= PHD_MAX_MEASUREMENTS; 0 = 256                                       */
+    int32_t max_measurements; /* <= PHD_MAX_MEASUREMENTS; 0 = 256: what a scan is clamped to (src/phdfilter.cu:3390-3394).  With map_capacity 512
+                               * (128) and the default survivor capacity the filter RESERVES room for 64 (32) measurements — one of the LDS
+                               * layouts the update kernel has compiled in (+3 % PHD ... +25 % CPHD on real scans); the clamp stays as given */
     int32_t survivor_capacity;/* pruned update components kept per particle before merging; 0 = auto (map_capacity + 8 max_measurements,
                                * at most 2048 — what LDS holds).  > 2048 adds a spill list in HBM: particles with more than 2048
                                * survivors (dense scans of large maps; the reference has no cap) are merged by a plain global-memory
@@ -260,10 +262,11 @@ int phd_debug_gm_rounds(phd_filter* f);
 /* global resamples of this shard that took the copy-free form (phd_global_resample_pull / _end: local parents by indirection,
  * remote ones parked in guest slabs; PHD_COPY_FREE=0 in the environment at phd_create selects the copying forms) — diagnostics */
 int phd_debug_copy_free_resamples(phd_filter* f);
-/* which instantiation of the update kernel the last update launch of this filter ran: the index into the launcher's table
- * (csrc/phd_kernels.hip: 0..17 take the LDS layout and the scan's length from the arguments, 18..26 have the layout of a
- * BASELINE.json configuration and a full scan compiled in — picked per launch; PHD_LAYOUT=0 in the environment at phd_create keeps a
- * filter on the former) — diagnostics; -1 before any launch */
+/* which instantiation of the update kernel the last update launch ran (csrc/phd_kernels.hip): below 18 the LDS layout and the scan's
+ * length come from the arguments (any filter; PHD_LAYOUT=0 in the environment at phd_create keeps a filter there); 27 ... 35 the layout
+ * of the filter is compiled in (map capacity 512 or 128 with the default survivor capacity), the scan's length is not - every real scan
+ * on such a filter; 18 ... 26 both are compiled in - a full scan (as many measurements as the filter holds: the bench configurations).
+ * Bit for bit the same results; diagnostics; -1 before any launch */
 int phd_debug_update_instantiation(phd_filter* f);
 
 /* ------------------------------------------------------------------------------------
