@@ -59,14 +59,14 @@ def main():
         if line.startswith("loop profile"):               # PHD_DRIVER_PROFILE=1
             print(line)
     t = np.loadtxt(os.path.join(out, "loopTime.log"))
-    # which instantiation of the update kernel the bundled scans ran (csrc/phd_kernels.hip: below 18 the layout and the scan's length
-    # come from the arguments; from 18 they are compiled in — only a scan as long as the filter's measurement capacity gets there)
+    # which instantiation of the update kernel the bundled scans ran (csrc/phd_kernels.hip, include/phdslam.h: phd_debug_update_instantiation)
     inst = [int(m.group(1)) for m in re.finditer(r"inst=(-?\d+)", r.stdout)]
     ms = [int(m.group(1)) for m in re.finditer(r" M=(\d+) ", r.stdout)]
     if inst:
         hist = {k: inst.count(k) for k in sorted(set(inst))}
-        print("update-kernel instantiation over the %d steps: %s (fast path = index >= 18: %d steps); measurements per step min %d, median %d, max %d"
-              % (len(inst), hist, sum(v for k, v in hist.items() if k >= 18), min(ms), int(np.median(ms)), max(ms)))
+        print("update-kernel instantiation over the %d steps: %s (below 18: everything from the arguments; 27 ... 35: the filter's LDS layout compiled in, "
+              "%d steps; 18 ... 26: the layout and a full scan compiled in, %d steps); measurements per step min %d, median %d, max %d"
+              % (len(inst), hist, sum(v for k, v in hist.items() if k >= 27), sum(v for k, v in hist.items() if 18 <= k < 27), min(ms), int(np.median(ms)), max(ms)))
     pf = os.path.join(out, "loopProfile.log")
     if os.path.exists(pf):                                    # PHD_DRIVER_PROFILE=1: which phase do the slow steps spend their time in?
         q = np.loadtxt(pf)
