@@ -74,8 +74,8 @@ class StepReport(C.Structure):
 class SnapshotView(C.Structure):
     """phd_snapshot_view: pointers into the slot's pinned block (valid until the slot is captured again)"""
     _fields_ = [("expected", C.c_void_p), ("map", C.c_void_p), ("poses", C.c_void_p), ("log_weights", C.c_void_p),
-                ("resample_idx", C.c_void_p), ("n_map", C.c_int32), ("particle", C.c_int32), ("n_particles", C.c_int32),
-                ("report", StepReport)]
+                ("resample_idx", C.c_void_p), ("cardinality", C.c_void_p), ("n_map", C.c_int32), ("particle", C.c_int32),
+                ("n_particles", C.c_int32), ("cardinality_len", C.c_int32), ("report", StepReport)]
 
 
 class Control(C.Structure):

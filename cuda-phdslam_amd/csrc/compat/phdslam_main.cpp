@@ -316,7 +316,7 @@ int main(int argc, char** argv)
     double step_t[5] = {0, 0, 0, 0, 0};
     FILE* prof_file = prof ? fopen((out_dir + "/loopProfile.log").c_str(), "w") : nullptr;
 #define PROF_MARK(k) do { if (prof) { const double t_ = now(); acc_t[k] += t_ - tp; step_t[k] = t_ - tp; tp = t_; } } while (0)
-    // ---- the pipelined loop (round 6): the plain configuration — one predicted particle per prior particle, MAP map, PHD filter —
+    // ---- the pipelined loop (round 6): the plain configuration — one predicted particle per prior particle, MAP map, PHD or CPHD filter —
     // runs WITHOUT a host synchronisation inside the step.  run_synth's step is predict -> update -> recoverSlamState -> log ->
     // nEff test -> resample (src/main.cpp:1244-1297), with the host waiting for the device three times; here the host only
     // enqueues: the control noise of step n + 1 and its resampling uniform are drawn by a helper thread (the SAME random stream in
@@ -325,7 +325,7 @@ int main(int argc, char** argv)
     // decided on the device from the same nEff float, and the log of step n is handed to the writers while step n + 1 runs.
     // Same files, character for character (tests/test_gpu_driver.py compares the two loops); PHD_DRIVER_SYNC=1 runs the loop below.
     const bool pipelined = !config.followTrajectory && kshot == 1 && !config.savePrediction && !(config.mapEstimate & 2) &&
-                           config.filterType != 1 && getenv("PHD_DRIVER_SYNC") == nullptr;
+                           getenv("PHD_DRIVER_SYNC") == nullptr;
     if (pipelined) {
         const int n_part = phd_n_particles(f);
         const int sub = config.subdividePredict > 0 ? config.subdividePredict : 1;
@@ -376,6 +376,7 @@ int main(int argc, char** argv)
             j.map.assign(v.map, v.map + v.n_map);
             j.logw.assign(v.log_weights, v.log_weights + n_cur);
             j.poses.assign(v.poses, v.poses + n_cur);
+            if (cphd_log && v.cardinality) j.cn.assign(v.cardinality, v.cardinality + v.cardinality_len);   // cn_estimate (:360)
             if (log7) {
                 j.ridx.resize((size_t)n_cur);
                 if (did && v.resample_idx) std::copy(v.resample_idx, v.resample_idx + n_cur, j.ridx.begin());

@@ -1190,7 +1190,7 @@ extern "C" int phd_state_snapshot(phd_filter* f, phd_pose* expected_out, phd_gau
 // captured on the filter's stream after the update, the report (nEff, the resample decision) is added after the resample launch —
 // but the host no longer waits: a second stream downloads the block while the filter's stream runs the next step.
 // ---------------------------------------------------------------------------------------------
-static size_t snap_words(const phd_filter* f) { return (size_t)PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)8 * f->n_max; }
+static size_t snap_words(const phd_filter* f) { return (size_t)PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)f->cn_len + (size_t)8 * f->n_max; }
 
 static int ensure_snapshot(phd_filter* f)
 {
@@ -1227,7 +1227,7 @@ extern "C" int phd_snapshot_capture(phd_filter* f, int slot)
     // ONE launch: phd_state_snapshot's two kernels restated operation for operation (the same bits) + the copies, straight
     // into the slot's staging block (phd_snapshot.hip)
     HIPCHK(launch_snapshot(f->pose[f->pose_cur], f->logw, f->n, f->n_max, f->maps[f->cur], f->parent[f->pcur], f->counts[f->cur], f->cap,
-                           f->snap_dev[slot], f->stream));
+                           f->cphd ? f->cn[f->cur] : nullptr, f->cn_len, f->snap_dev[slot], f->stream));
     f->snap_state[slot] = 1;
     f->snap_n[slot] = f->n;
     return PHD_OK;
@@ -1240,7 +1240,7 @@ extern "C" int phd_snapshot_send(phd_filter* f, int slot, int want_resample_idx)
     // the report as it stands NOW on the filter's stream (after the resample launch: nEff of the pre-resample weights and the
     // decision), and — for the 7-line log — the parent indices of the resample
     HIPCHK(hipMemcpyAsync(f->snap_dev[slot] + 16, f->report, 8 * 4, hipMemcpyDeviceToDevice, f->stream));
-    size_t words = (size_t)PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)7 * f->n_max;
+    size_t words = (size_t)PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)f->cn_len + (size_t)7 * f->n_max;
     f->snap_idx[slot] = want_resample_idx != 0;
     if (want_resample_idx) {
         HIPCHK(hipMemcpyAsync(f->snap_dev[slot] + words, f->idx, (size_t)f->n * 4, hipMemcpyDeviceToDevice, f->stream));
@@ -1268,8 +1268,10 @@ extern "C" int phd_snapshot_wait(phd_filter* f, int slot, phd_snapshot_view* out
     out->n_map = ((const int32_t*)h)[7];
     out->n_particles = ((const int32_t*)h)[8];
     out->map = (const phd_gaussian2d*)(h + PHD_SNAP_HEADER_WORDS);
-    out->poses = (const phd_pose*)(h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap);
-    out->log_weights = h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)6 * f->n_max;
+    out->cardinality = f->cphd ? h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap : nullptr;
+    out->cardinality_len = f->cphd ? f->cn_len : 0;
+    out->poses = (const phd_pose*)(h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)f->cn_len);
+    out->log_weights = h + PHD_SNAP_HEADER_WORDS + (size_t)7 * f->cap + (size_t)f->cn_len + (size_t)6 * f->n_max;
     out->resample_idx = f->snap_idx[slot] ? (const int32_t*)(out->log_weights + f->n_max) : nullptr;
     unsigned raw[8];
     memcpy(raw, h + 16, sizeof(raw));

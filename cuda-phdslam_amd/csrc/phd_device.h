@@ -191,7 +191,7 @@ hipError_t launch_iota(int* a, int n, hipStream_t st);
 // the pipelined state snapshot (phd_snapshot.hip): words of the staging block before the map
 #define PHD_SNAP_HEADER_WORDS 24
 hipError_t launch_snapshot(const phd_pose* poses, const float* logw, int n, int n_max, const float* slabs, const int* parent,
-                           const int* counts, int cap, float* out, hipStream_t st);
+                           const int* counts, int cap, const float* cn, int cn_len, float* out, hipStream_t st);
 hipError_t launch_fill(float* a, float v, int n, hipStream_t st);
 
 // expected-a-posteriori map / device-wide reduceGaussianMixture (phd_eap.hip)

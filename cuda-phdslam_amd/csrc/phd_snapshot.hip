@@ -30,15 +30,17 @@ __device__ __forceinline__ float snap_block_sum(float v, float* sc, int tid)
 }
 
 // staging block (32-bit words): [0..5] expected pose | [6] arg-max particle | [7] map size | [8] particle count | [9..15] - |
-// [16..23] the step report (copied after the resample launch, phd_snapshot_send) | map: cap x 7 | poses: n_max x 6 | log-weights: n_max |
-// resample indices: n_max (7-line log only)
+// [16..23] the step report (copied after the resample launch, phd_snapshot_send) | map: cap x 7 | CPHD: the arg-max particle's cardinality row,
+// cn_len | poses: n_max x 6 | log-weights: n_max | resample indices: n_max (7-line log only)
 __global__ __launch_bounds__(PHD_SNAP_T) void phd_snapshot_kernel(const phd_pose* __restrict__ poses, const float* __restrict__ logw, int n,
                                                                   int n_max, const float* __restrict__ slabs, const int* __restrict__ parent,
-                                                                  const int* __restrict__ counts, int cap, float* __restrict__ out)
+                                                                  const int* __restrict__ counts, int cap, const float* __restrict__ cn, int cn_len,
+                                                                  float* __restrict__ out)
 {
     const int tid = threadIdx.x;
     float* const o_map = out + PHD_SNAP_HEADER_WORDS;
-    float* const o_pose = o_map + (size_t)7 * cap;
+    float* const o_cn = o_map + (size_t)7 * cap;
+    float* const o_pose = o_cn + cn_len;
     float* const o_logw = o_pose + (size_t)6 * n_max;
     if (blockIdx.x > 0) {
         // ---- the copies: every particle's pose and log-weight
@@ -105,17 +107,19 @@ __global__ __launch_bounds__(PHD_SNAP_T) void phd_snapshot_kernel(const phd_pose
             v.cov[3] = s[5 * cap + i];
             om[i] = v;
         }
+        // CPHD: cn_estimate = the arg-max particle's cardinality row (src/main.cpp:360), indexed like its slab
+        for (int i = tid; i < cn_len; i += PHD_SNAP_T) o_cn[i] = cn[(size_t)src * cn_len + i];
     }
     if (tid == 0) { ((int*)out)[6] = p; ((int*)out)[7] = cnt; ((int*)out)[8] = n; }
 }
 
 hipError_t launch_snapshot(const phd_pose* poses, const float* logw, int n, int n_max, const float* slabs, const int* parent,
-                           const int* counts, int cap, float* out, hipStream_t st)
+                           const int* counts, int cap, const float* cn, int cn_len, float* out, hipStream_t st)
 {
     int copy_blocks = (6 * n + PHD_SNAP_T - 1) / PHD_SNAP_T;
     if (copy_blocks > 32) copy_blocks = 32;
     if (copy_blocks < 1) copy_blocks = 1;
-    hipLaunchKernelGGL(phd_snapshot_kernel, dim3(1 + copy_blocks), dim3(PHD_SNAP_T), 0, st, poses, logw, n, n_max, slabs, parent, counts, cap, out);
+    hipLaunchKernelGGL(phd_snapshot_kernel, dim3(1 + copy_blocks), dim3(PHD_SNAP_T), 0, st, poses, logw, n, n_max, slabs, parent, counts, cap, cn, cn ? cn_len : 0, out);
     return hipGetLastError();
 }
 

@@ -205,6 +205,7 @@ class PhdFilter:
         def arr(addr, dtype, count):
             return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype, count=count).copy()
         idx = arr(v.resample_idx, np.int32, n) if v.resample_idx else None
+        self.last_cardinality = arr(v.cardinality, np.float32, v.cardinality_len) if v.cardinality else None   # (CPHD: cn_estimate)
         self.last_report = v.report
         return (arr(v.expected, POSE, 1)[0], arr(v.map, GAUSSIAN, v.n_map), v.particle, arr(v.poses, POSE, n),
                 arr(v.log_weights, np.float32, n), idx, v.report)

@@ -474,7 +474,8 @@ typedef struct {
     const phd_pose* poses;
     const float* log_weights;
     const int32_t* resample_idx;   /* NULL unless asked for in phd_snapshot_send */
-    int32_t n_map, particle, n_particles;
+    const float* cardinality;      /* CPHD: cn_estimate, the arg-max particle's log cardinality row (src/main.cpp:360); NULL for a PHD filter */
+    int32_t n_map, particle, n_particles, cardinality_len;
     phd_step_report report;
 } phd_snapshot_view;
 int phd_snapshot_capture(phd_filter* f, int slot);

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "cuda-phdslam_amd")
 
 
-def write_dataset(d, n_steps=6, n_particles=48, seed=5):
+def write_dataset(d, n_steps=6, n_particles=48, seed=5, cphd=False):
     S = importlib.import_module("cuda-phdslam_amd.synthetic")
     w = S.make_workload(1, 20, 12, seed=seed, n_meas_sets=n_steps)
     with open(os.path.join(d, "measurements.txt"), "w") as f:
@@ -32,6 +32,9 @@ def write_dataset(d, n_steps=6, n_particles=48, seed=5):
     cfg = cfg.replace("n_particles = 200", "n_particles = %d" % n_particles)
     cfg = cfg.replace("resample_threshold = 0.5", "resample_threshold = 0.97")  # make the nEff trigger fire in a short run
     cfg = cfg.replace("data_directory = /data/synth_bowtie/", "data_directory = %s/" % d)
+    if cphd:
+        assert "filter_type = 0" in cfg and "max_cardinality = 255" in cfg
+        cfg = cfg.replace("filter_type = 0", "filter_type = 1").replace("max_cardinality = 255", "max_cardinality = 63")
     with open(os.path.join(d, "config.cfg"), "w") as f:
         f.write(cfg)
     return os.path.join(d, "config.cfg")
@@ -324,14 +327,16 @@ def test_driver_sharded_equals_single_device(tmp_path, extra, common):
     assert resampled >= 1 or common      # (the device generator's stream happens not to trigger a resample within these six steps)
 
 
-@pytest.mark.parametrize("extra", [[], ["--log7"], ["--device-noise"]], ids=["log5", "log7", "device_noise"])
+@pytest.mark.parametrize("extra", [[], ["--log7"], ["--device-noise"], ["cphd"], ["cphd", "--log7"]], ids=["log5", "log7", "device_noise", "cphd", "cphd_log7"])
 def test_pipelined_loop_writes_the_files_of_the_synchronous_loop(tmp_path, extra):
     """Round 6: the driver's default loop no longer waits for the device inside a step (noise drawn ahead by a helper thread in the
     same order from the same stream, state captured on the device between update and resample, resample decided on the device,
     the log of step n written while step n + 1 runs).  Every state_estimate file must be byte for byte what the step-synchronous
     loop (PHD_DRIVER_SYNC=1: run_synth's own structure, src/main.cpp:1178-1312) writes — resampled steps included."""
     d = str(tmp_path)
-    cfg_path = write_dataset(d, n_steps=12, n_particles=300, seed=11)
+    cphd = "cphd" in extra                       # filter_type = 1: the log's last line is cn_estimate, which rides in the snapshot too
+    extra = [e for e in extra if e != "cphd"]
+    cfg_path = write_dataset(d, n_steps=12, n_particles=300, seed=11, cphd=cphd)
     outs = {}
     for mode in ("pipelined", "sync"):
         out = os.path.join(d, "out_" + mode); os.makedirs(out)
