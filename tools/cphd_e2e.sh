@@ -1,8 +1,11 @@
+#!/bin/bash
+# the bundled simulation with filter_type = 1 (CPHD) through phdslam: pipelined loop against the step-synchronous one (loop time per step,
+# instantiation histogram, a log file's hash)   usage (repo root on the GPU box): bash tools/cphd_e2e.sh
 # CPHD drop-in: the bundled run with filter_type = 1, pipelined vs synchronous loop
 D=$(mktemp -d /tmp/phd_cphd_XXXX)
 python3 tools/e2e_run.py 4096 $D > /dev/null 2>&1
 sed -i 's/^filter_type *=.*/filter_type = 1/' $D/config.cfg
-B=cuda-phdslam_amd/bin/phdslam
+B=$GRAFT_REPO_ROOT/cuda-phdslam_amd/bin/phdslam
 for mode in pipelined sync; do
   rm -rf $D/o; mkdir -p $D/o
   if [ $mode = sync ]; then export PHD_DRIVER_SYNC=1; else unset PHD_DRIVER_SYNC; fi
