@@ -822,11 +822,20 @@ def compare_maps_with_oracle(maps, ref_poses, w, ocfg, picks, what, dlw=None, su
 # the merges — the instantiation bench.py times) against the staged, un-fused calls, bit for bit, on the BASELINE.json
 # workloads themselves, forced and nEff-triggered resampling; plus the oracle on a sample chosen by margin
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg_id,sample", [(2, 256), (3, 256), (5, 64)])
-def test_bench_path_at_bench_size(cfg_id, sample):
+@pytest.mark.parametrize("cfg_id,sample,m_scan", [(2, 256, 0), (3, 256, 0), (5, 64, 0), (3, 64, 44), (5, 32, 27)],
+                         ids=["2-256", "3-256", "5-64", "3-64-scan44", "5-32-scan27"])
+def test_bench_path_at_bench_size(cfg_id, sample, m_scan):
+    """m_scan: a scan of REAL length (44 / 27 of the filter's 64 measurements — round 6): the filter keeps its capacity, so the step
+    runs the instantiations with the LDS layout compiled in and the scan's length from the arguments (27 ... 35), a ragged last
+    chunk in pass 1, the one-shot finish of the merge — at bench size, against the oracle like the full scans."""
     P, S = pkg(), synthetic()
     w = S.config_workload(cfg_id, n_meas_sets=2)
     N, G, M = w["N"], w["G"], w["M"]
+    mm_cap = M
+    if m_scan:
+        w = dict(w)
+        w["z"] = np.ascontiguousarray(w["z"][:, :m_scan])
+        w["M"] = M = m_scan
     cfg = P.default_config()
     if cfg_id == 5:
         cfg.filterType = 1
@@ -834,7 +843,7 @@ def test_bench_path_at_bench_size(cfg_id, sample):
     ocfg = oracle_config_from(cfg)
     import torch
     dev = torch.device("cuda:0")
-    with make_filter(cfg, w, cap=2 * G, mm=M) as a, make_filter(cfg, w, cap=2 * G, mm=M) as b:
+    with make_filter(cfg, w, cap=2 * G, mm=mm_cap) as a, make_filter(cfg, w, cap=2 * G, mm=mm_cap) as b:
         b.debug(5)                                           # staged launches only + survivor inspection
         for k, force in enumerate((True, False)):
             dz = torch.from_numpy(w["z"][k].view(np.uint8).copy()).to(dev)
@@ -842,6 +851,8 @@ def test_bench_path_at_bench_size(cfg_id, sample):
             torch.cuda.synchronize()
             a.step_dev((2.0, 0.05), dn.data_ptr(), dz.data_ptr(), M, w["uniform"][k], force_resample=force)
             a.sync()
+            if m_scan:
+                assert 27 <= P._lib.lib().phd_debug_update_instantiation(a._h) < 36
             b.predict((2.0, 0.05), w["noise"][k])
             b.update(w["z"][k])
             pb_pre, lb_pre = b.get_particles()
